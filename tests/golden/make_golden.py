@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""
+Generate golden vectors from the REFERENCE's own Python code (run in the build
+container only; /root/reference does not exist on the GPU box).
+
+What is pinned here, and by which reference code:
+  * reweighting counts        <- evcouplings/align/alignment.py:1193-1233 num_cluster_members
+  * single / pair frequencies <- evcouplings/align/alignment.py:1079-1153
+  * `.model` plmc_v2 reader   <- evcouplings/couplings/model.py:317-389 (CouplingsModel)
+  * FN / CN (APC) scores      <- evcouplings/couplings/model.py:179-233, 744-827
+  * raw EC file reader        <- evcouplings/couplings/pairs.py:34-65
+
+numba is not installed, so the reference's @jit kernels run as plain Python under an
+identity `numba.jit` stub.  `num_cluster_members` rebinds L to a
+float and then calls range(L) (alignment.py:1216,1225) -- legal under numba, a TypeError
+in CPython -- so it is executed from an in-memory copy with that one call patched to
+range(int(L)).  No reference source is written into this repo.
+
+Usage:  python tests/golden/make_golden.py      (writes tests/golden/*.npz, *.model ...)
+"""
+import importlib.util
+import inspect
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("EVC_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+
+def install_stubs():
+    nb = types.ModuleType("numba")
+
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    nb.jit = jit
+    nb.njit = jit
+    nb.prange = range
+    sys.modules["numba"] = nb
+
+
+def load_reference_module(relpath, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def reference_alignment_kernels():
+    """frequencies / pair_frequencies / num_cluster_members without importing the whole
+    evcouplings package (its __init__ chain needs ruamel/billiard/...)."""
+    path = os.path.join(REF, "evcouplings/align/alignment.py")
+    src = open(path).read()
+    ns = {"np": np, "jit": sys.modules["numba"].jit}
+    out = {}
+    import ast
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in (
+                "frequencies", "pair_frequencies", "num_cluster_members"):
+            text = ast.get_source_segment(src, node)
+            # strip decorator line(s)
+            text = "\n".join(l for l in text.split("\n") if not l.strip().startswith("@jit"))
+            if node.name == "num_cluster_members":
+                assert "for k in range(L):" in text
+                text = text.replace("for k in range(L):", "for k in range(int(L)):")
+            exec(compile(text, path, "exec"), ns)
+            out[node.name] = ns[node.name]
+    assert len(out) == 3
+    return out
+
+
+def main():
+    install_stubs()
+    from evcouplings_amd.synthetic import synthetic_msa, ALPHABET_PROTEIN
+    from evcouplings_amd import model_io
+
+    kern = reference_alignment_kernels()
+    model_mod = load_reference_module("evcouplings/couplings/model.py", "ref_model")
+    q = 21
+
+    # ---- (1) reweighting + frequencies on small alignments, incl. threshold edge cases
+    cases = {}
+    for name, (N, L, theta, seed) in {
+        "a": (96, 20, 0.8, 1), "b": (150, 37, 0.8, 2), "c": (64, 25, 0.6, 3), "d": (80, 10, 0.3, 4),
+    }.items():
+        msa, _ = synthetic_msa(N, L, seed=seed)
+        # craft rows that sit exactly on / one off the identity threshold
+        T = int(np.ceil(theta * L - 1e-9))
+        base = msa[1].copy()
+        for k, nid in enumerate((T - 1, T, T + 1)):
+            nid = max(0, min(L, nid))
+            row = base.copy()
+            mism = np.arange(L - nid)
+            row[mism] = (row[mism] % 20) + 1  # force a different non-gap state
+            assert (row == base).sum() == nid
+            msa[2 + k] = row
+        counts = kern["num_cluster_members"](msa.astype(np.int64), theta)
+        w = 1.0 / counts
+        fi = kern["frequencies"](msa.astype(np.int64), w, q)
+        fij = kern["pair_frequencies"](msa.astype(np.int64), w, q, fi)
+        cases[name] = dict(msa=msa, theta=theta, counts=counts.astype(np.int32), fi=fi, fij=fij)
+    np.savez_compressed(
+        os.path.join(HERE, "reweight_freqs.npz"),
+        **{"%s_%s" % (k, f): v for k, d in cases.items() for f, v in d.items()})
+
+    # ---- (2) scoring + file formats: random parameters -> our writer -> reference reader
+    rng = np.random.default_rng(7)
+    L, N = 12, 30
+    npair = L * (L - 1) // 2
+    hi = rng.normal(size=(L, q)).astype(np.float32)
+    jij = (0.3 * rng.normal(size=(npair, q, q))).astype(np.float32)
+    fi = rng.dirichlet(np.ones(q), size=L).astype(np.float32)
+    fij = rng.dirichlet(np.ones(q * q), size=npair).reshape(npair, q, q).astype(np.float32)
+    weights = rng.random(N).astype(np.float32)
+    target = "".join(ALPHABET_PROTEIN[1 + k % 20] for k in range(L))
+    index_list = np.arange(5, 5 + L, dtype=np.int32)
+    index_list[6:] += 3  # numbering gap, as lowercase-skipped columns would leave
+    model_path = os.path.join(HERE, "tiny_L12.model")
+    model_io.write_model_file(
+        model_path, L=L, q=q, n_valid=N, n_invalid=2, num_iter=100, theta=0.2, lambda_h=0.01,
+        lambda_j=2.2, lambda_group=0.0, n_eff=17.25, alphabet=ALPHABET_PROTEIN,
+        weights=np.concatenate([weights, np.zeros(2, np.float32)]), target_seq=target,
+        index_list=index_list, fi=fi, hi=hi, fij=fij, jij=jij)
+    m = model_mod.CouplingsModel(model_path)
+    assert m.L == L and m.num_symbols == q and m.N_valid == N and m.N_invalid == 2
+    iu = np.triu_indices(L, 1)
+    np.testing.assert_array_equal(m.J_ij[iu].astype(np.float32), jij)
+    np.testing.assert_array_equal(m.J_ij[iu[1], iu[0]].astype(np.float32), jij.transpose(0, 2, 1))
+    np.testing.assert_array_equal(m.h_i.astype(np.float32), hi)
+    np.testing.assert_array_equal(m.index_list, index_list)
+    assert "".join(m.target_seq) == target
+    ecs = m.ecs.sort_values(["i", "j"])
+    np.savez_compressed(
+        os.path.join(HERE, "scores_L12.npz"), hi=hi, jij=jij, fi=fi, fij=fij, weights=weights,
+        index_list=index_list, target=np.array(target), fn=m.fn_scores, cn=m.cn_scores,
+        ecs_i=ecs["i"].values, ecs_j=ecs["j"].values, ecs_cn=ecs["cn"].values,
+        ecs_fn=ecs["fn"].values, theta=np.float32(0.2), lambda_h=np.float32(0.01),
+        lambda_j=np.float32(2.2), n_eff=np.float32(17.25))
+
+    # ---- (3) raw EC file: our writer -> reference reader semantics (pairs.py:55-58 is a
+    # plain pandas read_csv with these column names; pairs.py itself needs sklearn/scipy
+    # and the evcouplings package chain, so the call is restated on the spot)
+    import pandas as pd
+    ec_path = os.path.join(HERE, "tiny_L12_ECs.txt")
+    model_io.write_raw_ec_file(ec_path, index_list, target, m.cn_scores)
+    tab = pd.read_csv(ec_path, sep=" ", names=["i", "A_i", "j", "A_j", "fn", "cn"])
+    assert len(tab) == npair and (tab["fn"] == 0).all()
+    np.testing.assert_allclose(tab.sort_values(["i", "j"])["cn"].values, ecs["cn"].values, atol=5.1e-7)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
