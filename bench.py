@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""
+bench.py -- L-BFGS iterations/s of the MI355X pseudo-likelihood Potts solver on the
+BASELINE.json headline workload (synthetic MSA, L=300, q=21, N=50 000).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one L-BFGS iteration of the fit (line-search evaluations + two-loop recursion
+included) on the alignment already resident in HBM.  W warm-up iterations are followed by
+exactly K timed iterations, bracketed by barrier + device synchronise; rank 0 prints one
+JSON line.  With N > 1 the sites of the ONE problem are sharded across the ranks
+(strong scaling); the exchange is an RCCL all-gather (evcouplings_amd/dist.py).
+
+Extra blocks on the same line:
+  roofline      dominant kernel (HIP events inside the library, on the stream it launches on)
+  cpu_baseline  the oracle's float32/OpenMP build timed on this host on a bounded sample
+  fit           wall-clock of a whole fit to |g|/|x| < 1e-3 (the reference default stop rule)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HEADLINE = dict(L=300, N=50000, q=21, seed_offset=1)
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
+PEAK_F32_VALU_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-seqs", type=int, default=HEADLINE["N"])
+    ap.add_argument("--n-sites", type=int, default=HEADLINE["L"])
+    ap.add_argument("--no-fit", action="store_true", help="skip the whole-fit timing")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    from evcouplings_amd import plm
+    from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    q, L, N = HEADLINE["q"], args.n_sites, args.n_seqs
+    msa, _ = synthetic_msa(N, L, seed=BASE_SEED + HEADLINE["seed_offset"])
+    lam_j = plm.default_lambda_j(L, q)
+
+    # --- set-up (untimed): upload, reweight, marginals, start point ------------------------
+    t_setup = time.time()
+    ctx1 = plm.PlmContext(msa, q=q, lambda_h=0.01, lambda_j=lam_j, device=local_rank, max_iter=args.warmup,
+                          epsilon=1e-12)
+    w, counts, n_eff = ctx1.reweight()
+    ctx1.marginals(pairs=False)
+    ctx1.set_x(None)
+    if world > 1:
+        from evcouplings_amd.dist import make_torch_exchange
+        x0 = ctx1.get_x()
+        ctx1.close()
+        ctx = plm.PlmContext(msa, q=q, lambda_h=0.01, lambda_j=lam_j, device=local_rank, n_shards=world,
+                             shard=rank, max_iter=args.warmup, epsilon=1e-12)
+        ctx.set_weights(w)
+        ctx.set_exchange(make_torch_exchange())
+        ctx.set_x(x0)
+    else:
+        ctx = ctx1
+    t_setup = time.time() - t_setup
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # --- warm-up: W iterations; timed: exactly K more iterations ---------------------------
+    import ctypes as C
+    from evcouplings_amd import _lib
+
+    def run_iters(k):
+        # re-create the problem's iteration cap through a fresh optimise call from the current x
+        ctx._set_max_iter(k)
+        return ctx.optimize()
+
+    if args.warmup > 0:
+        run_iters(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    res = run_iters(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert res["iters"] == args.steps, res
+
+    out = {
+        "metric": "plmc L-BFGS iterations/sec (PLM fit, synthetic MSA)",
+        "value": args.steps / dt,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32 (f16 hi/lo split operands, f32 MFMA accumulation)",
+        "data": "synthetic",
+        "config": {"workload": "headline: synthetic MSA L=%d q=%d N=%d, theta=0.8, lambda_h=0.01, lambda_J=%.1f"
+                               % (L, q, N, lam_j),
+                   "n_eff": n_eff, "parallelism": "sites sharded x%d" % world,
+                   "evals_per_iteration": res["n_evals"] / max(1, res["iters"])},
+    }
+
+    if rank == 0 and world == 1:
+        # --- roofline of the dominant kernel (HIP events on the library's stream) ----------
+        km = ctx.time_kernels(reps=5)
+        dom = "forward" if km["forward"] >= km["backward"] else "backward"
+        t_dom = km[dom] * 1e-3
+        flops_dense = 2.0 * N * (L * q) ** 2            # one one-hot GEMM (flops_dense / 2)
+        flops_alg = 1.0 * N * L * (L - 1) * q           # gathered adds of one half (flops_alg / 2)
+        P = L * q + L * (L - 1) // 2 * q * q
+        bytes_alg = N * L + 4 * N + 8 * P
+        out["roofline"] = {
+            "kernel": "k_fwd" if dom == "forward" else "k_bwd",
+            "bound": "mfma",
+            "achieved": flops_dense / t_dom / 1e12,
+            "peak": PEAK_F16_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": flops_dense / t_dom / 1e12 / PEAK_F16_MFMA_TFLOPS,
+            "traffic": None,
+            "definition": "one-hot GEMM flops 2*N*(L*q)^2 per launch / HIP-event time; executed MFMA work is 2x "
+                          "that (f16 hi+lo planes) plus padding",
+            "alg_gather_tflops": flops_alg / t_dom / 1e12,
+            "alg_gather_frac_of_f32_valu": flops_alg / t_dom / 1e12 / PEAK_F32_VALU_TFLOPS,
+            "eval_hbm_alg_bytes": bytes_alg,
+            "eval_hbm_alg_frac": bytes_alg / (km["total"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "kernel_ms": km,
+        }
+        # --- whole fit to the reference's default stop rule ---------------------------------
+        if not args.no_fit:
+            t1 = time.perf_counter()
+            fit = plm.fit(msa, q, lambda_h=0.01, lambda_j=lam_j, max_iter=0, epsilon=1e-3, device=local_rank,
+                          want_fij=False)
+            out["fit"] = {"seconds_total": time.perf_counter() - t1, "iterations": fit["iters"],
+                          "evaluations": fit["n_evals"], "status": fit["status_msg"],
+                          "seconds": fit["seconds"], "epsilon": 1e-3}
+        # --- CPU baseline: oracle f32 + OpenMP on a bounded sample ---------------------------
+        if not args.no_cpu:
+            from oracle.oracle import Oracle
+            orc = Oracle("f32")
+            ns = min(N, 1500)
+            sub = np.ascontiguousarray(msa[:ns])
+            wsub = w[:ns].astype(np.float32)
+            x = np.zeros(plm.n_params(L, q), np.float32)
+            orc.eval(sub, wsub, q, 0.01, lam_j, x)      # touch
+            reps, t2 = 0, time.perf_counter()
+            while reps < 2 or time.perf_counter() - t2 < 8.0:
+                orc.eval(sub, wsub, q, 0.01, lam_j, x)
+                reps += 1
+            per_eval_full = (time.perf_counter() - t2) / reps * (N / ns)
+            epi = res["n_evals"] / max(1, res["iters"])
+            out["cpu_baseline"] = {
+                "value": 1.0 / (per_eval_full * epi), "unit": "iterations/s", "cores": orc.num_threads(),
+                "kind": "port",
+                "sample": "oracle f32/OpenMP objective+gradient on the first %d of %d sequences (L=%d), %d reps, "
+                          "scaled by N/%d and by the GPU run's %.2f evaluations per iteration" % (ns, N, L, reps, ns, epi),
+            }
+    if rank == 0:
+        out["setup_seconds"] = t_setup
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,936 @@
+// plm_host.cpp -- context, evaluation pipeline, L-BFGS driver and the C ABI of libplm_hip.so
+// (include/plm_hip.h).  Replaces the plmc child process of evcouplings/couplings/tools.py:266.
+// No CPU fallback exists: every entry point needs a gfx950 device and fails with
+// PLM_EDEVICE otherwise.
+#include "../../include/plm_hip.h"
+#include "plm_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(e__ == hipErrorOutOfMemory ? PLM_ENOMEM : PLM_EDEVICE, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e__), __FILE__, __LINE__);                        \
+    } while (0)
+#define PLM_TRY(expr)                  \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__ != PLM_OK) return rc__; \
+    } while (0)
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int check_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PLM_EDEVICE, "no HIP device visible (libplm_hip has no CPU path)");
+    if (device < 0 || device >= n) return fail(PLM_EINVAL, "device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PLM_EDEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    return PLM_OK;
+}
+
+int make_dims(const plm_problem_t &p, PlmDims *out) {
+    PlmDims d;
+    memset(&d, 0, sizeof d);
+    if (p.n_seqs <= 0 || p.n_sites <= 1) return fail(PLM_EINVAL, "need n_seqs > 0 and n_sites > 1");
+    if (!plm_q_supported(p.n_states))
+        return fail(PLM_EUNSUPPORTED, "alphabet size %d not instantiated (supported: 21, 20, 5, 4)", p.n_states);
+    const int nshards = p.n_shards > 0 ? p.n_shards : 1;
+    if (p.shard < 0 || p.shard >= nshards) return fail(PLM_EINVAL, "shard %d outside 0..%d", p.shard, nshards - 1);
+    d.N = p.n_seqs;
+    d.L = p.n_sites;
+    d.Q = p.n_states;
+    d.Np = (d.N + PLM_SEQ_TILE - 1) / PLM_SEQ_TILE * PLM_SEQ_TILE;
+    d.nb16 = (d.L + 15) / 16;
+    d.Lp16 = d.nb16 * 16;
+    d.nu = (d.L + 31) / 32;
+    d.Lp32 = d.nu * 32;
+    d.nksteps = d.nu * d.Q;
+    d.nssteps = d.Np / 32;
+    d.nstiles = d.Np / PLM_SEQ_TILE;
+    plm_pick_tile(d.Q, &d.FM, &d.FN);
+    d.nmf = d.nb16 * d.Q + d.FM;
+    d.nshards = nshards;
+    d.shard = p.shard;
+    d.blk_per_shard = (d.nb16 + nshards - 1) / nshards;
+    d.b16_lo = std::min(d.nb16, d.shard * d.blk_per_shard);
+    d.b16_hi = std::min(d.nb16, d.b16_lo + d.blk_per_shard);
+    d.nnfl = d.blk_per_shard * d.Q;
+    d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
+    d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
+    int ks = (1536 + d.nrow_tiles * d.ncol_tiles - 1) / (d.nrow_tiles * d.ncol_tiles);
+    ks = std::max(1, std::min(ks, 16));
+    ks = std::min(ks, std::max(1, d.nssteps / 8));
+    d.ksplit = ks;
+    d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
+    d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
+    d.n_native = d.nh_pad + d.nbp * d.Q * d.Q * 256;
+    d.n_canon = (int64_t)d.L * d.Q + (int64_t)d.L * (d.L - 1) / 2 * d.Q * d.Q;
+    *out = d;
+    return PLM_OK;
+}
+
+}  // namespace
+
+struct plm_ctx {
+    plm_problem_t prob;
+    PlmDims d;
+    int device = 0;
+    hipStream_t st = nullptr;
+    plm_exchange_cb exchange = nullptr;
+    void *exchange_user = nullptr;
+    // device buffers
+    int8_t *msa_rm = nullptr, *msa_cm = nullptr;
+    float *w = nullptr;
+    int32_t *counts = nullptr;
+    void *Bt = nullptr, *Rt = nullptr;
+    float *G = nullptr;        // split-K partial slabs (local)
+    float *gather = nullptr;   // exchange buffer [nshards][slab] (nshards > 1 only)
+    double *fx_part = nullptr, *reg_part = nullptr, *dot_scratch = nullptr, *scal = nullptr;
+    uint32_t *maxbits = nullptr;
+    int32_t *jexp = nullptr;
+    float *x = nullptr, *g = nullptr, *xp = nullptr, *gp = nullptr, *dir = nullptr, *hist = nullptr;
+    float *canon = nullptr;    // canonical-layout staging (n_canon floats, + L*L for fn)
+    int hist_m = 0;
+    double *h_scal = nullptr;  // pinned host scalars
+    bool have_weights = false;
+    double n_eff = 0;
+    int n_evals = 0;
+    std::vector<float> h_fi;   // L*q, kept for the start point
+
+    int n_fx_part() const { return d.nstiles * (d.b16_hi - d.b16_lo); }
+};
+
+namespace {
+
+template <typename T> int dalloc(T **p, size_t n_elems) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n_elems, 1) * sizeof(T));
+    if (e != hipSuccess)
+        return fail(PLM_ENOMEM, "hipMalloc of %zu bytes failed: %s", n_elems * sizeof(T), hipGetErrorString(e));
+    *p = (T *)q;
+    return PLM_OK;
+}
+
+int ctx_alloc_lbfgs(plm_ctx *c, int m) {
+    if (c->xp && c->hist_m >= m) return PLM_OK;
+    const size_t n = (size_t)c->d.n_native;
+    if (!c->xp) {
+        PLM_TRY(dalloc(&c->xp, n));
+        PLM_TRY(dalloc(&c->gp, n));
+        PLM_TRY(dalloc(&c->dir, n));
+    }
+    if (c->hist) hipFree(c->hist);
+    c->hist = nullptr;
+    PLM_TRY(dalloc(&c->hist, n * 2 * (size_t)m));
+    c->hist_m = m;
+    return PLM_OK;
+}
+
+// enqueue one objective+gradient evaluation at c->x -> c->g, scal[0] = fx, scal[1] = nll
+int ctx_eval_enqueue(plm_ctx *c) {
+    const PlmDims &d = c->d;
+    HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
+    HIP_TRY(plm_launch_expand(d, c->x, c->jexp, c->Bt, c->st));
+    HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
+    HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    const float *Gsrc = c->G;
+    int ks_count = d.ksplit, n_shard_nll = 0;
+    const double *shard_nll = nullptr;
+    if (d.nshards > 1) {
+        const size_t slab = plm_slab_bytes(d);
+        char *mine = (char *)c->gather + (size_t)d.shard * slab;
+        HIP_TRY(plm_launch_slab_reduce(d, c->G, (float *)mine, c->st));
+        HIP_TRY(plm_launch_partial_sum(c->fx_part, c->n_fx_part(), (double *)(mine + slab - 256), c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        if (!c->exchange) return fail(PLM_EINVAL, "n_shards > 1 but no exchange callback set");
+        if (c->exchange(c->gather, slab, d.nshards, d.shard, c->exchange_user) != 0)
+            return fail(PLM_ECALLBACK, "exchange callback failed");
+        Gsrc = c->gather;
+        ks_count = 1;
+        n_shard_nll = d.nshards;
+        shard_nll = (const double *)((char *)c->gather + slab - 256);
+    }
+    HIP_TRY(plm_launch_assemble(d, Gsrc, ks_count, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j, c->reg_part, 0,
+                                0.f, c->st));
+    HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), shard_nll, n_shard_nll, c->reg_part,
+                                 plm_reg_parts(d), c->scal, c->st));
+    c->n_evals++;
+    return PLM_OK;
+}
+
+int fetch_scalars(plm_ctx *c, int first, int count) {
+    HIP_TRY(hipMemcpyAsync(c->h_scal + first, c->scal + first, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return PLM_OK;
+}
+
+// scal slots: 0 fx, 1 nll, 2.. dot results
+int dots(plm_ctx *c, int npairs, const float *const *a, const float *const *b, int64_t n, int slot) {
+    HIP_TRY(plm_launch_dots(npairs, a, b, n, c->dot_scratch, c->scal + slot, c->st));
+    return PLM_OK;
+}
+
+// ---- More'-Thuente trial-step update (More' & Thuente 1994, sec. 4); scalar host code -------
+int mt_update(double *stx, double *fx, double *dx, double *sty, double *fy, double *dy, double *stp, double fp,
+              double dp, double tmin, double tmax, int *brackt) {
+    if (*brackt && (*stp <= std::min(*stx, *sty) || *stp >= std::max(*stx, *sty))) return -1;
+    if (*dx * (*stp - *stx) >= 0.0 || tmax < tmin) return -1;
+    const double sgnd = dp * (*dx / std::fabs(*dx));
+    double stpf, stpc, stpq, gamma, p, q, r, s, theta;
+    bool bound;
+    if (fp > *fx) {
+        bound = true;
+        theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+        s = std::max(std::fabs(theta), std::max(std::fabs(*dx), std::fabs(dp)));
+        gamma = s * std::sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+        if (*stp < *stx) gamma = -gamma;
+        p = (gamma - *dx) + theta;
+        q = ((gamma - *dx) + gamma) + dp;
+        r = p / q;
+        stpc = *stx + r * (*stp - *stx);
+        stpq = *stx + ((*dx / ((*fx - fp) / (*stp - *stx) + *dx)) / 2.0) * (*stp - *stx);
+        stpf = (std::fabs(stpc - *stx) < std::fabs(stpq - *stx)) ? stpc : stpc + (stpq - stpc) / 2.0;
+        *brackt = 1;
+    } else if (sgnd < 0.0) {
+        bound = false;
+        theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+        s = std::max(std::fabs(theta), std::max(std::fabs(*dx), std::fabs(dp)));
+        gamma = s * std::sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+        if (*stp > *stx) gamma = -gamma;
+        p = (gamma - dp) + theta;
+        q = ((gamma - dp) + gamma) + *dx;
+        r = p / q;
+        stpc = *stp + r * (*stx - *stp);
+        stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+        stpf = (std::fabs(stpc - *stp) > std::fabs(stpq - *stp)) ? stpc : stpq;
+        *brackt = 1;
+    } else if (std::fabs(dp) < std::fabs(*dx)) {
+        bound = true;
+        theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+        s = std::max(std::fabs(theta), std::max(std::fabs(*dx), std::fabs(dp)));
+        gamma = s * std::sqrt(std::max(0.0, (theta / s) * (theta / s) - (*dx / s) * (dp / s)));
+        if (*stp > *stx) gamma = -gamma;
+        p = (gamma - dp) + theta;
+        q = (gamma + (*dx - dp)) + gamma;
+        r = p / q;
+        if (r < 0.0 && gamma != 0.0) stpc = *stp + r * (*stx - *stp);
+        else stpc = (*stp > *stx) ? tmax : tmin;
+        stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+        if (*brackt) stpf = (std::fabs(*stp - stpc) < std::fabs(*stp - stpq)) ? stpc : stpq;
+        else stpf = (std::fabs(*stp - stpc) > std::fabs(*stp - stpq)) ? stpc : stpq;
+    } else {
+        bound = false;
+        if (*brackt) {
+            theta = 3.0 * (fp - *fy) / (*sty - *stp) + *dy + dp;
+            s = std::max(std::fabs(theta), std::max(std::fabs(*dy), std::fabs(dp)));
+            gamma = s * std::sqrt((theta / s) * (theta / s) - (*dy / s) * (dp / s));
+            if (*stp > *sty) gamma = -gamma;
+            p = (gamma - dp) + theta;
+            q = ((gamma - dp) + gamma) + *dy;
+            r = p / q;
+            stpf = *stp + r * (*sty - *stp);
+        } else {
+            stpf = (*stp > *stx) ? tmax : tmin;
+        }
+    }
+    if (fp > *fx) {
+        *sty = *stp; *fy = fp; *dy = dp;
+    } else {
+        if (sgnd < 0.0) { *sty = *stx; *fy = *fx; *dy = *dx; }
+        *stx = *stp; *fx = fp; *dx = dp;
+    }
+    stpf = std::max(tmin, std::min(tmax, stpf));
+    *stp = stpf;
+    if (*brackt && bound) {
+        const double lim = *stx + 0.66 * (*sty - *stx);
+        *stp = (*sty > *stx) ? std::min(lim, *stp) : std::max(lim, *stp);
+    }
+    return 0;
+}
+
+const char *status_text(int status) {
+    switch (status) {
+    case PLM_STATUS_CONVERGED: return "converged (|g|/max(1,|x|) below epsilon)";
+    case PLM_STATUS_MAXITER: return "maximum number of iterations reached";
+    default: return "line search could not improve further (treated as converged to precision)";
+    }
+}
+
+int set_start_point(plm_ctx *c) {
+    // h_i(a) = log(f_i(a) + 1/N_eff) minus the site mean, J = 0
+    const PlmDims &d = c->d;
+    if (c->h_fi.empty()) return fail(PLM_EINVAL, "start point needs single-site frequencies: run marginals first");
+    std::vector<float> h((size_t)d.nh_pad, 0.f);
+    for (int i = 0; i < d.L; i++) {
+        double mean = 0;
+        std::vector<double> v(d.Q);
+        for (int a = 0; a < d.Q; a++) {
+            v[a] = std::log((double)c->h_fi[(size_t)i * d.Q + a] + 1.0 / c->n_eff);
+            mean += v[a];
+        }
+        mean /= d.Q;
+        for (int a = 0; a < d.Q; a++) h[(size_t)i * d.Q + a] = (float)(v[a] - mean);
+    }
+    HIP_TRY(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_native, c->st));
+    HIP_TRY(hipMemcpyAsync(c->x, h.data(), sizeof(float) * d.nh_pad, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return PLM_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int plm_version(void) { return PLM_ABI_VERSION; }
+
+int plm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return fail(PLM_EDEVICE, "hipGetDeviceCount failed");
+    return n;
+}
+
+const char *plm_strerror(int code) {
+    switch (code) {
+    case PLM_OK: return "ok";
+    case PLM_EINVAL: return "invalid argument";
+    case PLM_ENOMEM: return "out of memory";
+    case PLM_EDEVICE: return "HIP device error";
+    case PLM_EUNSUPPORTED: return "unsupported alphabet size";
+    case PLM_ENUMERIC: return "non-finite value in objective";
+    case PLM_ECALLBACK: return "exchange callback failed";
+    default: return "unknown error";
+    }
+}
+
+const char *plm_last_error(void) { return g_err.c_str(); }
+
+void plm_ctx_destroy(plm_ctx_t *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
+                    c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
+                    c->canon};
+    for (void *b : bufs)
+        if (b) hipFree(b);
+    if (c->h_scal) hipHostFree(c->h_scal);
+    delete c;
+}
+
+int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_t **out) {
+    if (!prob || !out || !prob->msa) return fail(PLM_EINVAL, "NULL problem / msa / out");
+    *out = nullptr;
+    PLM_TRY(check_device(device));
+    PlmDims d;
+    PLM_TRY(make_dims(*prob, &d));
+    if (!(prob->theta_id >= 0.f && prob->theta_id <= 1.f)) return fail(PLM_EINVAL, "theta_id must be in [0,1]");
+    if (prob->lambda_h < 0 || prob->lambda_j < 0) return fail(PLM_EINVAL, "negative regularisation strength");
+    for (size_t k = 0; k < (size_t)d.N * d.L; k++)
+        if (prob->msa[k] < 0 || prob->msa[k] >= d.Q)
+            return fail(PLM_EINVAL, "msa[%zu] = %d outside 0..%d", k, (int)prob->msa[k], d.Q - 1);
+    plm_ctx *c = new plm_ctx();
+    c->prob = *prob;
+    c->prob.msa = nullptr;  // host pointer not retained
+    c->d = d;
+    c->device = device;
+    c->st = (hipStream_t)stream;
+    int rc = PLM_OK;
+    auto bail = [&](int code) {
+        plm_ctx_destroy(c);
+        return code;
+    };
+    // padded host images of the alignment (row- and column-major)
+    const size_t rm_rows = (size_t)d.Np + 32, cm_rows = (size_t)(d.nb16 + 1) * 16;
+    std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE), cm(cm_rows * d.Np, (int8_t)PLM_PAD_STATE);
+    for (int s = 0; s < d.N; s++) {
+        const int8_t *row = prob->msa + (size_t)s * d.L;
+        memcpy(&rm[(size_t)s * d.Lp32], row, d.L);
+        for (int i = 0; i < d.L; i++) cm[(size_t)i * d.Np + s] = row[i];
+        cm[(size_t)(d.nb16 * 16) * d.Np + s] = 0;  // "ones" column: state 0 for every real sequence
+    }
+    if ((rc = dalloc(&c->msa_rm, rm.size())) || (rc = dalloc(&c->msa_cm, cm.size())) ||
+        (rc = dalloc(&c->w, (size_t)d.Np)) || (rc = dalloc(&c->counts, (size_t)d.Np)) ||
+        (rc = dalloc((char **)&c->Bt, plm_bt_bytes(d))) || (rc = dalloc((char **)&c->Rt, plm_rt_bytes(d))) ||
+        (rc = dalloc((char **)&c->G, plm_g_bytes(d))) || (rc = dalloc(&c->fx_part, (size_t)c->n_fx_part())) ||
+        (rc = dalloc(&c->reg_part, (size_t)plm_reg_parts(d))) ||
+        (rc = dalloc(&c->dot_scratch, (size_t)4 * PLM_DOT_BLOCKS)) || (rc = dalloc(&c->scal, (size_t)64)) ||
+        (rc = dalloc(&c->maxbits, (size_t)1)) || (rc = dalloc(&c->jexp, (size_t)1)) ||
+        (rc = dalloc(&c->x, (size_t)d.n_native)) || (rc = dalloc(&c->g, (size_t)d.n_native)) ||
+        (rc = dalloc(&c->canon, (size_t)d.n_canon + (size_t)d.L * d.L)))
+        return bail(rc);
+    if (d.nshards > 1 && (rc = dalloc((char **)&c->gather, plm_slab_bytes(d) * d.nshards))) return bail(rc);
+    hipError_t e;
+    if ((e = hipHostMalloc((void **)&c->h_scal, sizeof(double) * 64)) != hipSuccess)
+        return bail(fail(PLM_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e)));
+#define CT(expr)                                                                                  \
+    if ((e = (expr)) != hipSuccess)                                                               \
+        return bail(fail(PLM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e)));
+    CT(hipMemcpyAsync(c->msa_rm, rm.data(), rm.size(), hipMemcpyHostToDevice, c->st));
+    CT(hipMemcpyAsync(c->msa_cm, cm.data(), cm.size(), hipMemcpyHostToDevice, c->st));
+    CT(hipMemsetAsync(c->w, 0, sizeof(float) * d.Np, c->st));
+    CT(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(d), c->st));
+    CT(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_native, c->st));
+    CT(hipMemsetAsync(c->g, 0, sizeof(float) * d.n_native, c->st));
+    if (c->gather) CT(hipMemsetAsync(c->gather, 0, plm_slab_bytes(d) * d.nshards, c->st));
+    CT(hipStreamSynchronize(c->st));
+#undef CT
+    *out = c;
+    return PLM_OK;
+}
+
+int plm_ctx_set_exchange(plm_ctx_t *c, plm_exchange_cb exchange, void *user) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    c->exchange = exchange;
+    c->exchange_user = user;
+    return PLM_OK;
+}
+
+int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, float epsilon, int32_t lbfgs_m) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    if (max_iter >= 0) c->prob.max_iter = max_iter;
+    if (epsilon >= 0) c->prob.epsilon = epsilon;
+    if (lbfgs_m >= 0) c->prob.lbfgs_m = lbfgs_m;
+    return PLM_OK;
+}
+
+int64_t plm_ctx_native_size(const plm_ctx_t *c) { return c ? c->d.n_native : 0; }
+
+int plm_ctx_set_weights(plm_ctx_t *c, const float *weights_host) {
+    if (!c || !weights_host) return fail(PLM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const PlmDims &d = c->d;
+    double neff = 0;
+    float wmax = 0;
+    for (int s = 0; s < d.N; s++) {
+        if (!(weights_host[s] >= 0.f) || !std::isfinite(weights_host[s]))
+            return fail(PLM_EINVAL, "weight %d is negative or not finite", s);
+        neff += weights_host[s];
+        wmax = std::max(wmax, weights_host[s]);
+    }
+    if (wmax >= 3.99f) return fail(PLM_EINVAL, "sequence weights must be < 3.99 (got %g): lower `scale`", wmax);
+    if (!(neff > 0)) return fail(PLM_EINVAL, "sum of weights is zero");
+    HIP_TRY(hipMemsetAsync(c->w, 0, sizeof(float) * d.Np, c->st));
+    HIP_TRY(hipMemcpyAsync(c->w, weights_host, sizeof(float) * d.N, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    c->n_eff = neff;
+    c->have_weights = true;
+    return PLM_OK;
+}
+
+int plm_ctx_reweight(plm_ctx_t *c) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    const PlmDims &d = c->d;
+    const int thresh = (int)std::ceil((double)c->prob.theta_id * d.L - 1e-9);
+    std::vector<int32_t> counts(d.N);
+    if (thresh <= 0) {
+        std::fill(counts.begin(), counts.end(), d.N);  // every pair is a neighbour
+        HIP_TRY(hipMemcpyAsync(c->counts, counts.data(), sizeof(int32_t) * d.N, hipMemcpyHostToDevice, c->st));
+    } else {
+        HIP_TRY(plm_launch_reweight(d, c->msa_rm, thresh, c->counts, c->st));
+        HIP_TRY(hipMemcpyAsync(counts.data(), c->counts, sizeof(int32_t) * d.N, hipMemcpyDeviceToHost, c->st));
+    }
+    HIP_TRY(hipStreamSynchronize(c->st));
+    std::vector<float> w(d.N);
+    const float scale = c->prob.scale > 0 ? c->prob.scale : 1.f;
+    for (int s = 0; s < d.N; s++) {
+        if (counts[s] < 1) return fail(PLM_ENUMERIC, "sequence %d has cluster size %d", s, counts[s]);
+        w[s] = scale / (float)counts[s];
+    }
+    return plm_ctx_set_weights(c, w.data());
+}
+
+int plm_ctx_get_weights(plm_ctx_t *c, float *weights_host, int32_t *counts_host, float *n_eff) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (weights_host) HIP_TRY(hipMemcpy(weights_host, c->w, sizeof(float) * c->d.N, hipMemcpyDeviceToHost));
+    if (counts_host) HIP_TRY(hipMemcpy(counts_host, c->counts, sizeof(int32_t) * c->d.N, hipMemcpyDeviceToHost));
+    if (n_eff) *n_eff = (float)c->n_eff;
+    return PLM_OK;
+}
+
+int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set: call plm_ctx_reweight / plm_ctx_set_weights");
+    if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "marginals run unsharded (create a 1-shard context)");
+    HIP_TRY(hipSetDevice(c->device));
+    const PlmDims &d = c->d;
+    // weighted one-hot Gram matrix through the backward GEMM: G = X^T diag(w) X
+    HIP_TRY(plm_launch_onehot_rt(d, c->msa_rm, c->w, c->Rt, c->st));
+    HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->g, c->g, 0.f, 0.f, c->reg_part, 1, (float)(1.0 / c->n_eff),
+                                c->st));
+    HIP_TRY(plm_launch_native_to_canon(d, c->g, c->canon, c->st));
+    c->h_fi.resize((size_t)d.L * d.Q);
+    HIP_TRY(hipMemcpyAsync(c->h_fi.data(), c->canon, sizeof(float) * d.L * d.Q, hipMemcpyDeviceToHost, c->st));
+    if (fij_host)
+        HIP_TRY(hipMemcpyAsync(fij_host, c->canon + (size_t)d.L * d.Q,
+                               sizeof(float) * (d.n_canon - (int64_t)d.L * d.Q), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    if (fi_host) memcpy(fi_host, c->h_fi.data(), sizeof(float) * d.L * d.Q);
+    return PLM_OK;
+}
+
+int plm_ctx_set_x(plm_ctx_t *c, const float *x_canonical_host) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!x_canonical_host) return set_start_point(c);
+    const PlmDims &d = c->d;
+    HIP_TRY(hipMemcpyAsync(c->canon, x_canonical_host, sizeof(float) * d.n_canon, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(plm_launch_canon_to_native(d, c->canon, c->x, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return PLM_OK;
+}
+
+static int get_vec(plm_ctx_t *c, const float *native, float *out_host) {
+    if (!c || !out_host) return fail(PLM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(plm_launch_native_to_canon(c->d, native, c->canon, c->st));
+    HIP_TRY(hipMemcpyAsync(out_host, c->canon, sizeof(float) * c->d.n_canon, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return PLM_OK;
+}
+int plm_ctx_get_x(plm_ctx_t *c, float *x_canonical_host) { return get_vec(c, c ? c->x : nullptr, x_canonical_host); }
+int plm_ctx_get_g(plm_ctx_t *c, float *g_canonical_host) { return get_vec(c, c ? c->g : nullptr, g_canonical_host); }
+
+int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
+    HIP_TRY(hipSetDevice(c->device));
+    PLM_TRY(ctx_eval_enqueue(c));
+    if (fx_out || nll_out) {
+        PLM_TRY(fetch_scalars(c, 0, 2));
+        if (fx_out) *fx_out = c->h_scal[0];
+        if (nll_out) *nll_out = c->h_scal[1];
+    }
+    return PLM_OK;
+}
+
+// L-BFGS (two-loop recursion, Nocedal 1980) with a More'-Thuente line search; vectors stay in
+// HBM, only scalars cross PCIe.  Defaults follow libLBFGS (m = 6, ftol 1e-4, gtol 0.9,
+// <= 20 trial steps), which plmc bundles [recollection, SURVEY.md App. C.4].
+int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
+    HIP_TRY(hipSetDevice(c->device));
+    const PlmDims &d = c->d;
+    const int64_t n = d.n_native;
+    const int m = c->prob.lbfgs_m > 0 ? c->prob.lbfgs_m : 6;
+    const int max_iter = c->prob.max_iter;
+    const double eps = c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3;
+    const int max_ls = 20;
+    const double ftol = 1e-4, gtol = 0.9, xtol = 1e-7, stpmin = 1e-20, stpmax = 1e20;
+    PLM_TRY(ctx_alloc_lbfgs(c, m));
+    float *S = c->hist, *Y = c->hist + (size_t)m * n;
+    std::vector<double> alpha(m), ys(m);
+    const double t0 = now_s();
+    c->n_evals = 0;
+
+    auto norms = [&](double *xnorm, double *gnorm, double *hn, double *en) -> int {
+        const float *a[3] = {c->x, c->g, c->x}, *b[3] = {c->x, c->g, c->x};
+        PLM_TRY(dots(c, 2, a, b, n, 2));
+        const float *ah[1] = {c->x};
+        PLM_TRY(dots(c, 1, ah, ah, d.nh_pad, 4));
+        PLM_TRY(fetch_scalars(c, 0, 5));
+        *xnorm = std::sqrt(c->h_scal[2]);
+        *gnorm = std::sqrt(c->h_scal[3]);
+        *hn = std::sqrt(c->h_scal[4]);
+        *en = std::sqrt(std::max(0.0, c->h_scal[2] - c->h_scal[4]));
+        return PLM_OK;
+    };
+    auto dot1 = [&](const float *a, const float *b, double *out) -> int {
+        const float *pa[1] = {a}, *pb[1] = {b};
+        PLM_TRY(dots(c, 1, pa, pb, n, 5));
+        PLM_TRY(fetch_scalars(c, 0, 6));
+        *out = c->h_scal[5];
+        return PLM_OK;
+    };
+
+    PLM_TRY(ctx_eval_enqueue(c));
+    double xnorm, gnorm, hn, en;
+    PLM_TRY(norms(&xnorm, &gnorm, &hn, &en));
+    double fx = c->h_scal[0], nll = c->h_scal[1];
+    if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
+    int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED;
+    if (gnorm / std::max(1.0, xnorm) > eps) {
+        HIP_TRY(plm_launch_lincomb(c->dir, -1.f, c->g, 0.f, nullptr, n, c->st));
+        double step = 1.0 / gnorm;
+        for (k = 1;; k++) {
+            HIP_TRY(hipMemcpyAsync(c->xp, c->x, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+            HIP_TRY(hipMemcpyAsync(c->gp, c->g, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+            double dginit;
+            PLM_TRY(dot1(c->g, c->dir, &dginit));
+            if (!(dginit < 0)) { status = PLM_STATUS_LINESEARCH; k--; break; }
+            const double finit = fx, nllinit = nll, dgtest = ftol * dginit;
+            int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
+            double width = stpmax - stpmin, prev_width = 2.0 * width;
+            double stx = 0, fxx = finit, dgx = dginit, sty = 0, fy = finit, dgy = dginit, stp = step, stmin, stmax;
+            for (;;) {
+                if (brackt) { stmin = std::min(stx, sty); stmax = std::max(stx, sty); }
+                else { stmin = stx; stmax = stp + 4.0 * (stp - stx); }
+                stp = std::max(stpmin, std::min(stpmax, stp));
+                if ((brackt && (stp <= stmin || stmax <= stp || count >= max_ls - 1 || uinfo)) ||
+                    (brackt && stmax - stmin <= xtol * stmax))
+                    stp = stx;
+                HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, (float)stp, c->dir, n, c->st));
+                PLM_TRY(ctx_eval_enqueue(c));
+                double dg;
+                PLM_TRY(dot1(c->g, c->dir, &dg));   // also fetches fx, nll
+                fx = c->h_scal[0];
+                nll = c->h_scal[1];
+                if (!std::isfinite(fx)) { fx = INFINITY; dg = 0; }
+                const double ftest1 = finit + stp * dgtest;
+                count++;
+                if (brackt && (stp <= stmin || stmax <= stp || uinfo)) { lsrc = -1; break; }
+                if (stp == stpmax && fx <= ftest1 && dg <= dgtest) { lsrc = -2; break; }
+                if (stp == stpmin && (ftest1 < fx || dgtest <= dg)) { lsrc = -3; break; }
+                if (brackt && stmax - stmin <= xtol * stmax) { lsrc = -4; break; }
+                if (count >= max_ls) { lsrc = -5; break; }
+                if (fx <= ftest1 && std::fabs(dg) <= gtol * (-dginit)) { lsrc = 1; break; }
+                if (stage1 && fx <= ftest1 && std::min(ftol, gtol) * dginit <= dg) stage1 = 0;
+                if (stage1 && ftest1 < fx && fx <= fxx) {
+                    double fm = fx - stp * dgtest, fxm = fxx - stx * dgtest, fym = fy - sty * dgtest;
+                    double dgm = dg - dgtest, dgxm = dgx - dgtest, dgym = dgy - dgtest;
+                    uinfo = mt_update(&stx, &fxm, &dgxm, &sty, &fym, &dgym, &stp, fm, dgm, stmin, stmax, &brackt);
+                    fxx = fxm + stx * dgtest; fy = fym + sty * dgtest;
+                    dgx = dgxm + dgtest; dgy = dgym + dgtest;
+                } else {
+                    uinfo = mt_update(&stx, &fxx, &dgx, &sty, &fy, &dgy, &stp, fx, dg, stmin, stmax, &brackt);
+                }
+                if (brackt) {
+                    if (0.66 * prev_width <= std::fabs(sty - stx)) stp = stx + 0.5 * (sty - stx);
+                    prev_width = width;
+                    width = std::fabs(sty - stx);
+                }
+            }
+            if (lsrc < 0) {
+                if (!(fx <= finit)) {  // restore the last accepted point
+                    HIP_TRY(hipMemcpyAsync(c->x, c->xp, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+                    HIP_TRY(hipMemcpyAsync(c->g, c->gp, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+                    fx = finit;
+                    nll = nllinit;
+                }
+                status = PLM_STATUS_LINESEARCH;
+                k--;
+                break;
+            }
+            step = stp;
+            PLM_TRY(norms(&xnorm, &gnorm, &hn, &en));
+            if (cb) cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, hn, en, user);
+            if (gnorm / std::max(1.0, xnorm) <= eps) { status = PLM_STATUS_CONVERGED; break; }
+            if (max_iter > 0 && k >= max_iter) { status = PLM_STATUS_MAXITER; break; }
+            // history update + two-loop recursion
+            float *s = S + (size_t)end * n, *y = Y + (size_t)end * n;
+            HIP_TRY(plm_launch_lincomb(s, 1.f, c->x, -1.f, c->xp, n, c->st));
+            HIP_TRY(plm_launch_lincomb(y, 1.f, c->g, -1.f, c->gp, n, c->st));
+            {
+                const float *a[2] = {y, y}, *b[2] = {s, y};
+                PLM_TRY(dots(c, 2, a, b, n, 6));
+                PLM_TRY(fetch_scalars(c, 6, 2));
+            }
+            const double ysv = c->h_scal[6], yy = c->h_scal[7];
+            ys[end] = ysv;
+            if (stored < m) stored++;
+            end = (end + 1) % m;
+            HIP_TRY(plm_launch_lincomb(c->dir, -1.f, c->g, 0.f, nullptr, n, c->st));
+            int j = end;
+            for (int i = 0; i < stored; i++) {
+                j = (j + m - 1) % m;
+                double sd;
+                PLM_TRY(dot1(S + (size_t)j * n, c->dir, &sd));
+                alpha[j] = sd / ys[j];
+                HIP_TRY(plm_launch_lincomb(c->dir, 1.f, c->dir, (float)-alpha[j], Y + (size_t)j * n, n, c->st));
+            }
+            HIP_TRY(plm_launch_lincomb(c->dir, (float)(ysv / yy), c->dir, 0.f, nullptr, n, c->st));
+            for (int i = 0; i < stored; i++) {
+                double yd;
+                PLM_TRY(dot1(Y + (size_t)j * n, c->dir, &yd));
+                const double beta = yd / ys[j];
+                HIP_TRY(plm_launch_lincomb(c->dir, 1.f, c->dir, (float)(alpha[j] - beta), S + (size_t)j * n, n,
+                                           c->st));
+                j = (j + 1) % m;
+            }
+            step = 1.0;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->st));
+    if (res) {
+        res->iters_done = k;
+        res->n_evals = c->n_evals;
+        res->status = status;
+        res->fx = fx;
+        res->n_eff = (float)c->n_eff;
+        res->seconds_optimize = now_s() - t0;
+        snprintf(res->status_msg, sizeof res->status_msg, "%s", status_text(status));
+    }
+    return PLM_OK;
+}
+
+int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
+    if (!c || !fn_host || !cn_host) return fail(PLM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const PlmDims &d = c->d;
+    float *fn_dev = c->canon + d.n_canon;
+    HIP_TRY(plm_launch_native_to_canon(d, c->x, c->canon, c->st));
+    HIP_TRY(plm_launch_fn(d, c->canon + (size_t)d.L * d.Q, fn_dev, c->st));
+    HIP_TRY(hipMemcpyAsync(fn_host, fn_dev, sizeof(float) * d.L * d.L, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    // APC (couplings/model.py:744-775): means over off-diagonal entries, diagonal blanked
+    const int L = d.L;
+    std::vector<double> col(L, 0.0);
+    double tot = 0;
+    for (int i = 0; i < L; i++)
+        for (int j = 0; j < L; j++) {
+            col[j] += fn_host[(size_t)i * L + j];
+            tot += fn_host[(size_t)i * L + j];
+        }
+    const double mean = tot / ((double)L * (L - 1));
+    for (int j = 0; j < L; j++) col[j] /= (double)(L - 1);
+    for (int i = 0; i < L; i++)
+        for (int j = 0; j < L; j++)
+            cn_host[(size_t)i * L + j] =
+                (i == j) ? 0.f : (float)((double)fn_host[(size_t)i * L + j] - col[i] * col[j] / mean);
+    return PLM_OK;
+}
+
+int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
+    if (!c || !out_ms || reps <= 0) return fail(PLM_EINVAL, "bad argument");
+    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
+    if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "kernel timing runs on 1-shard contexts");
+    HIP_TRY(hipSetDevice(c->device));
+    const PlmDims &d = c->d;
+    hipEvent_t ev[6];
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    double acc[PLM_K_COUNT] = {0};
+    for (int r = 0; r < reps; r++) {
+        HIP_TRY(hipEventRecord(ev[0], c->st));
+        HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
+        HIP_TRY(plm_launch_expand(d, c->x, c->jexp, c->Bt, c->st));
+        HIP_TRY(hipEventRecord(ev[1], c->st));
+        HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
+        HIP_TRY(hipEventRecord(ev[2], c->st));
+        HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+        HIP_TRY(hipEventRecord(ev[3], c->st));
+        HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j, c->reg_part,
+                                    0, 0.f, c->st));
+        HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d),
+                                     c->scal, c->st));
+        HIP_TRY(hipEventRecord(ev[4], c->st));
+        HIP_TRY(hipEventSynchronize(ev[4]));
+        float ms;
+        for (int k = 0; k < 4; k++) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            acc[k] += ms;
+        }
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[4]));
+        acc[PLM_K_TOTAL] += ms;
+    }
+    {
+        const int thresh = (int)std::ceil((double)c->prob.theta_id * d.L - 1e-9);
+        HIP_TRY(hipEventRecord(ev[0], c->st));
+        HIP_TRY(plm_launch_reweight(d, c->msa_rm, std::max(1, thresh), c->counts, c->st));
+        HIP_TRY(hipEventRecord(ev[1], c->st));
+        HIP_TRY(hipEventSynchronize(ev[1]));
+        float ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        acc[PLM_K_REWEIGHT] = ms * reps;
+    }
+    for (int k = 0; k < PLM_K_COUNT; k++) out_ms[k] = (float)(acc[k] / reps);
+    for (auto &e : ev) hipEventDestroy(e);
+    return PLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer conveniences built on the context API
+// ---------------------------------------------------------------------------------------------
+static plm_problem_t basic_problem(const int8_t *msa, int n, int l, int q) {
+    plm_problem_t p;
+    memset(&p, 0, sizeof p);
+    p.n_seqs = n; p.n_sites = l; p.n_states = q; p.msa = msa;
+    p.theta_id = 0.8f; p.scale = 1.f; p.n_shards = 1;
+    return p;
+}
+
+int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, float theta_id, int32_t *counts_out) {
+    if (!msa || !counts_out) return fail(PLM_EINVAL, "NULL argument");
+    // reweighting compares raw bytes; any state value 0..126 is legal here, so borrow q = 21
+    // only for the context's tiling and validate the range ourselves
+    for (size_t k = 0; k < (size_t)n_seqs * n_sites; k++)
+        if (msa[k] < 0 || msa[k] > 126) return fail(PLM_EINVAL, "msa[%zu] outside 0..126", k);
+    plm_problem_t p = basic_problem(msa, n_seqs, n_sites, 21);
+    p.theta_id = theta_id;
+    PLM_TRY(check_device(0));
+    PlmDims d;
+    PLM_TRY(make_dims(p, &d));
+    const size_t rm_rows = (size_t)d.Np + 32;
+    std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE);
+    for (int s = 0; s < d.N; s++) memcpy(&rm[(size_t)s * d.Lp32], msa + (size_t)s * d.L, d.L);
+    int8_t *dev = nullptr;
+    int32_t *cnt = nullptr;
+    PLM_TRY(dalloc(&dev, rm.size()));
+    int rc = dalloc(&cnt, (size_t)d.Np);
+    if (rc) { hipFree(dev); return rc; }
+    const int thresh = (int)std::ceil((double)theta_id * d.L - 1e-9);
+    hipError_t e = hipMemcpy(dev, rm.data(), rm.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && thresh > 0) e = plm_launch_reweight(d, dev, thresh, cnt, nullptr);
+    if (e == hipSuccess && thresh > 0) e = hipMemcpy(counts_out, cnt, sizeof(int32_t) * d.N, hipMemcpyDeviceToHost);
+    if (thresh <= 0) std::fill(counts_out, counts_out + d.N, d.N);
+    hipFree(dev);
+    hipFree(cnt);
+    if (e != hipSuccess) return fail(PLM_EDEVICE, "reweight failed: %s", hipGetErrorString(e));
+    return PLM_OK;
+}
+
+int plm_marginals(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites, int32_t n_states,
+                  float *fi_out, float *fij_out) {
+    if (!msa || !weights || !fi_out) return fail(PLM_EINVAL, "NULL argument");
+    plm_problem_t p = basic_problem(msa, n_seqs, n_sites, n_states);
+    plm_ctx_t *c = nullptr;
+    PLM_TRY(plm_ctx_create(&p, 0, nullptr, &c));
+    int rc = plm_ctx_set_weights(c, weights);
+    if (!rc) rc = plm_ctx_marginals(c, fi_out, fij_out);
+    plm_ctx_destroy(c);
+    return rc;
+}
+
+int plm_eval(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites, int32_t n_states,
+             float lambda_h, float lambda_j, const float *x, double *fx_out, double *nll_out, float *g_out) {
+    if (!msa || !weights || !x) return fail(PLM_EINVAL, "NULL argument");
+    plm_problem_t p = basic_problem(msa, n_seqs, n_sites, n_states);
+    p.lambda_h = lambda_h;
+    p.lambda_j = lambda_j;
+    plm_ctx_t *c = nullptr;
+    PLM_TRY(plm_ctx_create(&p, 0, nullptr, &c));
+    int rc = plm_ctx_set_weights(c, weights);
+    if (!rc) rc = plm_ctx_set_x(c, x);
+    double fx = 0, nll = 0;
+    if (!rc) rc = plm_ctx_eval(c, &fx, &nll);
+    if (!rc && g_out) rc = plm_ctx_get_g(c, g_out);
+    if (fx_out) *fx_out = fx;
+    if (nll_out) *nll_out = nll;
+    plm_ctx_destroy(c);
+    return rc;
+}
+
+int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_out, float *cn_out) {
+    if (!jij || !fn_out || !cn_out) return fail(PLM_EINVAL, "NULL argument");
+    if (n_sites < 2 || n_states < 1 || n_states > 32) return fail(PLM_EINVAL, "bad L / q");
+    std::vector<int8_t> dummy((size_t)n_sites, 0);
+    plm_problem_t p = basic_problem(dummy.data(), 1, n_sites, plm_q_supported(n_states) ? n_states : 21);
+    PLM_TRY(check_device(0));
+    PlmDims d;
+    PLM_TRY(make_dims(p, &d));
+    d.Q = n_states;
+    const size_t nj = (size_t)n_sites * (n_sites - 1) / 2 * n_states * n_states;
+    float *dj = nullptr, *dfn = nullptr;
+    PLM_TRY(dalloc(&dj, nj));
+    int rc = dalloc(&dfn, (size_t)n_sites * n_sites);
+    if (rc) { hipFree(dj); return rc; }
+    hipError_t e = hipMemcpy(dj, jij, sizeof(float) * nj, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = plm_launch_fn(d, dj, dfn, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(fn_out, dfn, sizeof(float) * n_sites * n_sites, hipMemcpyDeviceToHost);
+    hipFree(dj);
+    hipFree(dfn);
+    if (e != hipSuccess) return fail(PLM_EDEVICE, "scores failed: %s", hipGetErrorString(e));
+    const int L = n_sites;
+    std::vector<double> col(L, 0.0);
+    double tot = 0;
+    for (int i = 0; i < L; i++)
+        for (int j = 0; j < L; j++) {
+            col[j] += fn_out[(size_t)i * L + j];
+            tot += fn_out[(size_t)i * L + j];
+        }
+    const double mean = tot / ((double)L * (L - 1));
+    for (int j = 0; j < L; j++) col[j] /= (double)(L - 1);
+    for (int i = 0; i < L; i++)
+        for (int j = 0; j < L; j++)
+            cn_out[(size_t)i * L + j] =
+                (i == j) ? 0.f : (float)((double)fn_out[(size_t)i * L + j] - col[i] * col[j] / mean);
+    return PLM_OK;
+}
+
+int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,
+            void *iter_user, plm_exchange_cb exchange, void *exchange_user) {
+    if (!problem || !result) return fail(PLM_EINVAL, "NULL problem / result");
+    const double t0 = now_s();
+    const int nshards = problem->n_shards > 0 ? problem->n_shards : 1;
+    // reweighting and marginals are cheap and run unsharded on every rank (identical inputs ->
+    // identical weights everywhere); the optimisation runs on the sharded context
+    plm_problem_t p1 = *problem;
+    p1.n_shards = 1;
+    p1.shard = 0;
+    plm_ctx_t *c1 = nullptr;
+    PLM_TRY(plm_ctx_create(&p1, device, stream, &c1));
+    int rc = PLM_OK;
+    const int N = problem->n_seqs, L = problem->n_sites, q = problem->n_states;
+    const size_t npq = (size_t)L * (L - 1) / 2 * q * q;
+    std::vector<float> w(N), fi((size_t)L * q);
+    double t1 = now_s();
+    rc = plm_ctx_reweight(c1);
+    float neff = 0;
+    if (!rc) rc = plm_ctx_get_weights(c1, w.data(), nullptr, &neff);
+    result->seconds_reweight = now_s() - t1;
+    t1 = now_s();
+    if (!rc) rc = plm_ctx_marginals(c1, fi.data(), result->fij);
+    result->seconds_marginals = now_s() - t1;
+    plm_ctx_t *c = c1;
+    if (!rc && nshards > 1) {
+        rc = plm_ctx_create(problem, device, stream, &c);
+        if (!rc) rc = plm_ctx_set_weights(c, w.data());
+        if (!rc) {
+            c->h_fi = c1->h_fi;
+            plm_ctx_set_exchange(c, exchange, exchange_user);
+        }
+        plm_ctx_destroy(c1);
+        c1 = nullptr;
+    }
+    if (!rc) rc = plm_ctx_set_x(c, nullptr);
+    if (!rc) rc = plm_ctx_optimize(c, iter_cb, iter_user, result);
+    if (!rc && (result->hi || result->jij)) {
+        std::vector<float> x((size_t)c->d.n_canon);
+        rc = plm_ctx_get_x(c, x.data());
+        if (!rc && result->hi) memcpy(result->hi, x.data(), sizeof(float) * L * q);
+        if (!rc && result->jij) memcpy(result->jij, x.data() + (size_t)L * q, sizeof(float) * npq);
+    }
+    if (!rc && result->fn && result->cn) rc = plm_ctx_scores(c, result->fn, result->cn);
+    if (!rc) {
+        if (result->weights) memcpy(result->weights, w.data(), sizeof(float) * N);
+        if (result->fi) memcpy(result->fi, fi.data(), sizeof(float) * L * q);
+        result->n_eff = neff;
+    }
+    if (c) plm_ctx_destroy(c);
+    result->seconds_total = now_s() - t0;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// plm_internal.h -- data layout in HBM and launch-wrapper declarations shared by
+// plm_kernels.hip (device code) and plm_host.cpp (context, L-BFGS, C ABI).
+//
+// HBM layout (all sizes for N sequences, L sites, q states):
+//   msa_rm  int8 [Np][Lp32]        row-major alignment, pad value 127 (never a state)
+//   msa_cm  int8 [(nb16+1)*16][Np] column-major copy; the extra 16-site block holds the
+//                                  "ones" column (site 0 = state 0 for s < N) that turns the
+//                                  field gradient into one more row fragment of the GEMM
+//   x, g    f32  [n_native]        "native" parameter vector: h[L][q] padded to 256 floats,
+//                                  then per block pair (I<=J of 16-site blocks), per (a,b):
+//                                  a 16x16 tile [ii][jj] of J_{16I+ii,16J+jj}(a,b)
+//   Bt      f16  [b16][kstep][2][q][64][8]   one-hot GEMM B operand of the forward pass:
+//                                  expanded couplings split hi/lo, stored as ready-made MFMA
+//                                  B fragments (lane-linear 16 B per lane)
+//   Rt      f16  [sstep][nf][2][64][8]       residuals w_s (P_si(a) - [x_si=a]) * 2^14 split
+//                                  hi/lo, stored as MFMA B fragments of the backward pass
+//   G       f32  [shard][ksplit][mf][nfl][64][4]   asymmetric gradient slab, one 16x16
+//                                  MFMA accumulator tile per (row fragment, col fragment)
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+
+#define PLM_PAD_STATE 127
+#define PLM_SEQ_TILE 256      // sequences per forward workgroup (8 waves x 32)
+#define PLM_R_EXP 14          // residuals are stored scaled by 2^14 (|r| <= scale <= 1)
+
+struct PlmDims {
+    int N, L, Q;
+    int Np;        // N padded to PLM_SEQ_TILE
+    int nb16;      // 16-site blocks covering L
+    int Lp16;      // nb16 * 16
+    int nu;        // 32-site K blocks covering L
+    int Lp32;      // nu * 32
+    int nksteps;   // nu * Q      forward K steps (32 sites x one state)
+    int nssteps;   // Np / 32     backward K steps (32 sequences)
+    int nstiles;   // Np / PLM_SEQ_TILE
+    int FM, FN;    // backward wave tile in fragments
+    int nmf;       // row fragments of the backward GEMM: nb16*Q + FM (last FM = "ones" block)
+    int nshards, shard;
+    int blk_per_shard;  // ceil(nb16 / nshards) column blocks owned by each shard
+    int b16_lo, b16_hi; // this shard's column blocks [lo, hi)
+    int nnfl;      // local col fragments = blk_per_shard * Q (slab width, padded)
+    int ksplit;    // split-K factor of the backward GEMM
+    int nrow_tiles, ncol_tiles; // backward workgroup grid
+    int64_t nbp;       // block pairs I<=J
+    int64_t nh_pad;    // L*Q rounded up to 256
+    int64_t n_native;  // nh_pad + nbp*Q*Q*256
+    int64_t n_canon;   // L*Q + L(L-1)/2*Q*Q
+};
+
+static inline __host__ __device__ int64_t plm_bp_index(int I, int J, int nb16) { // I <= J
+    return (int64_t)I * nb16 - (int64_t)I * (I - 1) / 2 + (J - I);
+}
+static inline __host__ __device__ int64_t plm_pair_index(int i, int j, int L) { // i < j
+    return (int64_t)i * (2 * L - i - 1) / 2 + (j - i - 1);
+}
+
+// ---- launch wrappers (plm_kernels.hip) --------------------------------------------------
+// every wrapper enqueues on `st` and returns the hipError_t of the launch
+hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thresh, int32_t *counts,
+                               hipStream_t st);
+hipError_t plm_launch_onehot_rt(const PlmDims &d, const int8_t *msa_rm, const float *w, void *Rt,
+                                hipStream_t st);
+hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, uint32_t *maxbits, int32_t *jexp,
+                             hipStream_t st);
+hipError_t plm_launch_expand(const PlmDims &d, const float *x, const int32_t *jexp, void *Bt,
+                             hipStream_t st);
+hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
+                              const float *x, const int32_t *jexp, void *Rt, double *fx_part,
+                              hipStream_t st);
+hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G,
+                               hipStream_t st);
+hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab, hipStream_t st);
+// g = 2^-R_EXP * (G + G^T) + 2 lambda x ; mode 1: marginals (out = G / neff, no symmetrisation)
+hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *x,
+                               float *g, float lambda_h, float lambda_j, double *reg_part,
+                               int mode, float inv_neff, hipStream_t st);
+hipError_t plm_launch_finish_fx(const PlmDims &d, const double *fx_part, int n_fx_part,
+                                const double *shard_nll, int n_shard_nll, const double *reg_part,
+                                int n_reg_part, double *out2 /* fx, nll */, hipStream_t st);
+hipError_t plm_launch_partial_sum(const double *part, int n, double *out, hipStream_t st);
+// out[k] = sum a_k[i]*b_k[i] for k < npairs (<= 4); scratch holds npairs*PLM_DOT_BLOCKS doubles
+#define PLM_DOT_BLOCKS 1024
+hipError_t plm_launch_dots(int npairs, const float *const *a, const float *const *b, int64_t n,
+                           double *scratch, double *out, hipStream_t st);
+hipError_t plm_launch_lincomb(float *out, float ca, const float *a, float cb, const float *b,
+                              int64_t n, hipStream_t st);
+hipError_t plm_launch_canon_to_native(const PlmDims &d, const float *xc, float *xn, hipStream_t st);
+hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *xc, hipStream_t st);
+hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, hipStream_t st);
+size_t plm_bt_bytes(const PlmDims &d);
+size_t plm_rt_bytes(const PlmDims &d);
+size_t plm_g_bytes(const PlmDims &d);      // [ksplit][nmf][nnfl][256] floats
+size_t plm_slab_bytes(const PlmDims &d);   // [nmf][nnfl][256] floats + 256 B tail (shard nll)
+int plm_reg_parts(const PlmDims &d);       // number of double partials assemble writes
+bool plm_q_supported(int q);
+void plm_pick_tile(int q, int *fm, int *fn);

@@ -1,0 +1,839 @@
+// plm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the pseudo-likelihood Potts solver.
+//
+// Hot path, replacing the arithmetic of the external plmc
+// process that evcouplings/couplings/tools.py:266 launches:
+//   k_reweight   N x N Hamming identity counts on the packed int8 alignment (VALU, integer)
+//   k_expand     parameters -> forward B operand (f16 hi/lo MFMA fragments)
+//   k_fwd        one-hot(MSA) x J on MFMA + per-site softmax + residuals + -log P (fused)
+//   k_bwd        one-hot(MSA)^T x residuals on MFMA -> asymmetric gradient slab
+//   k_assemble   slab + slab^T + L2 term -> gradient, regulariser partial sums
+// plus small streaming kernels for L-BFGS (dots / linear combinations) and scoring.
+//
+// The alignment is int8 in HBM; one-hot MFMA A fragments are expanded from 8 packed bytes
+// in registers (never materialised in memory); the dense operand (couplings / residuals)
+// is split into two f16 planes (22-bit significand, power-of-two pre-scaled) and
+// accumulated in f32 by v_mfma_f32_16x16x32_f16.  Written for wave64 / gfx950 only.
+#include "plm_internal.h"
+#include <math.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+
+// half index e of an 8-wide MFMA k-chunk <-> byte PERM8[e] of the 8 packed alignment bytes
+// (pairing (0,2),(1,3) lets one multiply turn two match bits into two f16 1.0 values)
+__host__ __device__ __forceinline__ constexpr int perm8(int e) { return (e & 4) | ((e & 1) << 1) | ((e & 2) >> 1); }
+
+// 8 packed states (two dwords) vs state b -> 8 f16 values in {0,1}.  States are < 128, so
+// (x ^ b) + 0x7f sets bit 7 of a byte exactly when it differs from b, with no carries.
+__device__ __forceinline__ half8 onehot8(u32 lo, u32 hi, u32 bb) {
+    const u32 y0 = (lo ^ bb) + 0x7f7f7f7fu;
+    const u32 y1 = (hi ^ bb) + 0x7f7f7f7fu;
+    union {
+        u32 w[4];
+        half8 h;
+    } r;
+    r.w[0] = 0x3C003C00u - ((y0 >> 7) & 0x00010001u) * 0x3C00u;   // bytes 0,2
+    r.w[1] = 0x3C003C00u - ((y0 >> 15) & 0x00010001u) * 0x3C00u;  // bytes 1,3
+    r.w[2] = 0x3C003C00u - ((y1 >> 7) & 0x00010001u) * 0x3C00u;   // bytes 4,6
+    r.w[3] = 0x3C003C00u - ((y1 >> 15) & 0x00010001u) * 0x3C00u;  // bytes 5,7
+    return r.h;
+}
+
+__device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += sh[k];
+    return t;  // valid in thread 0
+}
+
+bool plm_q_supported(int q) { return q == 21 || q == 20 || q == 5 || q == 4; }
+void plm_pick_tile(int q, int *fm, int *fn) {
+    if (q == 21) { *fm = 7; *fn = 7; }
+    else if (q == 20) { *fm = 5; *fn = 5; }
+    else if (q == 5) { *fm = 5; *fn = 5; }
+    else { *fm = 4; *fn = 4; }
+}
+size_t plm_bt_bytes(const PlmDims &d) { return (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024; }
+size_t plm_rt_bytes(const PlmDims &d) { return (size_t)d.nssteps * d.nnfl * 2 * 1024; }
+size_t plm_g_bytes(const PlmDims &d) { return (size_t)d.ksplit * d.nmf * d.nnfl * 1024; }
+size_t plm_slab_bytes(const PlmDims &d) { return (size_t)d.nmf * d.nnfl * 1024 + 256; }
+int plm_reg_parts(const PlmDims &d) { return (int)(d.nbp * d.Q) + 1; }
+
+// =========================================================================================
+// K1  sequence reweighting (row a4; twin: align/alignment.py:1193-1233)
+//   counts[s] += #{ t in this block's range : ident(s,t) >= thresh }
+// One lane per sequence s; the other sequence t is wave-uniform and read through the scalar
+// cache.  4 alignment bytes per VALU triple: xor+add, and, popcount-accumulate.
+// =========================================================================================
+#define RW_TT 32   // t-rows per register tile
+#define RW_CW 16   // dwords (64 sites) per column chunk
+__global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32, int Lw, int N,
+                                                 int thresh_padded, int t_per_block,
+                                                 int32_t *__restrict__ counts) {
+    const int s = blockIdx.x * 256 + threadIdx.x;  // < Np always (rows exist, padded)
+    const int tb0 = blockIdx.y * t_per_block;
+    const int tb1 = min(N, tb0 + t_per_block);
+    const u32 *__restrict__ myrow = msa32 + (size_t)s * Lw;
+    int cnt = 0;
+    for (int t0 = tb0; t0 < tb1; t0 += RW_TT) {
+        int ident[RW_TT];
+#pragma unroll
+        for (int k = 0; k < RW_TT; k++) ident[k] = 0;
+        for (int c0 = 0; c0 < Lw; c0 += RW_CW) {   // Lw is a multiple of 8
+            u32 mine[RW_CW];
+            const int cw = min(RW_CW, Lw - c0);
+#pragma unroll
+            for (int k = 0; k < RW_CW; k++) mine[k] = k < cw ? myrow[c0 + k] : 0x7e7e7e7eu;
+#pragma unroll
+            for (int tt = 0; tt < RW_TT; tt++) {
+                // rows t >= N are padding rows (all 127): they exist in memory, never reach thresh
+                const u32 *__restrict__ trow = msa32 + (size_t)(t0 + tt) * Lw + c0;
+                int acc = ident[tt];
+#pragma unroll
+                for (int k = 0; k < RW_CW; k++) {
+                    const u32 other = k < cw ? trow[k] : 0x7d7d7d7du;
+                    const u32 y = (mine[k] ^ other) + 0x7f7f7f7fu;      // bit7 set <=> mismatch
+                    acc += 4 - __builtin_popcount(y & 0x80808080u);
+                }
+                ident[tt] = acc;
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < RW_TT; tt++) cnt += (t0 + tt < tb1 && ident[tt] >= thresh_padded) ? 1 : 0;
+    }
+    if (s < N && cnt) atomicAdd(&counts[s], cnt);
+}
+
+hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thresh, int32_t *counts,
+                               hipStream_t st) {
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * d.Np, st);
+    if (e != hipSuccess) return e;
+    const int Lw = d.Lp32 / 4;
+    // padded columns (value 127 in every row) always match: shift the threshold instead
+    const int thr = thresh + (d.Lp32 - d.L);
+    int tsplit = (2048 + d.nstiles - 1) / d.nstiles;
+    int tper = (d.N + tsplit - 1) / tsplit;
+    tper = ((tper + RW_TT - 1) / RW_TT) * RW_TT;
+    tsplit = (d.N + tper - 1) / tper;
+    // the padded rows t in [N, Np) are readable; rows beyond Np are not: cap the tile walk
+    // (tb1 <= N and t0+tt < t0+RW_TT <= Np + RW_TT) -> msa_rm is allocated with RW_TT spare rows
+    hipLaunchKernelGGL(k_reweight, dim3(d.nstiles, tsplit), dim3(256), 0, st,
+                       (const u32 *)msa_rm, Lw, d.N, thr, tper, counts);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// one-hot residual builder for the marginals:  R[s,(i,a)] = w_s [x_si = a]  in Rt layout
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_onehot_rt(PlmDims d, const int8_t *__restrict__ msa_rm,
+                                                  const float *__restrict__ w, _Float16 *__restrict__ Rt,
+                                                  float rscale) {
+    const int sstep = blockIdx.x, b16l = blockIdx.y, b16 = d.b16_lo + b16l;
+    for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
+        const int a = idx >> 6, lane = idx & 63, kg = lane >> 4, ii = lane & 15;
+        const int i = b16 * 16 + ii;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int s = sstep * 32 + kg * 8 + perm8(e);
+            float v = 0.f;
+            if (i < d.L && b16 < d.nb16 && msa_rm[(size_t)s * d.Lp32 + i] == a) v = w[s] * rscale;
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)(v - (float)h);
+        }
+        const size_t base = (((size_t)sstep * d.nnfl + (size_t)b16l * d.Q + a) * 2) * 512 + (size_t)lane * 8;
+        *(half8 *)(Rt + base) = hi;
+        *(half8 *)(Rt + base + 512) = lo;
+    }
+}
+hipError_t plm_launch_onehot_rt(const PlmDims &d, const int8_t *msa_rm, const float *w, void *Rt,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(k_onehot_rt, dim3(d.nssteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, msa_rm, w,
+                       (_Float16 *)Rt, ldexpf(1.f, PLM_R_EXP));
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// scale of the coupling operand: jexp = 14 - exponent(max |J|)  (so |J| 2^jexp < 2^14)
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_maxabs(const float *__restrict__ x, int64_t n, u32 *maxbits) {
+    u32 m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
+}
+__global__ void k_scale_from_max(const u32 *maxbits, int32_t *jexp) {
+    const float mx = __uint_as_float(*maxbits);
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) frexpf(mx, &e);  // mx = m * 2^e, m in [0.5, 1)
+    int s = PLM_R_EXP - e;
+    s = max(-100, min(100, s));
+    *jexp = (mx > 0.f) ? s : 0;
+}
+hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int32_t *jexp, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(u32), st);
+    if (e != hipSuccess) return e;
+    const int64_t n = d.n_native - d.nh_pad;
+    hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, x + d.nh_pad, n, maxbits);
+    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// K_expand: native parameter vector -> forward B operand.
+//   Bt[b16l][kstep=(u,b)][plane][a][lane=(kg,r)][e] = 2^jexp * J_{i,j}(a,b)
+//   i = 16*b16 + r (state a),  j = 32u + 8kg + perm8(e) (state b);  0 when i == j / padding
+// =========================================================================================
+__device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__restrict__ xj, int I, int ii,
+                                               int a, int J, int jj, int b) {
+    // coupling between (site 16I+ii, state a) and (site 16J+jj, state b)
+    const int QQ = d.Q * d.Q;
+    if (I < J) return xj[(plm_bp_index(I, J, d.nb16) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
+    if (I > J) return xj[(plm_bp_index(J, I, d.nb16) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
+    if (ii < jj) return xj[(plm_bp_index(I, I, d.nb16) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
+    if (ii > jj) return xj[(plm_bp_index(I, I, d.nb16) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
+    return 0.f;
+}
+__global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restrict__ x,
+                                               const int32_t *__restrict__ jexp, _Float16 *__restrict__ Bt) {
+    const int kstep = blockIdx.x, b16l = blockIdx.y, b16 = d.b16_lo + b16l;
+    const int u = kstep / d.Q, b = kstep % d.Q;
+    const float sc = ldexpf(1.f, *jexp);
+    const float *__restrict__ xj = x + d.nh_pad;
+    _Float16 *tile = Bt + ((size_t)b16l * d.nksteps + kstep) * (size_t)(2 * d.Q * 512);
+    for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
+        const int a = idx >> 6, lane = idx & 63, kg = lane >> 4, r = lane & 15;
+        const int i = b16 * 16 + r;
+        const int J = 2 * u + (kg >> 1);
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int jj = 8 * (kg & 1) + perm8(e);
+            const int j = J * 16 + jj;
+            float v = 0.f;
+            if (i < d.L && j < d.L && i != j) v = sc * load_coupling(d, xj, b16, r, a, J, jj, b);
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)(v - (float)h);
+        }
+        *(half8 *)(tile + (size_t)a * 512 + lane * 8) = hi;
+        *(half8 *)(tile + (size_t)(d.Q + a) * 512 + lane * 8) = lo;
+    }
+}
+hipError_t plm_launch_expand(const PlmDims &d, const float *x, const int32_t *jexp, void *Bt, hipStream_t st) {
+    hipLaunchKernelGGL(k_expand, dim3(d.nksteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, jexp,
+                       (_Float16 *)Bt);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// K_fwd: potentials + conditional softmax + residuals (rows a6 forward half)
+//   workgroup = 256 sequences x one 16-site block (all Q states); 8 waves x 32 sequences.
+//   K loop: 32 sites x one state per MFMA step; A = one-hot from registers, B = Bt tile
+//   streamed global -> LDS by global_load_lds (double buffered, one barrier per step).
+//   Accumulator fragment `a` of a wave holds H[s, i, a] for 16 sites i (lane & 15) and
+//   4 sequences per lane, so the softmax over states is pure in-lane register work.
+// =========================================================================================
+struct FwdArgs {
+    const int8_t *msa_rm;
+    const float *w;
+    const char *Bt;
+    const float *h;       // native vector (fields first)
+    const int32_t *jexp;
+    _Float16 *Rt;
+    double *fx_part;
+    float rscale;
+};
+
+template <int Q>
+__global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (guide 5/4a)
+    constexpr int TILE = 2 * Q * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
+    const int b16 = d.b16_lo + b16l;
+    const int r = lane & 15, g = lane >> 4;
+    const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
+    const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE;
+    const int8_t *arow0 = A.msa_rm + (size_t)(s_wave + r) * d.Lp32 + 8 * g;
+    const int8_t *arow1 = arow0 + (size_t)16 * d.Lp32;
+
+    f32x4 acc[2][Q];
+#pragma unroll
+    for (int a = 0; a < Q; a++) {
+        acc[0][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto stage = [&](int ks, int buf) {
+        const char *src = bt + (size_t)ks * TILE + lane * 16;
+        char *dst = smem + buf * TILE;
+        for (int p = wave; p < 2 * Q; p += 8)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src + p * 1024), LDS_PTR(dst + p * 1024), 16, 0, 0);
+    };
+    stage(0, 0);
+    uint2 xa0 = *(const uint2 *)arow0, xa1 = *(const uint2 *)arow1;
+    int ks = 0;
+    for (int u = 0; u < d.nu; ++u) {
+        uint2 na0 = xa0, na1 = xa1;
+        if (u + 1 < d.nu) {
+            na0 = *(const uint2 *)(arow0 + 32 * (u + 1));
+            na1 = *(const uint2 *)(arow1 + 32 * (u + 1));
+        }
+        for (int b = 0; b < Q; ++b, ++ks) {
+            __syncthreads();
+            if (ks + 1 < d.nksteps) stage(ks + 1, (ks + 1) & 1);
+            const char *lb = smem + (ks & 1) * TILE + lane * 16;
+            const u32 bb = (u32)b * 0x01010101u;
+            const half8 a0 = onehot8(xa0.x, xa0.y, bb);
+            const half8 a1 = onehot8(xa1.x, xa1.y, bb);
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                const half8 bh = *(const half8 *)(lb + a * 1024);
+                const half8 bl = *(const half8 *)(lb + (Q + a) * 1024);
+                acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc[0][a], 0, 0, 0);
+                acc[1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc[1][a], 0, 0, 0);
+                acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, acc[0][a], 0, 0, 0);
+                acc[1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc[1][a], 0, 0, 0);
+            }
+        }
+        xa0 = na0;
+        xa1 = na1;
+    }
+
+    // ---- epilogue: softmax over states, residuals, -log P -------------------------------
+    const float sc = ldexpf(1.f, -(*A.jexp));
+    const int i = b16 * 16 + r;
+    const bool site_ok = i < d.L;
+    float hv[Q];
+#pragma unroll
+    for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)i * Q + a] : 0.f;
+    float fxl = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int s = s_wave + 16 * m + 4 * g + reg;
+            const float ws = A.w[s];
+            const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                const float H = fmaf(acc[m][a][reg], sc, hv[a]);
+                acc[m][a][reg] = H;
+                mx = fmaxf(mx, H);
+            }
+            float Z = 0.f, hx = 0.f;
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                const float H = acc[m][a][reg] - mx;
+                hx = (a == xi) ? H : hx;
+                const float ev = __expf(H);
+                acc[m][a][reg] = ev;
+                Z += ev;
+            }
+            const float invZ = 1.f / Z;
+            if (site_ok) fxl -= ws * (hx - __logf(Z));
+            const float wr = site_ok ? ws * A.rscale : 0.f;
+#pragma unroll
+            for (int a = 0; a < Q; a++)
+                acc[m][a][reg] = wr * (acc[m][a][reg] * invZ - ((a == xi) ? 1.f : 0.f));
+        }
+    }
+    // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes) ----------------
+    const int sstep = s_wave >> 5;
+    _Float16 *rt = A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q) * 1024;  // 1024 halves per col frag
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int slot = ((2 * m + (g >> 1)) * 16 + r) * 8 + (g & 1) * 4;   // halves within a 512-half plane
+#pragma unroll
+        for (int a = 0; a < Q; a++) {
+            const f32x4 v = acc[m][a];
+            half4 hi, lo;
+            // half e = 4*(g&1) + {0,1,2,3} <-> sequence offset perm8(e): regs (0,2,1,3)
+            hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[2]; hi[2] = (_Float16)v[1]; hi[3] = (_Float16)v[3];
+            lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[2] - (float)hi[1]);
+            lo[2] = (_Float16)(v[1] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
+            *(half4 *)(rt + (size_t)a * 1024 + slot) = hi;
+            *(half4 *)(rt + (size_t)a * 1024 + 512 + slot) = lo;
+        }
+    }
+    __syncthreads();   // every wave is done with the B tiles: reuse the LDS for the reduction
+    const double tot = block_reduce_sum((double)fxl, (double *)smem);
+    if (tid == 0) A.fx_part[blockIdx.x] = tot;
+}
+
+hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
+                              const float *x, const int32_t *jexp, void *Rt, double *fx_part, hipStream_t st) {
+    FwdArgs A{msa_rm, w, (const char *)Bt, x, jexp, (_Float16 *)Rt, fx_part, ldexpf(1.f, PLM_R_EXP)};
+    const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
+    const size_t lds = (size_t)2 * 2 * d.Q * 1024;
+#define FWD_CASE(QQ)                                                                                   \
+    case QQ: {                                                                                         \
+        static bool attr_done = false;                                                                 \
+        if (!attr_done) {                                                                              \
+            hipError_t e = hipFuncSetAttribute((const void *)k_fwd<QQ>,                                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            if (e != hipSuccess) return e;                                                             \
+            attr_done = true;                                                                          \
+        }                                                                                              \
+        hipLaunchKernelGGL(k_fwd<QQ>, grid, block, lds, st, d, A);                                     \
+    } break;
+    switch (d.Q) {
+        FWD_CASE(21)
+        FWD_CASE(20)
+        FWD_CASE(5)
+        FWD_CASE(4)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef FWD_CASE
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// K_bwd: asymmetric gradient slab  G[(j,b),(i,a)] = sum_s [x_sj = b] * r_s(i,a)
+//   (row a6 backward half).  GEMM over K = sequences; A = one-hot of the column-major
+//   alignment expanded in registers, B = residual fragments (Rt) streamed through LDS.
+//   workgroup = 8 waves as 4 (rows) x 2 (cols); wave tile FM x FN accumulator fragments.
+//   Split-K over sequence ranges; XCD-aware block order keeps the row tiles that share a
+//   residual panel on one XCD (block b runs on XCD b % 8).
+// =========================================================================================
+template <int Q, int FM, int FN>
+__global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict__ msa_cm,
+                                            const char *__restrict__ Rt, float *__restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 2 * FN * 2 * 1024;  // 2*FN col fragments x 2 planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ngroups = d.ncol_tiles * d.ksplit;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = (slot / d.nrow_tiles) * 8 + xcd;
+    if (grp >= ngroups) return;
+    const int row_tile = slot % d.nrow_tiles;
+    const int col_tile = grp % d.ncol_tiles, ks = grp / d.ncol_tiles;
+    const int per = (d.nssteps + d.ksplit - 1) / d.ksplit;
+    const int k0 = ks * per, k1 = min(d.nssteps, k0 + per);
+
+    const int mf0 = (row_tile * 4 + wm) * FM;
+    const bool row_ok = mf0 < d.nmf;
+    const int j16 = row_ok ? mf0 / Q : 0, b0 = row_ok ? mf0 % Q : 0;
+    const int nfl0 = col_tile * 2 * FN;
+    const int r = lane & 15, g = lane >> 4;
+    const int8_t *acol = msa_cm + (size_t)(j16 * 16 + r) * d.Np + 8 * g;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int f = 0; f < FM; f++)
+#pragma unroll
+        for (int c = 0; c < FN; c++) acc[f][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int ss, int buf) {
+        char *dst = smem + buf * TILE;
+        for (int p = wave; p < 4 * FN; p += 8) {
+            const int c = p >> 1;   // col fragment within tile, plane = p & 1 (contiguous in Rt)
+            if (nfl0 + c < d.nnfl) {
+                const char *src = Rt + ((size_t)ss * d.nnfl + nfl0) * 2048 + (size_t)p * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+    if (k0 < k1) stage(k0, 0);
+    uint2 xa = (k0 < k1) ? *(const uint2 *)(acol + (size_t)32 * k0) : make_uint2(0, 0);
+    for (int ss = k0; ss < k1; ++ss) {
+        __syncthreads();
+        uint2 nx = xa;
+        if (ss + 1 < k1) {
+            stage(ss + 1, (ss + 1 - k0) & 1);
+            nx = *(const uint2 *)(acol + (size_t)32 * (ss + 1));
+        }
+        if (row_ok) {
+            const char *lb = smem + ((ss - k0) & 1) * TILE + (wn * FN) * 2048 + lane * 16;
+            half8 af[FM];
+#pragma unroll
+            for (int f = 0; f < FM; f++) af[f] = onehot8(xa.x, xa.y, (u32)(b0 + f) * 0x01010101u);
+#pragma unroll
+            for (int c = 0; c < FN; c++) {
+                const half8 bh = *(const half8 *)(lb + c * 2048);
+                const half8 bl = *(const half8 *)(lb + c * 2048 + 1024);
+#pragma unroll
+                for (int f = 0; f < FM; f++) {
+                    acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh, acc[f][c], 0, 0, 0);
+                    acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl, acc[f][c], 0, 0, 0);
+                }
+            }
+        }
+        xa = nx;
+    }
+    if (!row_ok) return;
+#pragma unroll
+    for (int f = 0; f < FM; f++)
+#pragma unroll
+        for (int c = 0; c < FN; c++) {
+            const int nfl = nfl0 + wn * FN + c;
+            if (nfl < d.nnfl)
+                *(f32x4 *)(G + ((((size_t)ks * d.nmf + mf0 + f) * d.nnfl + nfl) * 64 + lane) * 4) = acc[f][c];
+        }
+}
+
+hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G, hipStream_t st) {
+    const int ngroups = d.ncol_tiles * d.ksplit;
+    const dim3 grid(8 * ((ngroups + 7) / 8) * d.nrow_tiles), block(512);
+#define BWD_CASE(QQ, M, N)                                                                             \
+    case QQ: {                                                                                         \
+        const size_t lds = (size_t)2 * (2 * N * 2 * 1024);                                             \
+        static bool attr_done = false;                                                                 \
+        if (!attr_done) {                                                                              \
+            hipError_t e = hipFuncSetAttribute((const void *)k_bwd<QQ, M, N>,                          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            if (e != hipSuccess) return e;                                                             \
+            attr_done = true;                                                                          \
+        }                                                                                              \
+        hipLaunchKernelGGL((k_bwd<QQ, M, N>), grid, block, lds, st, d, msa_cm, (const char *)Rt, G);   \
+    } break;
+    switch (d.Q) {
+        BWD_CASE(21, 7, 7)
+        BWD_CASE(20, 5, 5)
+        BWD_CASE(5, 5, 5)
+        BWD_CASE(4, 4, 4)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef BWD_CASE
+    return hipGetLastError();
+}
+
+// sum the split-K partials into this shard's slab of the exchange buffer
+__global__ __launch_bounds__(256) void k_slab_reduce(const float4 *__restrict__ G, float4 *__restrict__ slab,
+                                                    int64_t n4, int ksplit) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = G[i];
+        for (int k = 1; k < ksplit; k++) {
+            const float4 t = G[i + (int64_t)k * n4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        slab[i] = s;
+    }
+}
+hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab, hipStream_t st) {
+    const int64_t n4 = (int64_t)d.nmf * d.nnfl * 64;
+    hipLaunchKernelGGL(k_slab_reduce, dim3(2048), dim3(256), 0, st, (const float4 *)G, (float4 *)slab, n4,
+                       d.ksplit);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// K_assemble: gradient in the native layout.
+//   block pair (I<=J), states (a,b), tile element (ii,jj):
+//     g = 2^-R * ( G[(J,b),(I,a)][jj][ii] + G[(I,a),(J,b)][ii][jj] ) + 2 lambda_J x
+//   An accumulator fragment stores element (row, col) at float index ((row>>2)*16+col)*4+(row&3).
+//   mode 1 (marginals): out = 2^-R * inv_neff * G[(J,b),(I,a)][jj][ii].
+// =========================================================================================
+__device__ __forceinline__ size_t g_frag(const PlmDims &d, int ks_count, size_t slab_stride, int block16,
+                                         int state, int mf) {
+    // fragment (row fragment mf, column = (block16, state)) -> float offset of partial 0
+    const int sh = block16 / d.blk_per_shard;
+    const int nfl = (block16 - sh * d.blk_per_shard) * d.Q + state;
+    return (size_t)sh * slab_stride + ((size_t)mf * d.nnfl + nfl) * 256;
+}
+__global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__restrict__ G, int ks_count,
+                                                 size_t slab_stride, const float *__restrict__ x,
+                                                 float *__restrict__ gout, float lambda_j,
+                                                 double *__restrict__ reg_part, int mode, float scale) {
+    __shared__ double red[4];
+    const int a = blockIdx.y;
+    // decode block pair
+    int I = 0;
+    int64_t rem = blockIdx.x;
+    while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
+    const int J = I + (int)rem;
+    const int ii = threadIdx.x >> 4, jj = threadIdx.x & 15;
+    const int i = I * 16 + ii, j = J * 16 + jj;
+    const bool valid = i < d.L && j < d.L && i < j;
+    const int t1 = ((jj >> 2) * 16 + ii) * 4 + (jj & 3);   // element [row=jj][col=ii]
+    const int t2 = ((ii >> 2) * 16 + jj) * 4 + (ii & 3);   // element [row=ii][col=jj]
+    const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
+    const size_t xoff = d.nh_pad + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
+    double reg = 0;
+    for (int b = 0; b < d.Q; b++) {
+        const size_t o1 = g_frag(d, ks_count, slab_stride, I, a, J * d.Q + b) + t1;
+        float v = 0.f;
+        for (int k = 0; k < ks_count; k++) v += G[o1 + k * kstride];
+        float out;
+        if (mode == 0) {
+            const size_t o2 = g_frag(d, ks_count, slab_stride, J, b, I * d.Q + a) + t2;
+            float v2 = 0.f;
+            for (int k = 0; k < ks_count; k++) v2 += G[o2 + k * kstride];
+            const float xv = x[xoff + (size_t)b * 256];
+            out = valid ? fmaf(scale, v + v2, 2.f * lambda_j * xv) : 0.f;
+            if (valid) reg += (double)xv * (double)xv;
+        } else {
+            out = valid ? scale * v : 0.f;
+        }
+        gout[xoff + (size_t)b * 256] = out;
+    }
+    if (mode == 0) {
+        const double t = block_reduce_sum(reg, red);
+        if (threadIdx.x == 0) reg_part[(size_t)blockIdx.x * d.Q + a] = (double)lambda_j * t;
+    }
+}
+// field part: column sums of the residuals arrive through the "ones" row fragment
+__global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__restrict__ G, int ks_count,
+                                                   size_t slab_stride, const float *__restrict__ x,
+                                                   float *__restrict__ gout, float lambda_h,
+                                                   double *__restrict__ reg_part, int mode, float scale) {
+    __shared__ double red[4];
+    double reg = 0;
+    const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
+    for (int64_t idx = threadIdx.x; idx < d.nh_pad; idx += 256) {
+        float out = 0.f;
+        if (idx < (int64_t)d.L * d.Q) {
+            const int i = (int)(idx / d.Q), a = (int)(idx % d.Q);
+            const size_t o = g_frag(d, ks_count, slab_stride, i >> 4, a, d.nb16 * d.Q) + (size_t)(i & 15) * 4;
+            float v = 0.f;
+            for (int k = 0; k < ks_count; k++) v += G[o + k * kstride];
+            if (mode == 0) {
+                const float xv = x[idx];
+                out = fmaf(scale, v, 2.f * lambda_h * xv);
+                reg += (double)xv * (double)xv;
+            } else {
+                out = scale * v;
+            }
+        }
+        gout[idx] = out;
+    }
+    if (mode == 0) {
+        const double t = block_reduce_sum(reg, red);
+        if (threadIdx.x == 0) reg_part[d.nbp * d.Q] = (double)lambda_h * t;
+    }
+}
+hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *x, float *g,
+                               float lambda_h, float lambda_j, double *reg_part, int mode, float inv_neff,
+                               hipStream_t st) {
+    const size_t slab_stride = plm_slab_bytes(d) / 4;
+    const float scale = ldexpf(1.f, -PLM_R_EXP) * (mode == 1 ? inv_neff : 1.f);
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.nbp, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride, x,
+                       g, lambda_j, reg_part, mode, scale);
+    hipLaunchKernelGGL(k_assemble_h, dim3(1), dim3(256), 0, st, d, G, ks_count, slab_stride, x, g, lambda_h,
+                       reg_part, mode, scale);
+    return hipGetLastError();
+}
+
+// fx = sum(nll partials) + sum(reg partials); nll either from local partials (single shard)
+// or from the per-shard sums that travelled in the slab tails
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ p, int n, double *out) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    const double t = block_reduce_sum(s, red);
+    if (threadIdx.x == 0) *out = t;
+}
+__global__ __launch_bounds__(256) void k_finish_fx(const double *__restrict__ fx_part, int nfx,
+                                                  const double *__restrict__ shard_nll, size_t shard_stride,
+                                                  int nshard, const double *__restrict__ reg_part, int nreg,
+                                                  double *out2) {
+    __shared__ double red[4];
+    double s = 0;
+    if (nshard > 0) {
+        if (threadIdx.x == 0)
+            for (int k = 0; k < nshard; k++) s += *(const double *)((const char *)shard_nll + k * shard_stride);
+    } else {
+        for (int i = threadIdx.x; i < nfx; i += 256) s += fx_part[i];
+    }
+    const double nll = block_reduce_sum(s, red);
+    __syncthreads();
+    double rsum = 0;
+    for (int i = threadIdx.x; i < nreg; i += 256) rsum += reg_part[i];
+    const double reg = block_reduce_sum(rsum, red);
+    if (threadIdx.x == 0) {
+        out2[0] = nll + reg;
+        out2[1] = nll;
+    }
+}
+hipError_t plm_launch_partial_sum(const double *part, int n, double *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, part, n, out);
+    return hipGetLastError();
+}
+hipError_t plm_launch_finish_fx(const PlmDims &d, const double *fx_part, int n_fx_part, const double *shard_nll,
+                                int n_shard_nll, const double *reg_part, int n_reg_part, double *out2,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(k_finish_fx, dim3(1), dim3(256), 0, st, fx_part, n_fx_part, shard_nll,
+                       plm_slab_bytes(d), n_shard_nll, reg_part, n_reg_part, out2);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// L-BFGS streaming kernels (row a7): dot products in f64, linear combinations in f32
+// =========================================================================================
+struct DotArgs {
+    const float *a[4];
+    const float *b[4];
+};
+template <int NP>
+__global__ __launch_bounds__(256) void k_dots(DotArgs A, int64_t n4, double *__restrict__ scratch) {
+    __shared__ double red[4];
+    double s[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) s[p] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const float4 u = ((const float4 *)A.a[p])[i], v = ((const float4 *)A.b[p])[i];
+            s[p] += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * v.z + (double)u.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const double t = block_reduce_sum(s[p], red);
+        if (threadIdx.x == 0) scratch[(size_t)p * PLM_DOT_BLOCKS + blockIdx.x] = t;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_dots_final(const double *__restrict__ scratch, double *out) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int i = threadIdx.x; i < PLM_DOT_BLOCKS; i += 256) s += scratch[(size_t)blockIdx.x * PLM_DOT_BLOCKS + i];
+    const double t = block_reduce_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+hipError_t plm_launch_dots(int npairs, const float *const *a, const float *const *b, int64_t n, double *scratch,
+                           double *out, hipStream_t st) {
+    if (npairs < 1 || npairs > 4 || (n & 3)) return hipErrorInvalidValue;
+    DotArgs A;
+    for (int p = 0; p < 4; p++) {
+        A.a[p] = a[p < npairs ? p : 0];
+        A.b[p] = b[p < npairs ? p : 0];
+    }
+    const int64_t n4 = n / 4;
+    switch (npairs) {
+    case 1: hipLaunchKernelGGL(k_dots<1>, dim3(PLM_DOT_BLOCKS), dim3(256), 0, st, A, n4, scratch); break;
+    case 2: hipLaunchKernelGGL(k_dots<2>, dim3(PLM_DOT_BLOCKS), dim3(256), 0, st, A, n4, scratch); break;
+    case 3: hipLaunchKernelGGL(k_dots<3>, dim3(PLM_DOT_BLOCKS), dim3(256), 0, st, A, n4, scratch); break;
+    default: hipLaunchKernelGGL(k_dots<4>, dim3(PLM_DOT_BLOCKS), dim3(256), 0, st, A, n4, scratch); break;
+    }
+    hipLaunchKernelGGL(k_dots_final, dim3(npairs), dim3(256), 0, st, scratch, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_lincomb(float4 *__restrict__ out, float ca, const float4 *__restrict__ a,
+                                                float cb, const float4 *__restrict__ b, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 u = a[i];
+        float4 r;
+        if (b) {
+            const float4 v = b[i];
+            r.x = fmaf(cb, v.x, ca * u.x); r.y = fmaf(cb, v.y, ca * u.y);
+            r.z = fmaf(cb, v.z, ca * u.z); r.w = fmaf(cb, v.w, ca * u.w);
+        } else {
+            r.x = ca * u.x; r.y = ca * u.y; r.z = ca * u.z; r.w = ca * u.w;
+        }
+        out[i] = r;
+    }
+}
+hipError_t plm_launch_lincomb(float *out, float ca, const float *a, float cb, const float *b, int64_t n,
+                              hipStream_t st) {
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lincomb, dim3(2048), dim3(256), 0, st, (float4 *)out, ca, (const float4 *)a, cb,
+                       (const float4 *)b, n / 4);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// layout conversion canonical <-> native, Frobenius norms of zero-sum-gauge blocks
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_canon_to_native(PlmDims d, const float *__restrict__ xc,
+                                                        float *__restrict__ xn) {
+    const int a = blockIdx.y;
+    int I = 0;
+    int64_t rem = blockIdx.x;
+    while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
+    const int J = I + (int)rem;
+    const int ii = threadIdx.x >> 4, jj = threadIdx.x & 15;
+    const int i = I * 16 + ii, j = J * 16 + jj;
+    const bool valid = i < d.L && j < d.L && i < j;
+    const size_t QQ = (size_t)d.Q * d.Q;
+    const size_t src = valid ? (size_t)d.L * d.Q + (size_t)plm_pair_index(i, j, d.L) * QQ + (size_t)a * d.Q : 0;
+    const size_t dst = d.nh_pad + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
+    for (int b = 0; b < d.Q; b++) xn[dst + (size_t)b * 256] = valid ? xc[src + b] : 0.f;
+}
+__global__ __launch_bounds__(256) void k_copy_h(PlmDims d, const float *__restrict__ src, float *__restrict__ dst,
+                                               int to_native) {
+    const int64_t n = to_native ? d.nh_pad : (int64_t)d.L * d.Q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = (i < (int64_t)d.L * d.Q) ? src[i] : 0.f;
+}
+__global__ __launch_bounds__(64) void k_native_to_canon(PlmDims d, const float *__restrict__ xn,
+                                                       float *__restrict__ xc) {
+    const int i = blockIdx.x, j = blockIdx.y;
+    if (j <= i) return;
+    const int I = i >> 4, J = j >> 4;
+    const int QQ = d.Q * d.Q;
+    const size_t src = d.nh_pad + (size_t)plm_bp_index(I, J, d.nb16) * QQ * 256 + (i & 15) * 16 + (j & 15);
+    const size_t dst = (size_t)d.L * d.Q + (size_t)plm_pair_index(i, j, d.L) * QQ;
+    for (int ab = threadIdx.x; ab < QQ; ab += 64) xc[dst + ab] = xn[src + (size_t)ab * 256];
+}
+hipError_t plm_launch_canon_to_native(const PlmDims &d, const float *xc, float *xn, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy_h, dim3(64), dim3(256), 0, st, d, xc, xn, 1);
+    hipLaunchKernelGGL(k_canon_to_native, dim3((unsigned)d.nbp, d.Q), dim3(256), 0, st, d, xc, xn);
+    return hipGetLastError();
+}
+hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *xc, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy_h, dim3(64), dim3(256), 0, st, d, xn, xc, 0);
+    hipLaunchKernelGGL(k_native_to_canon, dim3(d.L, d.L), dim3(64), 0, st, d, xn, xc);
+    return hipGetLastError();
+}
+
+// row a8: zero-sum gauge + Frobenius norm per pair (couplings/model.py:208-231, 792),
+// one wave per pair; means and the squared norm are accumulated in f64
+__global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict__ jij, float *__restrict__ fn) {
+    __shared__ float blk[32 * 32];
+    __shared__ double rm[32], cm[32];
+    __shared__ double red[1];
+    const int i = blockIdx.x, j = blockIdx.y;
+    if (j <= i) {
+        if (threadIdx.x == 0 && j == i) fn[(size_t)i * L + i] = 0.f;
+        return;
+    }
+    const int QQ = Q * Q;
+    const float *src = jij + (size_t)plm_pair_index(i, j, L) * QQ;
+    for (int k = threadIdx.x; k < QQ; k += 64) blk[k] = src[k];
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        double r = 0, c = 0;
+        for (int k = 0; k < Q; k++) {
+            r += blk[threadIdx.x * Q + k];
+            c += blk[k * Q + threadIdx.x];
+        }
+        rm[threadIdx.x] = r / Q;
+        cm[threadIdx.x] = c / Q;
+    }
+    __syncthreads();
+    double m = 0;
+    for (int k = 0; k < Q; k++) m += rm[k];
+    m /= Q;
+    double ss = 0;
+    for (int k = threadIdx.x; k < QQ; k += 64) {
+        const double z = (double)blk[k] - rm[k / Q] - cm[k % Q] + m;
+        ss += z * z;
+    }
+    const double t = block_reduce_sum(ss, red);
+    if (threadIdx.x == 0) {
+        const float v = (float)sqrt(t);
+        fn[(size_t)i * L + j] = v;
+        fn[(size_t)j * L + i] = v;
+    }
+}
+hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, hipStream_t st) {
+    hipLaunchKernelGGL(k_fn, dim3(d.L, d.L), dim3(64), 0, st, d.L, d.Q, jij_canon, fn);
+    return hipGetLastError();
+}

@@ -1,0 +1,265 @@
+"""
+Python host API over the C ABI of libplm_hip.so: numpy in, numpy out.
+
+This is the in-process replacement for what the reference obtains from the plmc child
+process (evcouplings/couplings/tools.py:202-307): sequence weights, frequencies, the
+fitted fields/couplings and the CN scores.  All arithmetic happens in the HIP library on
+an MI355X; nothing here computes on the CPU and there is no fallback path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from evcouplings_amd import _lib
+from evcouplings_amd._lib import PlmProblem, PlmResult, check
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _msa(msa):
+    msa = np.ascontiguousarray(msa, dtype=np.int8)
+    if msa.ndim != 2:
+        raise ValueError("msa must be a 2-D (N, L) int8 matrix")
+    return msa
+
+
+def n_params(L, q):
+    return L * q + L * (L - 1) // 2 * q * q
+
+
+def default_lambda_j(L, q, base=0.01):
+    """lambda_J * (q-1) * (L-1), the scaling of evcouplings/couplings/protocol.py:159-179."""
+    return base * (q - 1) * (L - 1)
+
+
+def device_count():
+    return _lib.load().plm_device_count()
+
+
+def reweight(msa, theta_id=0.8):
+    """Cluster sizes (incl. self) at identity >= theta_id; twin of alignment.py:1193-1233."""
+    lib = _lib.load()
+    msa = _msa(msa)
+    counts = np.zeros(msa.shape[0], dtype=np.int32)
+    check(lib.plm_reweight(_ptr(msa), msa.shape[0], msa.shape[1], float(theta_id), _ptr(counts)))
+    return counts
+
+
+def marginals(msa, weights, q, pairs=True):
+    """f_i (L,q) and f_ij (L(L-1)/2,q,q) for i<j; twin of alignment.py:1079-1153."""
+    lib = _lib.load()
+    msa = _msa(msa)
+    N, L = msa.shape
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    fi = np.zeros((L, q), dtype=np.float32)
+    fij = np.zeros((L * (L - 1) // 2, q, q), dtype=np.float32) if pairs else None
+    check(lib.plm_marginals(_ptr(msa), _ptr(w), N, L, q, _ptr(fi), _ptr(fij)))
+    return fi, fij
+
+
+def evaluate(msa, weights, q, lambda_h, lambda_j, x):
+    """Objective, its unregularised part and the gradient at x (canonical layout)."""
+    lib = _lib.load()
+    msa = _msa(msa)
+    N, L = msa.shape
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if x.size != n_params(L, q):
+        raise ValueError("x has %d entries, expected %d" % (x.size, n_params(L, q)))
+    g = np.zeros_like(x)
+    fx, nll = C.c_double(0), C.c_double(0)
+    check(lib.plm_eval(_ptr(msa), _ptr(w), N, L, q, float(lambda_h), float(lambda_j), _ptr(x),
+                       C.byref(fx), C.byref(nll), _ptr(g)))
+    return fx.value, nll.value, g
+
+
+def scores(jij, L, q):
+    """FN and CN (APC) matrices from i<j coupling blocks; twin of model.py:179-233, 744-827."""
+    lib = _lib.load()
+    jij = np.ascontiguousarray(jij, dtype=np.float32)
+    fn = np.zeros((L, L), dtype=np.float32)
+    cn = np.zeros((L, L), dtype=np.float32)
+    check(lib.plm_scores(_ptr(jij), L, q, _ptr(fn), _ptr(cn)))
+    return fn, cn
+
+
+def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, n_shards, shard):
+    N, L = msa.shape
+    p = PlmProblem()
+    p.n_seqs, p.n_sites, p.n_states = N, L, q
+    p.msa = msa.ctypes.data
+    p.theta_id, p.scale = float(theta_id), float(scale)
+    p.lambda_h, p.lambda_j = float(lambda_h), float(lambda_j)
+    p.max_iter, p.epsilon, p.lbfgs_m = int(max_iter), float(epsilon), int(lbfgs_m)
+    p.n_shards, p.shard, p.flags = int(n_shards), int(shard), 0
+    return p
+
+
+def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
+        epsilon=1e-3, lbfgs_m=6, device=0, stream=0, callback=None, n_shards=1, shard=0,
+        exchange=None, want_fij=True):
+    """
+    Whole couplings inference: reweight -> marginals -> L-BFGS -> scores.
+
+    callback(iter, secs, cond, fx, nll, norm_h, norm_e) is called once per iteration.
+    exchange(dev_ptr, bytes_per_shard, n_shards, shard) -> 0 implements the all-gather of
+    the site-sharded gradient slabs (see evcouplings_amd.dist) and is required iff n_shards > 1.
+    Returns a dict of numpy arrays and scalars.
+    """
+    lib = _lib.load()
+    msa = _msa(msa)
+    N, L = msa.shape
+    if lambda_j is None:
+        lambda_j = default_lambda_j(L, q)
+    npair = L * (L - 1) // 2
+    out = dict(
+        weights=np.zeros(N, np.float32), fi=np.zeros((L, q), np.float32),
+        fij=np.zeros((npair, q, q), np.float32) if want_fij else None,
+        hi=np.zeros((L, q), np.float32), jij=np.zeros((npair, q, q), np.float32),
+        fn=np.zeros((L, L), np.float32), cn=np.zeros((L, L), np.float32))
+    res = PlmResult()
+    for k in ("weights", "fi", "fij", "hi", "jij", "fn", "cn"):
+        setattr(res, k, None if out[k] is None else out[k].ctypes.data)
+    table = []
+
+    def _cb(it, secs, cond, fx, nll, nh, ne, user):
+        table.append((it, secs, cond, fx, nll, nh, ne))
+        if callback is not None:
+            callback(it, secs, cond, fx, nll, nh, ne)
+
+    cb = _lib.ITER_CB(_cb)
+    if exchange is not None:
+        xcb = _lib.EXCHANGE_CB(lambda buf, nbytes, ns, sh, user: int(exchange(buf, nbytes, ns, sh)))
+    else:
+        xcb = C.cast(None, _lib.EXCHANGE_CB)
+    prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
+                    n_shards, shard)
+    check(lib.plm_fit(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
+                      None, xcb, None))
+    out.update(
+        n_eff=float(res.n_eff), iters=int(res.iters_done), n_evals=int(res.n_evals),
+        status=int(res.status), status_msg=res.status_msg.decode("ascii", "replace"),
+        fx=float(res.fx), table=table, lambda_j=float(lambda_j),
+        seconds=dict(reweight=res.seconds_reweight, marginals=res.seconds_marginals,
+                     optimize=res.seconds_optimize, total=res.seconds_total))
+    return out
+
+
+class PlmContext:
+    """Alignment resident in HBM; step-wise access for benchmarks and the multi-GPU host."""
+
+    def __init__(self, msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None,
+                 max_iter=100, epsilon=1e-3, lbfgs_m=6, device=0, stream=0, n_shards=1, shard=0):
+        self.lib = _lib.load()
+        msa = _msa(msa)
+        self.N, self.L = msa.shape
+        self.q = q
+        self.lambda_j = default_lambda_j(self.L, q) if lambda_j is None else lambda_j
+        prob = _problem(msa, q, theta_id, scale, lambda_h, self.lambda_j, max_iter, epsilon, lbfgs_m,
+                        n_shards, shard)
+        self._h = C.c_void_p()
+        check(self.lib.plm_ctx_create(C.byref(prob), int(device), C.c_void_p(int(stream) or None),
+                                      C.byref(self._h)))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self.lib.plm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_exchange(self, exchange):
+        cb = _lib.EXCHANGE_CB(lambda buf, nbytes, ns, sh, user: int(exchange(buf, nbytes, ns, sh)))
+        self._keep.append(cb)
+        check(self.lib.plm_ctx_set_exchange(self._h, cb, None))
+
+    def set_options(self, max_iter=-1, epsilon=-1.0, lbfgs_m=-1):
+        check(self.lib.plm_ctx_set_options(self._h, int(max_iter), float(epsilon), int(lbfgs_m)))
+
+    def _set_max_iter(self, k):
+        self.set_options(max_iter=k)
+
+    def native_size(self):
+        return int(self.lib.plm_ctx_native_size(self._h))
+
+    def reweight(self):
+        check(self.lib.plm_ctx_reweight(self._h))
+        return self.weights()
+
+    def set_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        assert w.size == self.N
+        check(self.lib.plm_ctx_set_weights(self._h, _ptr(w)))
+
+    def weights(self):
+        w = np.zeros(self.N, np.float32)
+        counts = np.zeros(self.N, np.int32)
+        neff = C.c_float(0)
+        check(self.lib.plm_ctx_get_weights(self._h, _ptr(w), _ptr(counts), C.byref(neff)))
+        return w, counts, neff.value
+
+    def marginals(self, pairs=True):
+        fi = np.zeros((self.L, self.q), np.float32)
+        fij = np.zeros((self.L * (self.L - 1) // 2, self.q, self.q), np.float32) if pairs else None
+        check(self.lib.plm_ctx_marginals(self._h, _ptr(fi), _ptr(fij)))
+        return fi, fij
+
+    def set_x(self, x=None):
+        if x is not None:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            assert x.size == n_params(self.L, self.q)
+        check(self.lib.plm_ctx_set_x(self._h, _ptr(x)))
+
+    def get_x(self):
+        x = np.zeros(n_params(self.L, self.q), np.float32)
+        check(self.lib.plm_ctx_get_x(self._h, _ptr(x)))
+        return x
+
+    def get_g(self):
+        g = np.zeros(n_params(self.L, self.q), np.float32)
+        check(self.lib.plm_ctx_get_g(self._h, _ptr(g)))
+        return g
+
+    def eval(self, sync=True):
+        if not sync:
+            check(self.lib.plm_ctx_eval(self._h, None, None))
+            return None
+        fx, nll = C.c_double(0), C.c_double(0)
+        check(self.lib.plm_ctx_eval(self._h, C.byref(fx), C.byref(nll)))
+        return fx.value, nll.value
+
+    def optimize(self, callback=None):
+        res = PlmResult()
+        table = []
+
+        def _cb(it, secs, cond, fx, nll, nh, ne, user):
+            table.append((it, secs, cond, fx, nll, nh, ne))
+            if callback is not None:
+                callback(it, secs, cond, fx, nll, nh, ne)
+
+        cb = _lib.ITER_CB(_cb)
+        check(self.lib.plm_ctx_optimize(self._h, cb, None, C.byref(res)))
+        return dict(iters=int(res.iters_done), n_evals=int(res.n_evals), status=int(res.status),
+                    status_msg=res.status_msg.decode("ascii", "replace"), fx=float(res.fx),
+                    seconds=float(res.seconds_optimize), table=table)
+
+    def scores(self):
+        fn = np.zeros((self.L, self.L), np.float32)
+        cn = np.zeros((self.L, self.L), np.float32)
+        check(self.lib.plm_ctx_scores(self._h, _ptr(fn), _ptr(cn)))
+        return fn, cn
+
+    def time_kernels(self, reps=5):
+        ms = np.zeros(_lib.K_COUNT, np.float32)
+        check(self.lib.plm_ctx_time_kernels(self._h, int(reps), _ptr(ms)))
+        names = ["expand", "forward", "backward", "assemble", "total", "reweight"]
+        return dict(zip(names, ms.tolist()))

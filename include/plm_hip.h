@@ -1,0 +1,160 @@
+/*
+ * plm_hip.h -- C ABI of libplm_hip.so, the MI355X (gfx950) pseudo-likelihood Potts solver
+ * that replaces the external `plmc` process behind EVcouplings' couplings stage.
+ *
+ * Nothing like this ABI exists in the reference: its boundary for this path is a
+ * subprocess (evcouplings/couplings/tools.py:202-266 builds the argv, :266 launches it,
+ * :286 parses stderr).  Each entry point below names the piece of that boundary it
+ * replaces.  All functions return PLM_OK (0) or a negative PLM_E* code, never throw and
+ * never abort; plm_last_error() holds a message for the calling thread.  Host buffers are
+ * caller-owned; the library owns its device memory.  No torch types cross this boundary.
+ *
+ * Parameter-vector layout ("canonical", identical to the order of the plmc_v2 `.model`
+ * file, evcouplings/couplings/model.py:355-389):
+ *     x = [ h_i(a) : i<L, a<q ] ++ [ J_ij(a,b) : pairs i<j row-major, a<q (site i), b<q (site j) ]
+ */
+#ifndef PLM_HIP_H
+#define PLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLM_ABI_VERSION 1
+
+#define PLM_OK 0
+#define PLM_EINVAL (-1)      /* bad argument (NULL, size <= 0, state outside 0..q-1, ...) */
+#define PLM_ENOMEM (-2)      /* host or device allocation failed */
+#define PLM_EDEVICE (-3)     /* HIP runtime error / no gfx950 device */
+#define PLM_EUNSUPPORTED (-4)/* alphabet size not instantiated (supported: q = 21, 20, 5, 4) */
+#define PLM_ENUMERIC (-5)    /* NaN/Inf met in objective */
+#define PLM_ECALLBACK (-6)   /* exchange callback reported failure */
+
+/* optimisation end states (plm_result_t.status) -> "Gradient optimization: (.+)" line that
+ * tools.py:56,99 parses */
+#define PLM_STATUS_CONVERGED 0
+#define PLM_STATUS_MAXITER 1
+#define PLM_STATUS_LINESEARCH 2
+
+typedef struct plm_ctx plm_ctx_t;
+
+/* One inference problem.  Mirrors the plmc options run_plmc() can set
+ * (tools.py:126-130, 222-259): -t theta, -s scale, -lh, -le, -m iterations. */
+typedef struct {
+    int32_t n_seqs;      /* N  valid sequences */
+    int32_t n_sites;     /* L  model columns */
+    int32_t n_states;    /* q  alphabet size, gap first (alignment.py:25-26) */
+    const int8_t *msa;   /* host, row-major N x L, values 0..q-1 */
+    float theta_id;      /* identity threshold (0.8); cluster if ident >= ceil(theta*L - 1e-9) */
+    float scale;         /* cluster weight scale (plmc -s), w_s = scale / cluster size */
+    float lambda_h;      /* L2 strength on fields */
+    float lambda_j;      /* L2 strength on couplings, as passed to plmc -le (already scaled
+                            by (q-1)(L-1), protocol.py:179) */
+    int32_t max_iter;    /* L-BFGS iterations; 0 = until converged */
+    float epsilon;       /* stop when |g| / max(1,|x|) < epsilon */
+    int32_t lbfgs_m;     /* history length; 0 = default (6) */
+    int32_t n_shards;    /* site shards (GPUs); 1 = single GPU */
+    int32_t shard;       /* this process' shard index */
+    int32_t flags;       /* PLM_FLAG_* */
+} plm_problem_t;
+
+#define PLM_FLAG_NONE 0
+#define PLM_FLAG_VERBOSE 1
+
+/* Per-iteration progress: the 7 columns of plmc's stderr table that
+ * parse_plmc_log() collects (tools.py:59-83): iter time cond fx -loglk ||h|| ||e||. */
+typedef void (*plm_iter_cb)(int32_t iter, double secs, double cond, double fx, double nll,
+                            double norm_h, double norm_e, void *user);
+
+/* Exchange step of the site-sharded evaluation: every shard has
+ * written `bytes_per_shard` bytes at  dev_buf + shard * bytes_per_shard ; on return the
+ * whole buffer (n_shards * bytes_per_shard) must hold every shard's part.  The Python host
+ * implements it with torch.distributed.all_gather_into_tensor (RCCL).  Called on the
+ * context's stream after a stream synchronise; return 0 on success. */
+typedef int (*plm_exchange_cb)(void *dev_buf, size_t bytes_per_shard, int32_t n_shards,
+                               int32_t shard, void *user);
+
+typedef struct {
+    float *weights;      /* [N]            or NULL */
+    float *fi;           /* [L*q]          or NULL */
+    float *fij;          /* [L(L-1)/2*q*q] or NULL (i<j blocks, [a][b]) */
+    float *hi;           /* [L*q]          or NULL */
+    float *jij;          /* [L(L-1)/2*q*q] or NULL */
+    float *fn;           /* [L*L]          or NULL */
+    float *cn;           /* [L*L]          or NULL */
+    float n_eff;
+    int32_t iters_done;
+    int32_t n_evals;
+    int32_t status;      /* PLM_STATUS_* */
+    double fx;           /* final objective */
+    double seconds_reweight, seconds_marginals, seconds_optimize, seconds_total;
+    char status_msg[128];
+} plm_result_t;
+
+/* -- library ---------------------------------------------------------------------------- */
+int plm_version(void);                 /* PLM_ABI_VERSION */
+int plm_device_count(void);            /* visible gfx950 devices, or PLM_EDEVICE */
+const char *plm_strerror(int code);
+const char *plm_last_error(void);      /* thread-local message of the last failure */
+
+/* -- whole stage: replaces the `plmc` child process (tools.py:266) ----------------------- */
+/* Reweight -> marginals -> L-BFGS on the symmetric L2-regularised pseudo-likelihood ->
+ * zero-sum gauge / Frobenius / APC scores.  `stream` is a hipStream_t (0 = null stream);
+ * `device` the HIP device ordinal.  exchange/exchange_user are only used when
+ * problem->n_shards > 1. */
+int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
+            plm_iter_cb iter_cb, void *iter_user, plm_exchange_cb exchange, void *exchange_user);
+
+/* -- fine-grained, host buffers (parity tests) ------------------------------------------- */
+/* plmc sequence reweighting; twin: align/alignment.py:1193-1233.  counts[s] = cluster size. */
+int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, float theta_id,
+                 int32_t *counts_out);
+/* plmc marginals; twins: align/alignment.py:1079-1153.  weights need not be normalised. */
+int plm_marginals(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites,
+                  int32_t n_states, float *fi_out, float *fij_out);
+/* plmc objective + gradient at x (canonical layout). */
+int plm_eval(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites,
+             int32_t n_states, float lambda_h, float lambda_j, const float *x, double *fx_out,
+             double *nll_out, float *g_out);
+/* plmc EC scoring; twins: couplings/model.py:179-233, 744-775, 790-793.  fn/cn dense LxL. */
+int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_out,
+               float *cn_out);
+
+/* -- resident-context API (bench / multi-GPU host) ---------------------------------------- */
+/* Uploads the alignment once; everything below runs on data resident in HBM. */
+int plm_ctx_create(const plm_problem_t *problem, int device, void *stream, plm_ctx_t **out);
+void plm_ctx_destroy(plm_ctx_t *ctx);
+int plm_ctx_set_exchange(plm_ctx_t *ctx, plm_exchange_cb exchange, void *user);
+/* change the stop rule / history of later plm_ctx_optimize calls (negative = keep) */
+int plm_ctx_set_options(plm_ctx_t *ctx, int32_t max_iter, float epsilon, int32_t lbfgs_m);
+/* number of floats of the solver's internal ("native", 16-site blocked) parameter vector */
+int64_t plm_ctx_native_size(const plm_ctx_t *ctx);
+int plm_ctx_reweight(plm_ctx_t *ctx);                       /* fills device weights, N_eff */
+int plm_ctx_set_weights(plm_ctx_t *ctx, const float *weights_host);
+int plm_ctx_get_weights(plm_ctx_t *ctx, float *weights_host, int32_t *counts_host, float *n_eff);
+int plm_ctx_marginals(plm_ctx_t *ctx, float *fi_host, float *fij_host);
+int plm_ctx_set_x(plm_ctx_t *ctx, const float *x_canonical_host);   /* NULL = start point */
+int plm_ctx_get_x(plm_ctx_t *ctx, float *x_canonical_host);
+int plm_ctx_get_g(plm_ctx_t *ctx, float *g_canonical_host);
+/* one objective+gradient evaluation at the resident x; asynchronous unless fx_out != NULL */
+int plm_ctx_eval(plm_ctx_t *ctx, double *fx_out, double *nll_out);
+int plm_ctx_optimize(plm_ctx_t *ctx, plm_iter_cb cb, void *user, plm_result_t *result);
+int plm_ctx_scores(plm_ctx_t *ctx, float *fn_host, float *cn_host);
+/* average HIP-event duration (ms) of each kernel of the evaluation pipeline over `reps`
+ * evaluations: out_ms[PLM_K_*]; used by bench.py for the roofline block. */
+#define PLM_K_EXPAND 0
+#define PLM_K_FORWARD 1
+#define PLM_K_BACKWARD 2
+#define PLM_K_ASSEMBLE 3
+#define PLM_K_TOTAL 4
+#define PLM_K_REWEIGHT 5
+#define PLM_K_COUNT 6
+int plm_ctx_time_kernels(plm_ctx_t *ctx, int32_t reps, float *out_ms /* [PLM_K_COUNT] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLM_HIP_H */
