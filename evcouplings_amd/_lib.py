@@ -24,9 +24,9 @@ class PlmProblem(C.Structure):
     _fields_ = [
         ("n_seqs", C.c_int32), ("n_sites", C.c_int32), ("n_states", C.c_int32),
         ("msa", C.c_void_p),
-        ("theta_id", C.c_float), ("scale", C.c_float),
-        ("lambda_h", C.c_float), ("lambda_j", C.c_float),
-        ("max_iter", C.c_int32), ("epsilon", C.c_float), ("lbfgs_m", C.c_int32),
+        ("theta_id", C.c_double), ("scale", C.c_double),
+        ("lambda_h", C.c_double), ("lambda_j", C.c_double),
+        ("max_iter", C.c_int32), ("epsilon", C.c_double), ("lbfgs_m", C.c_int32),
         ("n_shards", C.c_int32), ("shard", C.c_int32), ("flags", C.c_int32),
     ]
 
@@ -52,15 +52,15 @@ SYMBOLS = [
     ("plm_last_error", C.c_char_p, []),
     ("plm_fit", C.c_int, [C.POINTER(PlmProblem), C.POINTER(PlmResult), C.c_int, _P, ITER_CB, _P,
                           EXCHANGE_CB, _P]),
-    ("plm_reweight", C.c_int, [_P, C.c_int32, C.c_int32, C.c_float, _P]),
+    ("plm_reweight", C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P]),
     ("plm_marginals", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
-    ("plm_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P,
+    ("plm_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P,
                            C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     ("plm_scores", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     ("plm_ctx_create", C.c_int, [C.POINTER(PlmProblem), C.c_int, _P, C.POINTER(_P)]),
     ("plm_ctx_destroy", None, [_P]),
     ("plm_ctx_set_exchange", C.c_int, [_P, EXCHANGE_CB, _P]),
-    ("plm_ctx_set_options", C.c_int, [_P, C.c_int32, C.c_float, C.c_int32]),
+    ("plm_ctx_set_options", C.c_int, [_P, C.c_int32, C.c_double, C.c_int32]),
     ("plm_ctx_native_size", C.c_int64, [_P]),
     ("plm_ctx_reweight", C.c_int, [_P]),
     ("plm_ctx_set_weights", C.c_int, [_P, _P]),

@@ -353,7 +353,7 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     PLM_TRY(check_device(device));
     PlmDims d;
     PLM_TRY(make_dims(*prob, &d));
-    if (!(prob->theta_id >= 0.f && prob->theta_id <= 1.f)) return fail(PLM_EINVAL, "theta_id must be in [0,1]");
+    if (!(prob->theta_id >= 0.0 && prob->theta_id <= 1.0)) return fail(PLM_EINVAL, "theta_id must be in [0,1]");
     if (prob->lambda_h < 0 || prob->lambda_j < 0) return fail(PLM_EINVAL, "negative regularisation strength");
     for (size_t k = 0; k < (size_t)d.N * d.L; k++)
         if (prob->msa[k] < 0 || prob->msa[k] >= d.Q)
@@ -415,7 +415,7 @@ int plm_ctx_set_exchange(plm_ctx_t *c, plm_exchange_cb exchange, void *user) {
     return PLM_OK;
 }
 
-int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, float epsilon, int32_t lbfgs_m) {
+int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, double epsilon, int32_t lbfgs_m) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (max_iter >= 0) c->prob.max_iter = max_iter;
     if (epsilon >= 0) c->prob.epsilon = epsilon;
@@ -462,7 +462,7 @@ int plm_ctx_reweight(plm_ctx_t *c) {
     }
     HIP_TRY(hipStreamSynchronize(c->st));
     std::vector<float> w(d.N);
-    const float scale = c->prob.scale > 0 ? c->prob.scale : 1.f;
+    const float scale = c->prob.scale > 0 ? (float)c->prob.scale : 1.f;
     for (int s = 0; s < d.N; s++) {
         if (counts[s] < 1) return fail(PLM_ENUMERIC, "sequence %d has cluster size %d", s, counts[s]);
         w[s] = scale / (float)counts[s];
@@ -550,6 +550,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     const double eps = c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3;
     const int max_ls = 20;
     const double ftol = 1e-4, gtol = 0.9, xtol = 1e-7, stpmin = 1e-20, stpmax = 1e20;
+    // f is an f64 sum of f32 terms: once an iteration's decrease drowns in that rounding noise the
+    // sufficient-decrease test is replaced by "f did not rise beyond noise" + the curvature
+    // condition (approximate Wolfe, Hager & Zhang 2005); same rule as the f32 oracle build
+    const double epsf = 1e-6;
     PLM_TRY(ctx_alloc_lbfgs(c, m));
     float *S = c->hist, *Y = c->hist + (size_t)m * n;
     std::vector<double> alpha(m), ys(m);
@@ -581,7 +585,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     PLM_TRY(norms(&xnorm, &gnorm, &hn, &en));
     double fx = c->h_scal[0], nll = c->h_scal[1];
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
-    int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED;
+    int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0;
     if (gnorm / std::max(1.0, xnorm) > eps) {
         HIP_TRY(plm_launch_lincomb(c->dir, -1.f, c->g, 0.f, nullptr, n, c->st));
         double step = 1.0 / gnorm;
@@ -590,7 +594,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             HIP_TRY(hipMemcpyAsync(c->gp, c->g, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
             double dginit;
             PLM_TRY(dot1(c->g, c->dir, &dginit));
-            if (!(dginit < 0)) { status = PLM_STATUS_LINESEARCH; k--; break; }
+            if (!(dginit < 0)) { status = PLM_STATUS_LINESEARCH; ls_reason = 10; k--; break; }
             const double finit = fx, nllinit = nll, dgtest = ftol * dginit;
             int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
             double width = stpmax - stpmin, prev_width = 2.0 * width;
@@ -616,7 +620,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 if (stp == stpmin && (ftest1 < fx || dgtest <= dg)) { lsrc = -3; break; }
                 if (brackt && stmax - stmin <= xtol * stmax) { lsrc = -4; break; }
                 if (count >= max_ls) { lsrc = -5; break; }
-                if (fx <= ftest1 && std::fabs(dg) <= gtol * (-dginit)) { lsrc = 1; break; }
+                if ((fx <= ftest1 || fx <= finit + epsf * std::fabs(finit)) && std::fabs(dg) <= gtol * (-dginit)) {
+                    lsrc = 1;
+                    break;
+                }
                 if (stage1 && fx <= ftest1 && std::min(ftol, gtol) * dginit <= dg) stage1 = 0;
                 if (stage1 && ftest1 < fx && fx <= fxx) {
                     double fm = fx - stp * dgtest, fxm = fxx - stx * dgtest, fym = fy - sty * dgtest;
@@ -641,6 +648,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     nll = nllinit;
                 }
                 status = PLM_STATUS_LINESEARCH;
+                ls_reason = -lsrc;
                 k--;
                 break;
             }
@@ -691,7 +699,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         res->fx = fx;
         res->n_eff = (float)c->n_eff;
         res->seconds_optimize = now_s() - t0;
-        snprintf(res->status_msg, sizeof res->status_msg, "%s", status_text(status));
+        if (status == PLM_STATUS_LINESEARCH)
+            snprintf(res->status_msg, sizeof res->status_msg, "%s [code %d]", status_text(status), ls_reason);
+        else
+            snprintf(res->status_msg, sizeof res->status_msg, "%s", status_text(status));
     }
     return PLM_OK;
 }
@@ -777,11 +788,11 @@ static plm_problem_t basic_problem(const int8_t *msa, int n, int l, int q) {
     plm_problem_t p;
     memset(&p, 0, sizeof p);
     p.n_seqs = n; p.n_sites = l; p.n_states = q; p.msa = msa;
-    p.theta_id = 0.8f; p.scale = 1.f; p.n_shards = 1;
+    p.theta_id = 0.8; p.scale = 1.0; p.n_shards = 1;
     return p;
 }
 
-int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, float theta_id, int32_t *counts_out) {
+int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id, int32_t *counts_out) {
     if (!msa || !counts_out) return fail(PLM_EINVAL, "NULL argument");
     // reweighting compares raw bytes; any state value 0..126 is legal here, so borrow q = 21
     // only for the context's tiling and validate the range ourselves
@@ -824,7 +835,7 @@ int plm_marginals(const int8_t *msa, const float *weights, int32_t n_seqs, int32
 }
 
 int plm_eval(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites, int32_t n_states,
-             float lambda_h, float lambda_j, const float *x, double *fx_out, double *nll_out, float *g_out) {
+             double lambda_h, double lambda_j, const float *x, double *fx_out, double *nll_out, float *g_out) {
     if (!msa || !weights || !x) return fail(PLM_EINVAL, "NULL argument");
     plm_problem_t p = basic_problem(msa, n_seqs, n_sites, n_states);
     p.lambda_h = lambda_h;

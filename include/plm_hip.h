@@ -48,13 +48,13 @@ typedef struct {
     int32_t n_sites;     /* L  model columns */
     int32_t n_states;    /* q  alphabet size, gap first (alignment.py:25-26) */
     const int8_t *msa;   /* host, row-major N x L, values 0..q-1 */
-    float theta_id;      /* identity threshold (0.8); cluster if ident >= ceil(theta*L - 1e-9) */
-    float scale;         /* cluster weight scale (plmc -s), w_s = scale / cluster size */
-    float lambda_h;      /* L2 strength on fields */
-    float lambda_j;      /* L2 strength on couplings, as passed to plmc -le (already scaled
+    double theta_id;     /* identity threshold (0.8); cluster if ident >= ceil(theta*L - 1e-9) */
+    double scale;        /* cluster weight scale (plmc -s), w_s = scale / cluster size */
+    double lambda_h;     /* L2 strength on fields */
+    double lambda_j;     /* L2 strength on couplings, as passed to plmc -le (already scaled
                             by (q-1)(L-1), protocol.py:179) */
     int32_t max_iter;    /* L-BFGS iterations; 0 = until converged */
-    float epsilon;       /* stop when |g| / max(1,|x|) < epsilon */
+    double epsilon;      /* stop when |g| / max(1,|x|) < epsilon */
     int32_t lbfgs_m;     /* history length; 0 = default (6) */
     int32_t n_shards;    /* site shards (GPUs); 1 = single GPU */
     int32_t shard;       /* this process' shard index */
@@ -110,14 +110,14 @@ int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void
 
 /* -- fine-grained, host buffers (parity tests) ------------------------------------------- */
 /* plmc sequence reweighting; twin: align/alignment.py:1193-1233.  counts[s] = cluster size. */
-int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, float theta_id,
+int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id,
                  int32_t *counts_out);
 /* plmc marginals; twins: align/alignment.py:1079-1153.  weights need not be normalised. */
 int plm_marginals(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites,
                   int32_t n_states, float *fi_out, float *fij_out);
 /* plmc objective + gradient at x (canonical layout). */
 int plm_eval(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites,
-             int32_t n_states, float lambda_h, float lambda_j, const float *x, double *fx_out,
+             int32_t n_states, double lambda_h, double lambda_j, const float *x, double *fx_out,
              double *nll_out, float *g_out);
 /* plmc EC scoring; twins: couplings/model.py:179-233, 744-775, 790-793.  fn/cn dense LxL. */
 int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_out,
@@ -129,7 +129,7 @@ int plm_ctx_create(const plm_problem_t *problem, int device, void *stream, plm_c
 void plm_ctx_destroy(plm_ctx_t *ctx);
 int plm_ctx_set_exchange(plm_ctx_t *ctx, plm_exchange_cb exchange, void *user);
 /* change the stop rule / history of later plm_ctx_optimize calls (negative = keep) */
-int plm_ctx_set_options(plm_ctx_t *ctx, int32_t max_iter, float epsilon, int32_t lbfgs_m);
+int plm_ctx_set_options(plm_ctx_t *ctx, int32_t max_iter, double epsilon, int32_t lbfgs_m);
 /* number of floats of the solver's internal ("native", 16-site blocked) parameter vector */
 int64_t plm_ctx_native_size(const plm_ctx_t *ctx);
 int plm_ctx_reweight(plm_ctx_t *ctx);                       /* fills device weights, N_eff */

@@ -386,6 +386,7 @@ typedef struct {
     int m;           /* history */
     int max_ls;      /* function evaluations per line search */
     double ftol, gtol, xtol, stpmin, stpmax;
+    double epsf;     /* relative noise allowance on f in the sufficient-decrease test */
 } lbfgs_opt_t;
 
 /* returns number of iterations done (>=0) or a negative error; status: 0 converged,
@@ -446,7 +447,13 @@ static int lbfgs_run(evalctx_t *c, size_t n, real *x, const lbfgs_opt_t *o, plmo
                 if (stp == o->stpmin && (ftest1 < fx || dgtest <= dg)) { lsrc = -3; break; }
                 if (brackt && stmax - stmin <= o->xtol * stmax) { lsrc = -4; break; }
                 if (count >= o->max_ls) { lsrc = -5; break; }
-                if (fx <= ftest1 && fabs(dg) <= o->gtol * (-dginit)) { lsrc = 1; break; }
+                /* accept on strong Wolfe; once the decrease drowns in rounding noise of f, fall back
+                 * to "f did not rise beyond noise" + the curvature condition (the approximate Wolfe
+                 * idea of Hager & Zhang 2005) so the gradient test can still be reached */
+                if ((fx <= ftest1 || fx <= finit + o->epsf * fabs(finit)) && fabs(dg) <= o->gtol * (-dginit)) {
+                    lsrc = 1;
+                    break;
+                }
                 if (stage1 && fx <= ftest1 && fmin(o->ftol, o->gtol) * dginit <= dg) stage1 = 0;
                 if (stage1 && ftest1 < fx && fx <= fxx) {
                     double fm = fx - stp * dgtest, fxm = fxx - stx * dgtest, fym = fy - sty * dgtest;
@@ -567,7 +574,8 @@ int PLMO_NAME(fit)(const int8_t *msa, int N, int L, int q, double theta_id, doub
         for (int a = 0; a < q; a++) x_out[(size_t)i * q + a] -= (real)mean;
     }
     evalctx_t c = {msa, w, N, L, q, lambda_h, lambda_j, 0};
-    lbfgs_opt_t o = {max_iter, epsilon, lbfgs_m > 0 ? lbfgs_m : 6, 20, 1e-4, 0.9, 1e-16, 1e-20, 1e20};
+    lbfgs_opt_t o = {max_iter, epsilon, lbfgs_m > 0 ? lbfgs_m : 6, 20, 1e-4, 0.9, 1e-16, 1e-20, 1e20,
+                     sizeof(real) == 4 ? 1e-6 : 1e-13};
     int status = 0;
     double fx = 0;
     const int iters = lbfgs_run(&c, n, x_out, &o, cb, user, &fx, &status);

@@ -1,7 +1,12 @@
 import os
 import sys
 
-import pytest
+# the oracle's OpenMP loops are tiny in the tests: a thread per core of a 128-core GPU host
+# (possibly under a CPU quota) only adds barrier overhead
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
