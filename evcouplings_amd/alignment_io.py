@@ -1,0 +1,141 @@
+"""
+Alignment input for the couplings stage: A2M/FASTA -> the int8 state matrix the HIP
+solver consumes, following plmc's focus-mode conventions as the reference relies on them.
+
+Rules restated here (in-repo statement of the same column rule:
+evcouplings/couplings/mean_field.py:103-120):
+  * focus mode: model columns = positions where the focus sequence has an UPPERCASE,
+    non-gap character; everything else ('.', '-', lowercase in the focus row) is dropped.
+  * index_list[i] = region_start + number of focus-sequence residues (letters of either
+    case) before that column; region_start comes from the ``NAME/start-end`` header
+    (evcouplings/couplings/tools.py:219 passes only NAME to plmc -f).
+  * a sequence with a symbol outside the alphabet in a kept column is INVALID: it is
+    excluded from the model and counted in N_invalid (plmc behaviour [recollection]; the
+    in-repo Alignment class instead maps unknown symbols to gap, alignment.py:446-476 --
+    deliberately not copied).  '.' in a kept column is treated as the gap character.
+  * non-focus mode (focus_seq=None): every column is a model column, numbering 1..L,
+    the first record supplies target_seq.
+"""
+import re
+
+import numpy as np
+
+ALPHABET_PROTEIN = "-ACDEFGHIKLMNPQRSTVWY"   # evcouplings/align/alignment.py:25-26
+
+
+class AlignmentFormatError(ValueError):
+    pass
+
+
+def read_fasta_records(path):
+    """-> (ids, sequences) with sequences as python bytes objects (A2M is FASTA-framed)."""
+    ids, seqs, cur = [], [], []
+    with open(path, "rb") as f:
+        for raw in f:
+            line = raw.strip()
+            if not line:
+                continue
+            if line.startswith(b">"):
+                if ids:
+                    seqs.append(b"".join(cur))
+                ids.append(line[1:].decode("ascii", "replace"))
+                cur = []
+            else:
+                if not ids:
+                    raise AlignmentFormatError("sequence data before the first '>' header in %s" % path)
+                cur.append(line)
+    if ids:
+        seqs.append(b"".join(cur))
+    if not ids:
+        raise AlignmentFormatError("no sequences in %s" % path)
+    return ids, seqs
+
+
+def parse_region(header):
+    """'NAME/start-end ...' -> (NAME, start, end); start/end None if absent."""
+    name = header.split()[0] if header.split() else header
+    m = re.match(r"^(.*)/(\d+)-(\d+)$", name)
+    if m:
+        return m.group(1), int(m.group(2)), int(m.group(3))
+    return name, None, None
+
+
+class EncodedAlignment:
+    """Result of encode_alignment(); plain attributes, numpy arrays."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def encode_alignment(path, focus_seq=None, alphabet=None):
+    """
+    Read an A2M/FASTA alignment and encode it for the solver.
+
+    Returns EncodedAlignment with
+      msa            int8 (N_valid, L) states 0..q-1, valid sequences in file order
+      valid          bool (N_total,)   which input sequences are valid
+      focus_index    1-based index of the focus sequence among all sequences, or None
+      columns        indices of the kept alignment columns
+      index_list     int32 (L,) sequence numbering of the model columns
+      target_seq     str of length L
+      region_start   int
+      n_total_sites  number of residues of the focus sequence (focus mode) / columns
+      alphabet       the alphabet used (gap first)
+    """
+    alphabet = ALPHABET_PROTEIN if alphabet is None else alphabet
+    if len(set(alphabet)) != len(alphabet) or len(alphabet) < 2 or len(alphabet) > 32:
+        raise AlignmentFormatError("alphabet must hold 2..32 distinct symbols, gap first")
+    ids, seqs = read_fasta_records(path)
+    width = len(seqs[0])
+    for k, s in enumerate(seqs):
+        if len(s) != width:
+            raise AlignmentFormatError("sequence %d (%s) has length %d, expected %d" % (k + 1, ids[k], len(s), width))
+    n_total = len(seqs)
+    mat = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(n_total, width)
+    gap = ord(alphabet[0])
+
+    focus_index = None
+    region_start = 1
+    if focus_seq is not None:
+        want = focus_seq.split("/")[0]            # tools.py:219
+        hit = [k for k, h in enumerate(ids) if parse_region(h)[0] == want or h.split()[0] == focus_seq]
+        if not hit:
+            raise AlignmentFormatError("focus sequence %r not found in %s" % (focus_seq, path))
+        fk = hit[0]
+        focus_index = fk + 1
+        frow = mat[fk]
+        is_upper = (frow >= ord("A")) & (frow <= ord("Z"))
+        is_lower = (frow >= ord("a")) & (frow <= ord("z"))
+        columns = np.nonzero(is_upper)[0]
+        residues_before = np.cumsum(is_upper | is_lower) - 1      # 0-based residue index per column
+        _, start, _ = parse_region(ids[fk])
+        region_start = start if start is not None else 1
+        index_list = (region_start + residues_before[columns]).astype(np.int32)
+        n_total_sites = int((is_upper | is_lower).sum())
+        target_seq = frow[columns].tobytes().decode("ascii")
+    else:
+        columns = np.arange(width)
+        index_list = np.arange(1, width + 1, dtype=np.int32)
+        n_total_sites = width
+        target_seq = mat[0].tobytes().decode("ascii")
+
+    if columns.size < 2:
+        raise AlignmentFormatError("fewer than 2 model columns")
+    sub = mat[:, columns]
+    lut = np.full(256, -1, dtype=np.int8)
+    for k, ch in enumerate(alphabet):
+        lut[ord(ch)] = k
+    lut[ord(".")] = 0                               # insert-gap in a match column counts as gap
+    enc = lut[sub]
+    valid = (enc >= 0).all(axis=1)
+    if focus_index is not None and not valid[focus_index - 1]:
+        raise AlignmentFormatError("focus sequence contains symbols outside the alphabet")
+    if not valid.any():
+        raise AlignmentFormatError("no valid sequences")
+    if focus_index is None:
+        target_seq = "".join(alphabet[k] if k >= 0 else "-" for k in enc[0]) if valid[0] else target_seq
+    return EncodedAlignment(
+        msa=np.ascontiguousarray(enc[valid]), valid=valid, focus_index=focus_index,
+        columns=columns, index_list=index_list, target_seq=target_seq, region_start=int(region_start),
+        n_total_sites=int(n_total_sites), n_total_seqs=int(n_total), n_valid_seqs=int(valid.sum()),
+        alphabet=alphabet, gap=chr(gap), ids=ids)

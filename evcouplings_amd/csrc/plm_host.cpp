@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -599,6 +600,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
             double width = stpmax - stpmin, prev_width = 2.0 * width;
             double stx = 0, fxx = finit, dgx = dginit, sty = 0, fy = finit, dgy = dginit, stp = step, stmin, stmax;
+            double trace[64][3];
             for (;;) {
                 if (brackt) { stmin = std::min(stx, sty); stmax = std::max(stx, sty); }
                 else { stmin = stx; stmax = stp + 4.0 * (stp - stx); }
@@ -614,6 +616,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 nll = c->h_scal[1];
                 if (!std::isfinite(fx)) { fx = INFINITY; dg = 0; }
                 const double ftest1 = finit + stp * dgtest;
+                if (count < 64) { trace[count][0] = stp; trace[count][1] = fx - finit; trace[count][2] = dg; }
                 count++;
                 if (brackt && (stp <= stmin || stmax <= stp || uinfo)) { lsrc = -1; break; }
                 if (stp == stpmax && fx <= ftest1 && dg <= dgtest) { lsrc = -2; break; }
@@ -639,6 +642,11 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     prev_width = width;
                     width = std::fabs(sty - stx);
                 }
+            }
+            if (lsrc < 0 && getenv("PLM_DEBUG")) {
+                fprintf(stderr, "[plm] line search failed at iteration %d: code %d, finit=%.6f dginit=%.6e step0=%.3e brackt=%d stx=%.6e sty=%.6e\n", k, -lsrc, finit, dginit, step, brackt, stx, sty);
+                for (int t = 0; t < count && t < 64; t++)
+                    fprintf(stderr, "[plm]   trial %d: stp=%.9e  f-f0=%.6e  dg=%.6e\n", t, trace[t][0], trace[t][1], trace[t][2]);
             }
             if (lsrc < 0) {
                 if (!(fx <= finit)) {  // restore the last accepted point

@@ -31,7 +31,7 @@ def shard_blocks(n_sites, n_shards):
 
 def shard_sites(n_sites, n_shards):
     """Site ranges [lo, hi) owned by each shard."""
-    return [(16 * lo, min(n_sites, 16 * hi)) for lo, hi in shard_blocks(n_sites, n_shards)]
+    return [(min(n_sites, 16 * lo), min(n_sites, 16 * hi)) for lo, hi in shard_blocks(n_sites, n_shards)]
 
 
 def all_gather_inplace(buf, n_shards, shard, group=None):

@@ -154,6 +154,42 @@ def main():
     tab = pd.read_csv(ec_path, sep=" ", names=["i", "A_i", "j", "A_j", "fn", "cn"])
     assert len(tab) == npair and (tab["fn"] == 0).all()
     np.testing.assert_allclose(tab.sort_values(["i", "j"])["cn"].values, ecs["cn"].values, atol=5.1e-7)
+    # ---- (4) stderr grammar: our log text -> the reference's parse_plmc_log (tools.py:20-108)
+    import ast
+    import json
+    import re as _re
+    tools_path = os.path.join(REF, "evcouplings/couplings/tools.py")
+    tsrc = open(tools_path).read()
+    fn = [n for n in ast.parse(tsrc).body if isinstance(n, ast.FunctionDef) and n.name == "parse_plmc_log"][0]
+    ns = {"re": _re, "pd": pd}
+    exec(compile(ast.get_source_segment(tsrc, fn), tools_path, "exec"), ns)
+    from evcouplings_amd import tools as our_tools
+    table = [(1, 0.0123, 2984.1234567, 31645564.4534, 31645153.2858, 187.448, 1.0),
+             (2, 0.0381, 2857.0, 29529698.8806, 29525634.5811, 187.429, 7.88),
+             (3, 1.5, 0.000912, 13235552.0132, 10736296.9835, 185.93, 204.421)]
+    cases = {
+        "focus": dict(focus_name="SYN", focus_index=1, n_valid=49990, n_total=50000, n_sites=300,
+                      n_total_sites=312, region_start=17, n_eff=12345.678,
+                      status_msg="converged (|g|/max(1,|x|) below epsilon)", table=table),
+        "nofocus": dict(focus_name=None, focus_index=None, n_valid=10, n_total=12, n_sites=20,
+                        n_total_sites=20, region_start=1, n_eff=7.0,
+                        status_msg="maximum number of iterations reached", table=table[:1]),
+    }
+    out = {}
+    for name, kw in cases.items():
+        text = our_tools.format_plmc_log(**kw)
+        iter_df, fields = ns["parse_plmc_log"](text)
+        out[name] = dict(inputs={k: v for k, v in kw.items()}, log=text, parsed_fields=list(fields),
+                         iter_columns=list(iter_df.columns), iter_rows=iter_df.values.tolist())
+        assert fields[1] == kw["n_valid"] and fields[2] == kw["n_total"]
+        assert fields[6] == float("%.1f" % kw["n_eff"]) and fields[7] == kw["status_msg"]
+        assert len(iter_df) == len(kw["table"]) and list(iter_df.columns) == our_tools.ITER_COLUMNS
+        if kw["focus_index"] is not None:
+            assert fields[0] == kw["focus_index"] and fields[3:6] == (kw["n_sites"], kw["n_total_sites"], kw["region_start"])
+        else:
+            assert fields[0] is None and fields[3] is None and fields[5] == 1
+    with open(os.path.join(HERE, "plmc_log.json"), "w") as f:
+        json.dump(out, f, indent=1)
     print("golden vectors written to", HERE)
 
 

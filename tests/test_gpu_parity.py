@@ -182,3 +182,66 @@ def test_sharded_evaluation_matches_single(plm, oracle64):
         fx, nll, g = LoopbackShards(msa, w, Q, 0.01, 7.8, n_shards).evaluate(x)
         assert fx == pytest.approx(fx1, rel=1e-6)
         np.testing.assert_allclose(g, g1, atol=1e-5 * np.abs(g1).max(), rtol=1e-5)
+
+
+# ---------------------------------------------------------------- the boundary (rows a1-a3, a9-a11)
+def test_run_plmc_hip_end_to_end_files_and_result(plm, tmp_path):
+    from evcouplings_amd import model_io, tools
+    from evcouplings_amd.synthetic import msa_to_a2m
+    N, L = 800, 30
+    msa, planted = synthetic_msa(N, L, seed=17)
+    # two invalid sequences (X) and lowercase/insert columns around the model columns
+    ali = str(tmp_path / "in.a2m")
+    msa_to_a2m(msa, ali, region_start=5)
+    lines = open(ali).read().split("\n")
+    lines[5] = "X" + lines[5][1:]
+    lines[9] = lines[9][:3] + "X" + lines[9][4:]
+    open(ali, "w").write("\n".join(lines))
+    ec, model = str(tmp_path / "out" / "t_ECs.txt"), str(tmp_path / "out" / "t.model")
+    lam_j = plm.default_lambda_j(L, Q)
+    res = tools.run_plmc_hip(ali, ec, model, focus_seq="SYN/5-34", theta=0.8, scale=1.0, iterations=60,
+                             lambda_h=0.01, lambda_J=lam_j, lambda_g=0.0, cpu=2)
+    assert isinstance(res, tools.PlmcResult) and res._fields[0] == "couplings_file"
+    assert res.num_valid_seqs == N - 2 and res.num_total_seqs == N and res.focus_seq_index == 1
+    assert res.num_valid_sites == L and res.num_total_sites == L and res.region_start == 5
+    assert type(res.effective_samples) is float and type(res.num_valid_seqs) is int     # YAML-serialisable
+    assert list(res.iteration_table.columns) == tools.ITER_COLUMNS and len(res.iteration_table) == 60
+    m = model_io.read_model_file(model)
+    assert (m["L"], m["q"], m["n_valid"], m["n_invalid"], m["num_iter"]) == (L, Q, N - 2, 2, 60)
+    assert m["theta"] == pytest.approx(0.2) and m["lambda_j"] == pytest.approx(lam_j, rel=1e-6)
+    assert m["weights"].shape == (N,) and m["weights"][2] == 0 and m["weights"][4] == 0   # invalid rows
+    assert m["n_eff"] == pytest.approx(m["weights"].sum(), rel=1e-5)
+    assert m["index_list"].tolist() == list(range(5, 35)) and m["alphabet"][0] == "-"
+    # the EC file is the CN of the written couplings (what CouplingsModel.ecs re-derives, model.py:777)
+    fn, cn = plm.scores(m["jij"], L, Q)
+    import pandas as pd
+    tab = pd.read_csv(ec, sep=" ", names=["i", "A_i", "j", "A_j", "fn", "cn"])
+    iu, ju = np.triu_indices(L, 1)
+    np.testing.assert_allclose(tab["cn"].values, cn[iu, ju], atol=2e-6)
+    assert tab["i"].tolist() == (5 + iu).tolist() and tab["j"].tolist() == (5 + ju).tolist()
+    np.testing.assert_allclose(m["fi"].sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_cli_shim_log_is_parseable(plm, tmp_path):
+    import re
+    import subprocess
+    import sys
+    from evcouplings_amd.synthetic import msa_to_a2m
+    msa, _ = synthetic_msa(300, 20, seed=4)
+    ali = msa_to_a2m(msa, str(tmp_path / "in.a2m"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ec, model = str(tmp_path / "e.txt"), str(tmp_path / "m.model")
+    # the argv of evcouplings/couplings/tools.py:202-262
+    cmd = [sys.executable, os.path.join(root, "bin", "plmc_hip"), "-c", ec, "-o", model, "-f", "SYN", "-m", "15",
+           "-t", str(1.0 - 0.8), "-s", "1.0", "-lh", "0.01", "-le", "3.8", "-lg", "0.0", "-n", "2", ali]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    err = p.stderr
+    assert re.search(r"Found focus (.+) as sequence (\d+)", err).groups() == ("SYN", "1")
+    assert re.search(r"(\d+) valid sequences out of (\d+)", err).groups() == ("300", "300")
+    assert re.search(r"(\d+) sites out of (\d+)", err).groups() == ("20", "20")
+    assert re.search(r"Region starts at (\d+)", err).group(1) == "1"
+    assert float(re.search(r"Effective number of samples: (\d+\.\d+)", err).group(1)) > 1
+    assert re.search(r"Gradient optimization: (.+)", err)
+    rows = re.findall(r"^(\d+)" + r"\s+(\d+\.\d+)" * 6 + r"$", err, flags=re.M)
+    assert len(rows) == 15 and os.path.getsize(ec) > 0 and os.path.getsize(model) > 0

@@ -1,0 +1,160 @@
+"""
+CPU tests of the host layer around the C ABI: alignment reader (focus-mode rules), the two
+output formats, the plmc stderr grammar and the plmc-argv shim.  Golden files come from the
+reference's own readers/parsers (tests/golden/make_golden.py).
+"""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from evcouplings_amd import alignment_io, cli, model_io, tools
+from evcouplings_amd.synthetic import ALPHABET_PROTEIN, msa_to_a2m, synthetic_msa
+
+
+def _write(tmp_path, text, name="a.a2m"):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+# ------------------------------------------------------------------ alignment reader
+def test_focus_mode_columns_numbering_and_invalid_sequences(tmp_path):
+    # focus row: uppercase = model column, lowercase/'.'/'-' = dropped; numbering counts every residue
+    path = _write(tmp_path, "\n".join([
+        ">FOC/11-20 extra words",
+        "ACd.E-FGhiKL",          # residues: A C d E F G h i K L -> 10 residues, region 11-20
+        ">s2/1-9",
+        "AC-.EWFG--KL",
+        ">s3/5-9",
+        "XCa.E-FGhiKL",          # X in kept column 0 -> invalid
+        ">s4",
+        "-Cd.EAFG..K.",          # '.' in kept columns -> gap
+    ]) + "\n")
+    enc = alignment_io.encode_alignment(path, focus_seq="FOC/11-20")
+    assert enc.focus_index == 1 and enc.region_start == 11
+    assert enc.target_seq == "ACEFGKL"
+    assert enc.columns.tolist() == [0, 1, 4, 6, 7, 10, 11]
+    assert enc.index_list.tolist() == [11, 12, 14, 15, 16, 19, 20]   # d, h, i skipped in numbering
+    assert enc.n_total_sites == 10 and enc.n_total_seqs == 4 and enc.n_valid_seqs == 3
+    assert enc.valid.tolist() == [True, True, False, True]
+    A = ALPHABET_PROTEIN
+    assert enc.msa.dtype == np.int8 and enc.msa.shape == (3, 7)
+    assert enc.msa[0].tolist() == [A.index(c) for c in "ACEFGKL"]
+    assert enc.msa[1].tolist() == [A.index(c) for c in "ACEFGKL"]
+    assert enc.msa[2].tolist() == [0, A.index("C"), A.index("E"), A.index("F"), A.index("G"), A.index("K"), 0]
+    # the name without the /range also selects the focus (tools.py:219)
+    assert alignment_io.encode_alignment(path, focus_seq="FOC").focus_index == 1
+
+
+def test_non_focus_mode_and_errors(tmp_path):
+    path = _write(tmp_path, ">a\nACDE\n>b\nAC-E\n>c\nACBE\n")
+    enc = alignment_io.encode_alignment(path)
+    assert enc.focus_index is None and enc.index_list.tolist() == [1, 2, 3, 4]
+    assert enc.n_valid_seqs == 2 and enc.valid.tolist() == [True, True, False]   # 'B' is not in the alphabet
+    with pytest.raises(alignment_io.AlignmentFormatError):
+        alignment_io.encode_alignment(path, focus_seq="nope")
+    ragged = _write(tmp_path, ">a\nACDE\n>b\nACD\n", "r.a2m")
+    with pytest.raises(alignment_io.AlignmentFormatError):
+        alignment_io.encode_alignment(ragged)
+    empty = _write(tmp_path, "", "e.a2m")
+    with pytest.raises(alignment_io.AlignmentFormatError):
+        alignment_io.encode_alignment(empty)
+    dna = _write(tmp_path, ">a\nACGT-\n>b\nAC-TT\n", "d.fa")
+    enc = alignment_io.encode_alignment(dna, alphabet="-ACGT")
+    assert enc.msa.tolist() == [[1, 2, 3, 4, 0], [1, 2, 0, 4, 4]]
+
+
+def test_synthetic_a2m_round_trip(tmp_path):
+    msa, _ = synthetic_msa(50, 30, seed=3)
+    path = msa_to_a2m(msa, str(tmp_path / "syn.a2m"), region_start=7)
+    enc = alignment_io.encode_alignment(path, focus_seq="SYN/7-36")
+    np.testing.assert_array_equal(enc.msa, msa)
+    assert enc.index_list.tolist() == list(range(7, 37)) and enc.region_start == 7
+
+
+# ------------------------------------------------------------------ output formats
+def test_model_writer_matches_file_validated_by_reference_reader(tmp_path, golden_dir):
+    z = np.load(os.path.join(golden_dir, "scores_L12.npz"))
+    L, q, N = 12, 21, 30
+    out = str(tmp_path / "m.model")
+    model_io.write_model_file(
+        out, L=L, q=q, n_valid=N, n_invalid=2, num_iter=100, theta=0.2, lambda_h=0.01, lambda_j=2.2,
+        lambda_group=0.0, n_eff=17.25, alphabet=ALPHABET_PROTEIN,
+        weights=np.concatenate([z["weights"], np.zeros(2, np.float32)]), target_seq=str(z["target"]),
+        index_list=z["index_list"], fi=z["fi"], hi=z["hi"], fij=z["fij"], jij=z["jij"])
+    golden = os.path.join(golden_dir, "tiny_L12.model")   # CouplingsModel read this one back exactly
+    assert open(out, "rb").read() == open(golden, "rb").read()
+    assert os.path.getsize(out) == model_io.model_file_size(L, q, N + 2)
+    back = model_io.read_model_file(out)
+    np.testing.assert_array_equal(back["jij"], z["jij"])
+    np.testing.assert_array_equal(back["index_list"], z["index_list"])
+    assert back["alphabet"] == ALPHABET_PROTEIN and back["n_invalid"] == 2
+    with pytest.raises(ValueError):
+        model_io.write_model_file(out, L=L, q=q, n_valid=N, n_invalid=2, num_iter=1, theta=0.2, lambda_h=-1.0,
+                                  lambda_j=1, lambda_group=0, n_eff=1, alphabet=ALPHABET_PROTEIN,
+                                  weights=np.zeros(N + 2), target_seq=str(z["target"]), index_list=z["index_list"],
+                                  fi=z["fi"], hi=z["hi"], fij=z["fij"], jij=z["jij"])
+
+
+def test_raw_ec_file_format(tmp_path, golden_dir):
+    z = np.load(os.path.join(golden_dir, "scores_L12.npz"))
+    out = str(tmp_path / "ecs.txt")
+    model_io.write_raw_ec_file(out, z["index_list"], str(z["target"]), z["cn"])
+    assert open(out).read() == open(os.path.join(golden_dir, "tiny_L12_ECs.txt")).read()
+    first = open(out).readline().split(" ")
+    assert len(first) == 6 and first[4] == "0" and len(first[5].strip().split(".")[1]) == 6
+    tab = pd.read_csv(out, sep=" ", names=["i", "A_i", "j", "A_j", "fn", "cn"])   # pairs.py:55-58
+    assert len(tab) == 66 and (np.diff(tab["i"].values) >= 0).all()
+    np.testing.assert_allclose(tab["cn"].values, z["ecs_cn"], atol=5.1e-7)
+
+
+# ------------------------------------------------------------------ stderr grammar
+def test_log_text_is_what_the_reference_parser_accepted(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "plmc_log.json")))
+    for name, c in cases.items():
+        kw = dict(c["inputs"])
+        kw["table"] = [tuple(r) for r in kw["table"]]
+        assert tools.format_plmc_log(**kw) == c["log"], name
+        df = tools.iteration_dataframe(kw["table"])
+        assert list(df.columns) == c["iter_columns"]
+        assert df.values.tolist() == c["iter_rows"]      # same string cells parse_plmc_log produced
+        import re
+        for row in df.values.tolist():
+            assert all(re.fullmatch(r"\d+\.\d+", cell) for cell in row[1:]) and re.fullmatch(r"\d+", row[0])
+
+
+# ------------------------------------------------------------------ plmc argv shim
+def test_cli_parses_the_argv_run_plmc_builds():
+    # evcouplings/couplings/tools.py:202-262 for a typical monomer job
+    argv = ["-c", "out/x_ECs.txt", "-o", "out/x.model", "-f", "RASH_HUMAN", "-m", "100", "-t",
+            str(1.0 - 0.8), "-s", "1.0", "-lh", "0.01", "-le", "59.8", "-lg", "0.0", "-n", "2", "ali.a2m"]
+    o = cli.parse_argv(argv)
+    assert o["couplings_file"] == "out/x_ECs.txt" and o["param_file"] == "out/x.model"
+    assert o["focus_seq"] == "RASH_HUMAN" and o["iterations"] == 100 and o["alignment"] == "ali.a2m"
+    assert round(1.0 - o["theta_div"], 12) == 0.8 and o["lambda_J"] == 59.8 and not o["ignore_gaps"]
+    assert cli.parse_argv(["-c", "e", "-g", "-m", "max", "-n", "max", "a"])["iterations"] == "max"
+    for bad in (["-c", "e"], ["a"], ["-c", "e", "-zz", "a"], ["-c", "e", "a", "b"], ["-c"]):
+        with pytest.raises(ValueError):
+            cli.parse_argv(bad)
+    assert cli.main(["-c"]) == 1
+
+
+def test_run_plmc_hip_error_conventions(tmp_path):
+    with pytest.raises(tools.ResourceError):
+        tools.run_plmc_hip(str(tmp_path / "missing.a2m"), str(tmp_path / "e.txt"))
+    msa, _ = synthetic_msa(20, 12, seed=1)
+    ali = msa_to_a2m(msa, str(tmp_path / "s.a2m"))
+    with pytest.raises(tools.ExternalToolError):
+        tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), ignore_gaps=True)
+    with pytest.raises(tools.ExternalToolError):
+        tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), lambda_g=0.5)
+    with pytest.raises(tools.ExternalToolError):
+        tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), iterations="lots")
+    from evcouplings_amd import _lib
+    if _lib.load().plm_device_count() <= 0:
+        # no GPU here: the solver must fail loudly (as ExternalToolError), never fall back to a CPU path
+        with pytest.raises(tools.ExternalToolError):
+            tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), str(tmp_path / "m.model"), focus_seq="SYN/1-12")
