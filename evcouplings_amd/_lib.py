@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplm_hip.so")
+# PLM_HIP_LIB selects another build of the same library (kernel A/B experiments only)
+LIB_PATH = os.environ.get("PLM_HIP_LIB") or os.path.join(_HERE, "libplm_hip.so")
 
 PLM_OK = 0
 STATUS_CONVERGED, STATUS_MAXITER, STATUS_LINESEARCH = 0, 1, 2

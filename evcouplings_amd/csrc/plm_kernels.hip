@@ -21,6 +21,9 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
+#ifndef PLM_STAGE_GLDS
+#define PLM_STAGE_GLDS 1   // 1: global_load_lds (LDS-DMA) staging; 0: register staging (debug A/B)
+#endif
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
@@ -278,8 +281,13 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     auto stage = [&](int ks, int buf) {
         const char *src = bt + (size_t)ks * TILE + lane * 16;
         char *dst = smem + buf * TILE;
-        for (int p = wave; p < 2 * Q; p += 8)
+        for (int p = wave; p < 2 * Q; p += 8) {
+#if PLM_STAGE_GLDS
             __builtin_amdgcn_global_load_lds(GLB_PTR(src + p * 1024), LDS_PTR(dst + p * 1024), 16, 0, 0);
+#else
+            *(float4 *)(dst + p * 1024 + lane * 16) = *(const float4 *)(src + p * 1024);
+#endif
+        }
     };
     stage(0, 0);
     uint2 xa0 = *(const uint2 *)arow0, xa1 = *(const uint2 *)arow1;
@@ -291,6 +299,10 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             na1 = *(const uint2 *)(arow1 + 32 * (u + 1));
         }
         for (int b = 0; b < Q; ++b, ++ks) {
+            // hipcc does NOT drain the LDS-DMA queue at this barrier (only lgkmcnt): without the
+            // explicit wait a late global_load_lds piece is read before it lands (seen as
+            // run-to-run noise at N=50k); every wave drains its own pieces, then the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (ks + 1 < d.nksteps) stage(ks + 1, (ks + 1) & 1);
             const char *lb = smem + (ks & 1) * TILE + lane * 16;
@@ -444,13 +456,18 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
             const int c = p >> 1;   // col fragment within tile, plane = p & 1 (contiguous in Rt)
             if (nfl0 + c < d.nnfl) {
                 const char *src = Rt + ((size_t)ss * d.nnfl + nfl0) * 2048 + (size_t)p * 1024 + lane * 16;
+#if PLM_STAGE_GLDS
                 __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + p * 1024), 16, 0, 0);
+#else
+                *(float4 *)(dst + p * 1024 + lane * 16) = *(const float4 *)src;
+#endif
             }
         }
     };
     if (k0 < k1) stage(k0, 0);
     uint2 xa = (k0 < k1) ? *(const uint2 *)(acol + (size_t)32 * k0) : make_uint2(0, 0);
     for (int ss = k0; ss < k1; ++ss) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed (see k_fwd)
         __syncthreads();
         uint2 nx = xa;
         if (ss + 1 < k1) {

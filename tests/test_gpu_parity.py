@@ -245,3 +245,26 @@ def test_cli_shim_log_is_parseable(plm, tmp_path):
     assert re.search(r"Gradient optimization: (.+)", err)
     rows = re.findall(r"^(\d+)" + r"\s+(\d+\.\d+)" * 6 + r"$", err, flags=re.M)
     assert len(rows) == 15 and os.path.getsize(ec) > 0 and os.path.getsize(model) > 0
+
+
+def test_evaluation_is_bit_reproducible_at_scale(plm):
+    """config-2 size (L=200, N=20k): repeated evaluations must agree bit for bit -- the pipeline has
+    no float atomics, so any difference is a race (one was found this way: a missing vmcnt(0)
+    drain before the barrier that publishes global_load_lds tiles)."""
+    msa, _ = synthetic_msa(20000, 200, seed=9)
+    with plm.PlmContext(msa, q=Q, max_iter=8, epsilon=1e-12) as ctx:
+        ctx.reweight()
+        ctx.marginals(pairs=False)
+        ctx.set_x(None)
+        ctx.optimize()
+        x = ctx.get_x()
+        ref = None
+        for _ in range(3):
+            ctx.set_x(x)
+            fx, nll = ctx.eval()
+            g = ctx.get_g()
+            if ref is None:
+                ref = (fx, nll, g)
+            else:
+                assert fx == ref[0] and nll == ref[1]
+                assert np.array_equal(g, ref[2])

@@ -1,0 +1,120 @@
+"""
+Config-1 "plumbing" row: the REFERENCE's own couplings protocol (evcouplings/couplings/
+protocol.py:363 `standard`) driven end to end on top of our backend, using the reference's
+unmodified readers (pairs.read_raw_ec_file, CouplingsModel), segment mapping, rescoring and
+post-processing.
+
+The build container has the reference but no GPU; the GPU box has a GPU but no reference.  So
+the solver output used here is a fixture produced ON an MI355X by scripts/make_gpu_fixture.py
+(tests/golden/hip_fit_L24.*: alignment, raw fit arrays, and the two files the HIP path wrote),
+and `plm.fit` is replaced by a function that returns those arrays -- everything else is the
+real host code and the real reference code.  Skipped where /root/reference is absent.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import refstubs  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not refstubs.reference_available(), reason="reference tree not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    refstubs.install()
+    import evcouplings.couplings.protocol as cp
+    import evcouplings.couplings.tools as ct
+    from evcouplings.couplings.model import CouplingsModel
+    return dict(cp=cp, ct=ct, CouplingsModel=CouplingsModel)
+
+
+@pytest.fixture()
+def gpu_fit(golden_dir, monkeypatch):
+    z = np.load(os.path.join(golden_dir, "hip_fit_L24.npz"))
+    fit = {k: z[k] for k in ("weights", "fi", "fij", "hi", "jij", "fn", "cn")}
+    fit.update(n_eff=float(z["n_eff"]), iters=int(z["iters"]), n_evals=int(z["n_evals"]), status=int(z["status"]),
+               status_msg=str(z["status_msg"]), fx=float(z["fx"]), lambda_j=float(z["lambda_j"]),
+               table=[tuple(r) for r in z["table"]], seconds={})
+    from evcouplings_amd import plm
+    calls = []
+
+    def fake_fit(msa, **kw):
+        calls.append((msa.shape, kw))
+        return dict(fit)
+
+    monkeypatch.setattr(plm, "fit", fake_fit)
+    return fit, calls, z
+
+
+def test_files_written_on_the_gpu_load_in_the_reference(ref, golden_dir):
+    """the .model and EC file the HIP path wrote on the MI355X, read by the reference's readers"""
+    m = ref["CouplingsModel"](os.path.join(golden_dir, "hip_fit_L24.model"))
+    z = np.load(os.path.join(golden_dir, "hip_fit_L24.npz"))
+    assert (m.L, m.num_symbols, m.N_valid, m.N_invalid) == (24, 21, 500, 0)
+    assert m.index_list.tolist() == list(range(10, 34)) and "".join(m.alphabet) == "-ACDEFGHIKLMNPQRSTVWY"
+    iu = np.triu_indices(24, 1)
+    np.testing.assert_array_equal(m.J_ij[iu].astype(np.float32), z["jij"])
+    np.testing.assert_array_equal(m.h_i.astype(np.float32), z["hi"])
+    assert m.N_eff == pytest.approx(float(z["n_eff"]), rel=1e-6) and m.lambda_h == pytest.approx(0.01)
+    # CouplingsModel re-derives CN in float64 (model.py:777-827); the GPU scored in f32
+    np.testing.assert_allclose(m.cn_scores, z["cn"], atol=5e-6)
+    from evcouplings.couplings.pairs import read_raw_ec_file
+    ecs = read_raw_ec_file(os.path.join(golden_dir, "hip_fit_L24_ECs.txt"))
+    ref_ecs = m.ecs
+    merged = ecs.merge(ref_ecs, on=["i", "j"], suffixes=("", "_ref"))
+    assert len(merged) == 276
+    np.testing.assert_allclose(merged["cn"], merged["cn_ref"], atol=5e-6)
+    assert (merged["A_i"] == merged["A_i_ref"]).all()
+    # the planted pairs top the reference's own ranking of our output
+    planted = {(int(a) + 10, int(b) + 10) for a, b in z["planted"]}
+    # (long-range only: terminal gap runs make sequence neighbours co-vary as well)
+    lr = ecs[(ecs["j"] - ecs["i"]).abs() >= 6]
+    top = set(zip(lr["i"].head(8).tolist(), lr["j"].head(8).tolist()))
+    assert len(top & planted) >= 6, (top, planted)
+    # mutation-effect consumers (mutate stage) work on it
+    assert np.isfinite(m.to_independent_model().h_i).all()
+
+
+def test_reference_standard_protocol_runs_on_our_backend(ref, gpu_fit, golden_dir, tmp_path):
+    fit, calls, z = gpu_fit
+    from evcouplings_amd import protocol as hip_protocol
+    from evcouplings_amd import tools as hip_tools
+    cp = ref["cp"]
+    prefix = str(tmp_path / "couplings" / "job")
+    kwargs = dict(
+        prefix=prefix, alignment_file=os.path.join(golden_dir, "hip_fit_L24.a2m"), focus_mode=True,
+        focus_sequence="SYN/10-33", segments=[["aa", "A_1", 10, 33, list(range(10, 34))]] if False else None,
+        theta=0.8, alphabet=None, ignore_gaps=False, iterations=100, lambda_h=0.01, lambda_J=0.01,
+        lambda_J_times_Lq=True, lambda_group=None, scale_clusters=None, cpu=2, plmc="plmc", reuse_ecs=False,
+        min_sequence_distance=6, frequencies_file=None, scoring_model="skewnormal", save_model=True)
+    hip_protocol.install()
+    try:
+        assert ref["ct"].run_plmc is hip_tools.run_plmc_hip
+        outcfg = cp.run(protocol="standard", **kwargs)
+    finally:
+        hip_protocol.uninstall()
+    assert ref["ct"].run_plmc is not hip_tools.run_plmc_hip
+    # our backend was called with the lambda_J the reference scaled (protocol.py:159-179)
+    (shape, kw), = calls
+    assert shape == (500, 24) and kw["lambda_j"] == pytest.approx(0.01 * 20 * 23) and kw["max_iter"] == 100
+    assert kw["theta_id"] == 0.8 and kw["q"] == 21
+    assert outcfg["num_sites"] == 24 and outcfg["num_valid_sequences"] == 500 and outcfg["region_start"] == 10
+    assert outcfg["effective_sequences"] == pytest.approx(float(z["n_eff"]), abs=0.06)
+    for key in ("raw_ec_file", "model_file", "ec_file", "ec_longrange_file"):
+        assert os.path.getsize(outcfg[key]) > 0, key
+    import pandas as pd
+    table = pd.read_csv(outcfg["ec_file"])
+    assert {"i", "j", "cn", "probability"} <= set(table.columns) and len(table) == 276
+    it = pd.read_csv(prefix + "_iteration_table.csv")
+    assert len(it) == 100 and list(it.columns)[1:] == hip_tools.ITER_COLUMNS
+    # restart path: reuse_ecs short-circuits the solver (protocol.py:186-199) and still works
+    calls.clear()
+    hip_protocol.install()
+    try:
+        out2 = cp.run(protocol="standard", **{**kwargs, "reuse_ecs": True})
+    finally:
+        hip_protocol.uninstall()
+    assert calls == [] and out2["num_sites"] == 24
