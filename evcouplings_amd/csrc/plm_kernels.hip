@@ -15,12 +15,18 @@
 // accumulated in f32 by v_mfma_f32_16x16x32_f16.  Written for wave64 / gfx950 only.
 #include "plm_internal.h"
 #include <math.h>
+#include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
+// PLM_ABLATE bit mask for timing experiments (results invalid): 1 no barrier/vmcnt in k_fwd,
+// 2 no LDS-DMA in k_fwd, 4 no LDS reads in k_fwd (reuse the first fragments), 8 no one-hot expansion
+#ifndef PLM_ABLATE
+#define PLM_ABLATE 0
+#endif
 #ifndef PLM_STAGE_GLDS
 #define PLM_STAGE_GLDS 1   // 1: global_load_lds (LDS-DMA) staging; 0: register staging (debug A/B)
 #endif
@@ -45,6 +51,56 @@ __device__ __forceinline__ half8 onehot8(u32 lo, u32 hi, u32 bb) {
     r.w[2] = 0x3C003C00u - ((y1 >> 7) & 0x00010001u) * 0x3C00u;   // bytes 4,6
     r.w[3] = 0x3C003C00u - ((y1 >> 15) & 0x00010001u) * 0x3C00u;  // bytes 5,7
     return r.h;
+}
+
+// ---- hand-scheduled LDS reads ---------------------------------------------------------------
+// hipcc sinks every ds_read next to its first use and waits lgkmcnt(0) there (LDS latency exposed
+// once per fragment).  These helpers issue the read early as inline asm and tie the counted wait
+// to the destination registers by data dependence, so nothing that uses them can be hoisted
+// above the wait (cdna_hip_programming.md section 5.4 rule 18).  LDS returns in order, so
+// "N newer reads may still be in flight" is s_waitcnt lgkmcnt(N).
+__device__ __forceinline__ u32 lds_addr(const void *p) {
+    return (u32)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+template <int OFF> __device__ __forceinline__ half8 lds_read_b128(u32 addr) {
+    half8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N> __device__ __forceinline__ void lds_wait(half8 &a, half8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+// ---- LDS-DMA pieces spread over a K step ------------------------------------------------------
+// A tile is copied global -> LDS in 1 KB pieces (one global_load_lds per wave-instruction).  Issuing
+// a wave's 4-6 pieces back to back right after the barrier keeps every wave of the workgroup out
+// of the MFMA pipe at the same time; instead piece PI is issued between the MFMA groups of an
+// early fragment of the step (first ~60 % so it has landed before the next barrier).
+struct DmaPlan {
+    const char *src;   // global address of this lane's 16 B of piece 0
+    char *dst;         // LDS base of the target buffer (wave-uniform)
+    int first;         // this wave's first piece (= wave id); pieces first + 8*PI
+    int limit;         // number of pieces to copy (0 = nothing to stage)
+};
+template <int PI> __device__ __forceinline__ void dma_issue(const DmaPlan &P) {
+    const int p = P.first + 8 * PI;
+    if (p < P.limit) {
+#if PLM_STAGE_GLDS
+        __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
+#else
+        *(float4 *)(P.dst + p * 1024 + (threadIdx.x & 63) * 16) = *(const float4 *)(P.src + p * 1024);
+#endif
+    }
+}
+// issue every piece whose slot is fragment index A; NP pieces per wave, NF fragments per step
+template <int NP, int NF, int A, int PI = 0> __device__ __forceinline__ void dma_slot(const DmaPlan &P) {
+    if constexpr (PI < NP) {
+        // measured on MI355X: spreading the pieces over the step (slot = PI * 0.6 NF / NP) made k_bwd
+        // 35 % slower -- late pieces stall the vmcnt(0) before the next barrier -- so all pieces
+        // go out with the first fragment of the step
+        if constexpr (A == 0) dma_issue<PI>(P);
+        dma_slot<NP, NF, A, PI + 1>(P);
+    }
 }
 
 __device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
@@ -259,6 +315,42 @@ struct FwdArgs {
     float rscale;
 };
 
+// one K step of the forward GEMM for one wave: Q states x (hi, lo) planes x 2 row fragments.
+// The B fragments of state A+2 are issued before state A computes (6 reads in flight at most).
+template <int Q, int A>
+__device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb,
+                                          half8 (&bh)[3], half8 (&bl)[3], const DmaPlan &dma) {
+#if !(PLM_ABLATE & 4)
+    if constexpr (A + 2 < Q) {
+        bh[(A + 2) % 3] = lds_read_b128<(A + 2) * 1024>(lb);
+        bl[(A + 2) % 3] = lds_read_b128<(Q + A + 2) * 1024>(lb);
+    }
+    constexpr int newer = (A + 2 < Q) ? 4 : (A + 1 < Q) ? 2 : 0;
+    lds_wait<newer>(bh[A % 3], bl[A % 3]);
+#else
+    if constexpr (A == 0) lds_wait<0>(bh[0], bl[0]);
+    if constexpr (A == 0) lds_wait<0>(bh[1], bl[1]);
+    if constexpr (A == 0) { bh[2] = bh[0]; bl[2] = bl[1]; }
+#endif
+    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh[A % 3], acc[0][A], 0, 0, 0);
+    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[A % 3], acc[1][A], 0, 0, 0);
+    dma_slot<(2 * Q + 7) / 8, Q, A>(dma);
+    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[A % 3], acc[0][A], 0, 0, 0);
+    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[A % 3], acc[1][A], 0, 0, 0);
+}
+template <int Q, int... A>
+__device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb,
+                                          const DmaPlan &dma, std::integer_sequence<int, A...>) {
+    half8 bh[3], bl[3];
+    bh[0] = lds_read_b128<0>(lb);
+    bl[0] = lds_read_b128<Q * 1024>(lb);
+    if constexpr (Q > 1) {
+        bh[1] = lds_read_b128<1024>(lb);
+        bl[1] = lds_read_b128<(Q + 1) * 1024>(lb);
+    }
+    (fwd_state<Q, A>(acc, a0, a1, lb, bh, bl, dma), ...);
+}
+
 template <int Q>
 __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (guide 5/4a)
@@ -302,22 +394,25 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             // hipcc does NOT drain the LDS-DMA queue at this barrier (only lgkmcnt): without the
             // explicit wait a late global_load_lds piece is read before it lands (seen as
             // run-to-run noise at N=50k); every wave drains its own pieces, then the barrier
+#if !(PLM_ABLATE & 1)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (ks + 1 < d.nksteps) stage(ks + 1, (ks + 1) & 1);
+#endif
+            const DmaPlan dma{bt + (size_t)(ks + 1) * TILE + lane * 16, smem + ((ks + 1) & 1) * TILE, wave,
+                              ((PLM_ABLATE & 2) == 0 && ks + 1 < d.nksteps) ? 2 * Q : 0};
             const char *lb = smem + (ks & 1) * TILE + lane * 16;
             const u32 bb = (u32)b * 0x01010101u;
+#if !(PLM_ABLATE & 8)
             const half8 a0 = onehot8(xa0.x, xa0.y, bb);
             const half8 a1 = onehot8(xa1.x, xa1.y, bb);
-#pragma unroll
-            for (int a = 0; a < Q; a++) {
-                const half8 bh = *(const half8 *)(lb + a * 1024);
-                const half8 bl = *(const half8 *)(lb + (Q + a) * 1024);
-                acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc[0][a], 0, 0, 0);
-                acc[1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc[1][a], 0, 0, 0);
-                acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, acc[0][a], 0, 0, 0);
-                acc[1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc[1][a], 0, 0, 0);
-            }
+#else
+            half8 a0, a1;
+            ((u32 *)&a0)[0] = xa0.x; ((u32 *)&a0)[1] = xa0.y; ((u32 *)&a0)[2] = bb; ((u32 *)&a0)[3] = xa1.x;
+            ((u32 *)&a1)[0] = xa1.x; ((u32 *)&a1)[1] = xa1.y; ((u32 *)&a1)[2] = bb; ((u32 *)&a1)[3] = xa0.y;
+#endif
+            // software pipeline: the B fragments of state a+PF are in flight while state a computes
+            // (without it hipcc waits lgkmcnt(0) before every group of 4 MFMAs: LDS latency x21)
+            fwd_kstep<Q>(acc, a0, a1, lds_addr(lb), dma, std::make_integer_sequence<int, Q>{});
         }
         xa0 = na0;
         xa1 = na1;
@@ -421,6 +516,31 @@ hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const floa
 //   Split-K over sequence ranges; XCD-aware block order keeps the row tiles that share a
 //   residual panel on one XCD (block b runs on XCD b % 8).
 // =========================================================================================
+// one K step (32 sequences) of the backward GEMM for one wave: the B fragments of column C+1 are
+// in flight while the 2*FM MFMAs of column C run
+template <int FM, int FN, int C>
+__device__ __forceinline__ void bwd_col(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb, half8 (&bh)[2],
+                                        half8 (&bl)[2], const DmaPlan &dma) {
+    if constexpr (C + 1 < FN) {
+        bh[(C + 1) & 1] = lds_read_b128<(C + 1) * 2048>(lb);
+        bl[(C + 1) & 1] = lds_read_b128<(C + 1) * 2048 + 1024>(lb);
+    }
+    lds_wait<(C + 1 < FN) ? 2 : 0>(bh[C & 1], bl[C & 1]);
+#pragma unroll
+    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh[C & 1], acc[f][C], 0, 0, 0);
+    dma_slot<(4 * FN + 7) / 8, FN, C>(dma);
+#pragma unroll
+    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl[C & 1], acc[f][C], 0, 0, 0);
+}
+template <int FM, int FN, int... C>
+__device__ __forceinline__ void bwd_kstep(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb,
+                                          const DmaPlan &dma, std::integer_sequence<int, C...>) {
+    half8 bh[2], bl[2];
+    bh[0] = lds_read_b128<0>(lb);
+    bl[0] = lds_read_b128<1024>(lb);
+    (bwd_col<FM, FN, C>(acc, af, lb, bh, bl, dma), ...);
+}
+
 template <int Q, int FM, int FN>
 __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict__ msa_cm,
                                             const char *__restrict__ Rt, float *__restrict__ G) {
@@ -470,25 +590,18 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed (see k_fwd)
         __syncthreads();
         uint2 nx = xa;
-        if (ss + 1 < k1) {
-            stage(ss + 1, (ss + 1 - k0) & 1);
-            nx = *(const uint2 *)(acol + (size_t)32 * (ss + 1));
-        }
+        if (ss + 1 < k1) nx = *(const uint2 *)(acol + (size_t)32 * (ss + 1));
+        const int np_valid = min(4 * FN, 2 * (d.nnfl - nfl0));
+        const DmaPlan dma{Rt + ((size_t)(ss + 1) * d.nnfl + nfl0) * 2048 + lane * 16,
+                          smem + ((ss + 1 - k0) & 1) * TILE, wave, (ss + 1 < k1) ? np_valid : 0};
         if (row_ok) {
             const char *lb = smem + ((ss - k0) & 1) * TILE + (wn * FN) * 2048 + lane * 16;
             half8 af[FM];
 #pragma unroll
             for (int f = 0; f < FM; f++) af[f] = onehot8(xa.x, xa.y, (u32)(b0 + f) * 0x01010101u);
-#pragma unroll
-            for (int c = 0; c < FN; c++) {
-                const half8 bh = *(const half8 *)(lb + c * 2048);
-                const half8 bl = *(const half8 *)(lb + c * 2048 + 1024);
-#pragma unroll
-                for (int f = 0; f < FM; f++) {
-                    acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh, acc[f][c], 0, 0, 0);
-                    acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl, acc[f][c], 0, 0, 0);
-                }
-            }
+            bwd_kstep<FM, FN>(acc, af, lds_addr(lb), dma, std::make_integer_sequence<int, FN>{});
+        } else {
+            dma_slot<(4 * FN + 7) / 8, 1, 0>(dma);   // idle row waves still copy their share of the tile
         }
         xa = nx;
     }
