@@ -384,14 +384,15 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
         (rc = dalloc((char **)&c->Bt, plm_bt_bytes(d))) || (rc = dalloc((char **)&c->Rt, plm_rt_bytes(d))) ||
         (rc = dalloc((char **)&c->G, plm_g_bytes(d))) || (rc = dalloc(&c->fx_part, (size_t)c->n_fx_part())) ||
         (rc = dalloc(&c->reg_part, (size_t)plm_reg_parts(d))) ||
-        (rc = dalloc(&c->dot_scratch, (size_t)4 * PLM_DOT_BLOCKS)) || (rc = dalloc(&c->scal, (size_t)64)) ||
+        (rc = dalloc(&c->dot_scratch, (size_t)4 * PLM_MAX_BASIS * PLM_DOT_BLOCKS)) ||
+        (rc = dalloc(&c->scal, (size_t)256)) ||
         (rc = dalloc(&c->maxbits, (size_t)1)) || (rc = dalloc(&c->jexp, (size_t)1)) ||
         (rc = dalloc(&c->x, (size_t)d.n_native)) || (rc = dalloc(&c->g, (size_t)d.n_native)) ||
         (rc = dalloc(&c->canon, (size_t)d.n_canon + (size_t)d.L * d.L)))
         return bail(rc);
     if (d.nshards > 1 && (rc = dalloc((char **)&c->gather, plm_slab_bytes(d) * d.nshards))) return bail(rc);
     hipError_t e;
-    if ((e = hipHostMalloc((void **)&c->h_scal, sizeof(double) * 64)) != hipSuccess)
+    if ((e = hipHostMalloc((void **)&c->h_scal, sizeof(double) * 256)) != hipSuccess)
         return bail(fail(PLM_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e)));
 #define CT(expr)                                                                                  \
     if ((e = (expr)) != hipSuccess)                                                               \
@@ -537,16 +538,20 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
     return PLM_OK;
 }
 
-// L-BFGS (two-loop recursion, Nocedal 1980) with a More'-Thuente line search; vectors stay in
-// HBM, only scalars cross PCIe.  Defaults follow libLBFGS (m = 6, ftol 1e-4, gtol 0.9,
-// <= 20 trial steps), which plmc bundles [recollection, SURVEY.md App. C.4].
+// L-BFGS with a More'-Thuente line search; vectors stay in HBM, only scalars cross PCIe.
+// Defaults follow libLBFGS (m = 6, ftol 1e-4, gtol 0.9, <= 20 trial steps), which plmc bundles
+// [recollection, SURVEY.md App. C.4].  The two-loop recursion (Nocedal 1980) is evaluated in
+// coefficient space ("vector-free" L-BFGS, Chen et al. 2014): every inner product it needs is an
+// entry of the Gram matrix of {s_j, y_j, g}, refreshed by ONE pass over the history per
+// iteration (k_multidot), and the direction is ONE fused linear combination (k_multiaxpy).
+// Two host synchronisations per iteration: after the line-search evaluation and after the pass.
 int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
     HIP_TRY(hipSetDevice(c->device));
     const PlmDims &d = c->d;
     const int64_t n = d.n_native;
-    const int m = c->prob.lbfgs_m > 0 ? c->prob.lbfgs_m : 6;
+    const int m = std::min(20, c->prob.lbfgs_m > 0 ? c->prob.lbfgs_m : 6);
     const int max_iter = c->prob.max_iter;
     const double eps = c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3;
     const int max_ls = 20;
@@ -557,45 +562,88 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     const double epsf = 1e-6;
     PLM_TRY(ctx_alloc_lbfgs(c, m));
     float *S = c->hist, *Y = c->hist + (size_t)m * n;
-    std::vector<double> alpha(m), ys(m);
+    // Gram matrix pieces, indexed by history slot
+    std::vector<double> SS(m * m, 0.0), SY(m * m, 0.0), YY(m * m, 0.0), Sg(m, 0.0), Yg(m, 0.0);
+    double gg = 0, xx = 0, hh = 0;
+    std::vector<double> alpha(m), cs(m), cy(m);
     const double t0 = now_s();
     c->n_evals = 0;
+    enum { SL_FX = 0, SL_NLL = 1, SL_XX = 2, SL_HH = 3, SL_DG = 4, SL_MD = 8 };
 
-    auto norms = [&](double *xnorm, double *gnorm, double *hn, double *en) -> int {
-        const float *a[3] = {c->x, c->g, c->x}, *b[3] = {c->x, c->g, c->x};
-        PLM_TRY(dots(c, 2, a, b, n, 2));
-        const float *ah[1] = {c->x};
-        PLM_TRY(dots(c, 1, ah, ah, d.nh_pad, 4));
-        PLM_TRY(fetch_scalars(c, 0, 5));
-        *xnorm = std::sqrt(c->h_scal[2]);
-        *gnorm = std::sqrt(c->h_scal[3]);
-        *hn = std::sqrt(c->h_scal[4]);
-        *en = std::sqrt(std::max(0.0, c->h_scal[2] - c->h_scal[4]));
+    auto norm_dots = [&]() -> int {   // x.x (all) and x.x (fields only)
+        const float *a[1] = {c->x};
+        PLM_TRY(dots(c, 1, a, a, n, SL_XX));
+        PLM_TRY(dots(c, 1, a, a, d.nh_pad, SL_HH));
         return PLM_OK;
     };
-    auto dot1 = [&](const float *a, const float *b, double *out) -> int {
-        const float *pa[1] = {a}, *pb[1] = {b};
-        PLM_TRY(dots(c, 1, pa, pb, n, 5));
-        PLM_TRY(fetch_scalars(c, 0, 6));
-        *out = c->h_scal[5];
+    auto direction = [&](int stored, int end, double *dginit) -> int {
+        // coefficients of p = sum cs[j] s_j + sum cy[j] y_j + cg g, two-loop in coefficient space
+        std::fill(cs.begin(), cs.end(), 0.0);
+        std::fill(cy.begin(), cy.end(), 0.0);
+        double cg = -1.0;
+        auto s_dot_p = [&](int i) {
+            double v = cg * Sg[i];
+            for (int j = 0; j < stored; j++) v += cs[j] * SS[i * m + j] + cy[j] * SY[i * m + j];
+            return v;
+        };
+        auto y_dot_p = [&](int i) {
+            double v = cg * Yg[i];
+            for (int j = 0; j < stored; j++) v += cs[j] * SY[j * m + i] + cy[j] * YY[i * m + j];
+            return v;
+        };
+        int j = end;
+        for (int i = 0; i < stored; i++) {
+            j = (j + m - 1) % m;
+            alpha[j] = s_dot_p(j) / SY[j * m + j];
+            cy[j] -= alpha[j];
+        }
+        if (stored > 0) {
+            const int newest = (end + m - 1) % m;
+            const double gamma = SY[newest * m + newest] / YY[newest * m + newest];
+            cg *= gamma;
+            for (int i = 0; i < stored; i++) { cs[i] *= gamma; cy[i] *= gamma; }
+        }
+        for (int i = 0; i < stored; i++) {
+            const double beta = y_dot_p(j) / SY[j * m + j];
+            cs[j] += alpha[j] - beta;
+            j = (j + 1) % m;
+        }
+        PlmVecList B;
+        PlmCoefList C;
+        B.n = 0;
+        for (int i = 0; i < stored; i++) { B.v[B.n] = S + (size_t)i * n; C.c[B.n++] = (float)cs[i]; }
+        for (int i = 0; i < stored; i++) { B.v[B.n] = Y + (size_t)i * n; C.c[B.n++] = (float)cy[i]; }
+        B.v[B.n] = c->g;
+        C.c[B.n++] = (float)cg;
+        HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, c->st));
+        double dg = cg * gg;
+        for (int i = 0; i < stored; i++) dg += cs[i] * Sg[i] + cy[i] * Yg[i];
+        *dginit = dg;
         return PLM_OK;
     };
 
     PLM_TRY(ctx_eval_enqueue(c));
-    double xnorm, gnorm, hn, en;
-    PLM_TRY(norms(&xnorm, &gnorm, &hn, &en));
-    double fx = c->h_scal[0], nll = c->h_scal[1];
+    {
+        const float *a[1] = {c->g};
+        PLM_TRY(dots(c, 1, a, a, n, SL_DG));
+        PLM_TRY(norm_dots());
+        PLM_TRY(fetch_scalars(c, 0, 8));
+        gg = c->h_scal[SL_DG];
+        xx = c->h_scal[SL_XX];
+        hh = c->h_scal[SL_HH];
+    }
+    double fx = c->h_scal[SL_FX], nll = c->h_scal[SL_NLL];
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0;
-    if (gnorm / std::max(1.0, xnorm) > eps) {
-        HIP_TRY(plm_launch_lincomb(c->dir, -1.f, c->g, 0.f, nullptr, n, c->st));
-        double step = 1.0 / gnorm;
+    if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) > eps) {
+        double step = 1.0 / std::sqrt(gg);
         for (k = 1;; k++) {
-            HIP_TRY(hipMemcpyAsync(c->xp, c->x, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
-            HIP_TRY(hipMemcpyAsync(c->gp, c->g, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
             double dginit;
-            PLM_TRY(dot1(c->g, c->dir, &dginit));
+            PLM_TRY(direction(stored, end, &dginit));
             if (!(dginit < 0)) { status = PLM_STATUS_LINESEARCH; ls_reason = 10; k--; break; }
+            // the accepted point moves to (xp, gp); trial points are built in (x, g)
+            std::swap(c->x, c->xp);
+            std::swap(c->g, c->gp);
             const double finit = fx, nllinit = nll, dgtest = ftol * dginit;
             int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
             double width = stpmax - stpmin, prev_width = 2.0 * width;
@@ -610,10 +658,14 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     stp = stx;
                 HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, (float)stp, c->dir, n, c->st));
                 PLM_TRY(ctx_eval_enqueue(c));
-                double dg;
-                PLM_TRY(dot1(c->g, c->dir, &dg));   // also fetches fx, nll
-                fx = c->h_scal[0];
-                nll = c->h_scal[1];
+                {
+                    const float *a[1] = {c->g}, *b[1] = {c->dir};
+                    PLM_TRY(dots(c, 1, a, b, n, SL_DG));
+                    PLM_TRY(fetch_scalars(c, 0, 8));
+                }
+                double dg = c->h_scal[SL_DG];
+                fx = c->h_scal[SL_FX];
+                nll = c->h_scal[SL_NLL];
                 if (!std::isfinite(fx)) { fx = INFINITY; dg = 0; }
                 const double ftest1 = finit + stp * dgtest;
                 if (count < 64) { trace[count][0] = stp; trace[count][1] = fx - finit; trace[count][2] = dg; }
@@ -649,9 +701,9 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     fprintf(stderr, "[plm]   trial %d: stp=%.9e  f-f0=%.6e  dg=%.6e\n", t, trace[t][0], trace[t][1], trace[t][2]);
             }
             if (lsrc < 0) {
-                if (!(fx <= finit)) {  // restore the last accepted point
-                    HIP_TRY(hipMemcpyAsync(c->x, c->xp, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
-                    HIP_TRY(hipMemcpyAsync(c->g, c->gp, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+                if (!(fx <= finit)) {  // the last accepted point is still in (xp, gp): make it current again
+                    std::swap(c->x, c->xp);
+                    std::swap(c->g, c->gp);
                     fx = finit;
                     nll = nllinit;
                 }
@@ -661,40 +713,45 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 break;
             }
             step = stp;
-            PLM_TRY(norms(&xnorm, &gnorm, &hn, &en));
-            if (cb) cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, hn, en, user);
+            // new pair into slot `end`, then ONE pass: rows of the Gram matrix for s, y, g + norms
+            float *s = S + (size_t)end * n, *y = Y + (size_t)end * n;
+            HIP_TRY(plm_launch_sy(s, y, c->x, c->xp, c->g, c->gp, n, c->st));
+            const int nst = std::min(m, stored + 1);
+            PlmVecList Qv, B;
+            Qv.n = 3;
+            Qv.v[0] = s; Qv.v[1] = y; Qv.v[2] = c->g;
+            B.n = 0;
+            for (int i = 0; i < nst; i++) B.v[B.n++] = S + (size_t)i * n;
+            for (int i = 0; i < nst; i++) B.v[B.n++] = Y + (size_t)i * n;
+            B.v[B.n++] = c->g;
+            HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, c->st));
+            PLM_TRY(norm_dots());
+            PLM_TRY(fetch_scalars(c, 0, SL_MD + 3 * B.n));
+            const double *md = c->h_scal + SL_MD;
+            const int nbv = B.n, e = end;
+            for (int j = 0; j < nst; j++) {
+                SS[e * m + j] = SS[j * m + e] = md[0 * nbv + j];
+                SY[e * m + j] = md[0 * nbv + nst + j];            // s_e . y_j
+                SY[j * m + e] = md[1 * nbv + j];                  // s_j . y_e
+                YY[e * m + j] = YY[j * m + e] = md[1 * nbv + nst + j];
+                Sg[j] = md[2 * nbv + j];
+                Yg[j] = md[2 * nbv + nst + j];
+            }
+            gg = md[2 * nbv + 2 * nst];
+            xx = c->h_scal[SL_XX];
+            hh = c->h_scal[SL_HH];
+            const double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg);
+            if (cb)
+                cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
+                   std::sqrt(std::max(0.0, xx - hh)), user);
             if (gnorm / std::max(1.0, xnorm) <= eps) { status = PLM_STATUS_CONVERGED; break; }
             if (max_iter > 0 && k >= max_iter) { status = PLM_STATUS_MAXITER; break; }
-            // history update + two-loop recursion
-            float *s = S + (size_t)end * n, *y = Y + (size_t)end * n;
-            HIP_TRY(plm_launch_lincomb(s, 1.f, c->x, -1.f, c->xp, n, c->st));
-            HIP_TRY(plm_launch_lincomb(y, 1.f, c->g, -1.f, c->gp, n, c->st));
-            {
-                const float *a[2] = {y, y}, *b[2] = {s, y};
-                PLM_TRY(dots(c, 2, a, b, n, 6));
-                PLM_TRY(fetch_scalars(c, 6, 2));
-            }
-            const double ysv = c->h_scal[6], yy = c->h_scal[7];
-            ys[end] = ysv;
-            if (stored < m) stored++;
-            end = (end + 1) % m;
-            HIP_TRY(plm_launch_lincomb(c->dir, -1.f, c->g, 0.f, nullptr, n, c->st));
-            int j = end;
-            for (int i = 0; i < stored; i++) {
-                j = (j + m - 1) % m;
-                double sd;
-                PLM_TRY(dot1(S + (size_t)j * n, c->dir, &sd));
-                alpha[j] = sd / ys[j];
-                HIP_TRY(plm_launch_lincomb(c->dir, 1.f, c->dir, (float)-alpha[j], Y + (size_t)j * n, n, c->st));
-            }
-            HIP_TRY(plm_launch_lincomb(c->dir, (float)(ysv / yy), c->dir, 0.f, nullptr, n, c->st));
-            for (int i = 0; i < stored; i++) {
-                double yd;
-                PLM_TRY(dot1(Y + (size_t)j * n, c->dir, &yd));
-                const double beta = yd / ys[j];
-                HIP_TRY(plm_launch_lincomb(c->dir, 1.f, c->dir, (float)(alpha[j] - beta), S + (size_t)j * n, n,
-                                           c->st));
-                j = (j + 1) % m;
+            if (SY[e * m + e] > 0) {   // curvature pair accepted (always true under the Wolfe conditions)
+                stored = nst;
+                end = (end + 1) % m;
+            } else {                   // slot e now holds a rejected pair: restart the history
+                stored = 0;
+                end = 0;
             }
             step = 1.0;
         }

@@ -96,3 +96,23 @@ size_t plm_slab_bytes(const PlmDims &d);   // [nmf][nnfl][256] floats + 256 B ta
 int plm_reg_parts(const PlmDims &d);       // number of double partials assemble writes
 bool plm_q_supported(int q);
 void plm_pick_tile(int q, int *fm, int *fn);
+
+// ---- vector-free L-BFGS kernels (plm_kernels.hip) ----------------------------------------
+#define PLM_MAX_BASIS 41   // 2*m + 1 with m <= 20
+struct PlmVecList {
+    const float *v[PLM_MAX_BASIS];
+    int n;
+};
+// out[q * basis.n + k] = <queries.v[q], basis.v[k]>  (queries.n <= 4), f64 accumulation;
+// scratch holds queries.n * basis.n * PLM_DOT_BLOCKS doubles
+hipError_t plm_launch_multidot(const PlmVecList &queries, const PlmVecList &basis, int64_t n, double *scratch,
+                               double *out, hipStream_t st);
+// out = sum_k coef[k] * basis.v[k]   (coefficients passed by value, f32)
+struct PlmCoefList {
+    float c[PLM_MAX_BASIS];
+};
+hipError_t plm_launch_multiaxpy(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n,
+                                hipStream_t st);
+// s = x - xp ; y = g - gp in one pass
+hipError_t plm_launch_sy(float *s, float *y, const float *x, const float *xp, const float *g, const float *gp,
+                         int64_t n, hipStream_t st);

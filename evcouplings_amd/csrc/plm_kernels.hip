@@ -967,3 +967,93 @@ hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, hi
     hipLaunchKernelGGL(k_fn, dim3(d.L, d.L), dim3(64), 0, st, d.L, d.Q, jij_canon, fn);
     return hipGetLastError();
 }
+
+// =========================================================================================
+// vector-free L-BFGS (row a7): all dot products the two-loop recursion needs come from one
+// pass over the history (queries x basis), the direction from one fused linear combination
+// =========================================================================================
+#define MD_CHUNK 8
+template <int NQ>
+__global__ __launch_bounds__(256) void k_multidot(PlmVecList Q, PlmVecList B, int64_t n4, double *__restrict__ scratch) {
+    // blockIdx.y selects a chunk of MD_CHUNK basis vectors (keeps the f64 accumulators in registers)
+    __shared__ double red[4];
+    const int nb = B.n, k0 = blockIdx.y * MD_CHUNK;
+    const float4 *bp[MD_CHUNK];
+#pragma unroll
+    for (int k = 0; k < MD_CHUNK; k++) bp[k] = (const float4 *)B.v[min(k0 + k, nb - 1)];
+    double acc[NQ][MD_CHUNK];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int k = 0; k < MD_CHUNK; k++) acc[q][k] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 qv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) qv[q] = ((const float4 *)Q.v[q])[i];
+#pragma unroll
+        for (int k = 0; k < MD_CHUNK; k++) {
+            const float4 b = bp[k][i];
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                acc[q][k] += (double)qv[q].x * b.x + (double)qv[q].y * b.y + (double)qv[q].z * b.z +
+                             (double)qv[q].w * b.w;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int k = 0; k < MD_CHUNK; k++) {
+            const double t = block_reduce_sum(acc[q][k], red);
+            if (threadIdx.x == 0 && k0 + k < nb) scratch[((size_t)q * nb + k0 + k) * PLM_DOT_BLOCKS + blockIdx.x] = t;
+            __syncthreads();
+        }
+}
+hipError_t plm_launch_multidot(const PlmVecList &queries, const PlmVecList &basis, int64_t n, double *scratch,
+                               double *out, hipStream_t st) {
+    if (queries.n < 1 || queries.n > 4 || basis.n < 1 || basis.n > PLM_MAX_BASIS || (n & 3)) return hipErrorInvalidValue;
+    const int64_t n4 = n / 4;
+    switch (queries.n) {
+    case 1: hipLaunchKernelGGL(k_multidot<1>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
+    case 2: hipLaunchKernelGGL(k_multidot<2>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
+    case 3: hipLaunchKernelGGL(k_multidot<3>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
+    default: hipLaunchKernelGGL(k_multidot<4>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
+    }
+    hipLaunchKernelGGL(k_dots_final, dim3(queries.n * basis.n), dim3(256), 0, st, scratch, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_multiaxpy(float4 *__restrict__ out, PlmVecList B, PlmCoefList C, int64_t n4) {
+    const int nb = B.n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < nb; k++) {
+            const float4 b = ((const float4 *)B.v[k])[i];
+            const float c = C.c[k];
+            r.x = fmaf(c, b.x, r.x); r.y = fmaf(c, b.y, r.y); r.z = fmaf(c, b.z, r.z); r.w = fmaf(c, b.w, r.w);
+        }
+        out[i] = r;
+    }
+}
+hipError_t plm_launch_multiaxpy(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n, hipStream_t st) {
+    if (basis.n < 1 || basis.n > PLM_MAX_BASIS || (n & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_multiaxpy, dim3(2048), dim3(256), 0, st, (float4 *)out, basis, coef, n / 4);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_sy(float4 *__restrict__ s, float4 *__restrict__ y, const float4 *__restrict__ x,
+                                           const float4 *__restrict__ xp, const float4 *__restrict__ g,
+                                           const float4 *__restrict__ gp, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = x[i], b = xp[i], c = g[i], e = gp[i];
+        s[i] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+        y[i] = make_float4(c.x - e.x, c.y - e.y, c.z - e.z, c.w - e.w);
+    }
+}
+hipError_t plm_launch_sy(float *s, float *y, const float *x, const float *xp, const float *g, const float *gp,
+                         int64_t n, hipStream_t st) {
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sy, dim3(2048), dim3(256), 0, st, (float4 *)s, (float4 *)y, (const float4 *)x,
+                       (const float4 *)xp, (const float4 *)g, (const float4 *)gp, n / 4);
+    return hipGetLastError();
+}
