@@ -172,6 +172,63 @@ __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32,
     if (s < N && cnt) atomicAdd(&counts[s], cnt);
 }
 
+// Register-resident variant (the one normally used): the lane's whole row (LW dwords) stays in
+// VGPRs, partner rows t stream through the scalar cache one at a time (wave-uniform address ->
+// s_load_dwordx16), 3 VALU per 4 sites: v_xad (xor+add), v_and, v_bcnt (popcount-accumulate).
+// LW is the row length in dwords rounded up to 8; rows longer than 192 dwords (L > 768) fall
+// back to the column-chunked kernel above.
+template <int LW>
+__global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ msa32, int Lw, int N,
+                                                     int thresh_padded, int t_per_block,
+                                                     int32_t *__restrict__ counts) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int tb0 = blockIdx.y * t_per_block;
+    const int tb1 = min(N, tb0 + t_per_block);
+    const u32 *__restrict__ myrow = msa32 + (size_t)s * Lw;
+    u32 mine[LW];
+#pragma unroll
+    for (int k = 0; k < LW; k += 4) {
+        if (k < Lw) {   // Lw is a multiple of 8: whole uint4 loads
+            const uint4 v = *(const uint4 *)(myrow + k);
+            mine[k] = v.x; mine[k + 1] = v.y; mine[k + 2] = v.z; mine[k + 3] = v.w;
+        } else {
+            mine[k] = mine[k + 1] = mine[k + 2] = mine[k + 3] = 0x7e7e7e7eu;   // never matches the partner's pad
+        }
+    }
+    // mismatches are counted (popcount of the per-byte "differs" flags); ident = 4*Lw - mism.
+    // The partner row is consumed in 16-dword chunks (one s_load_dwordx16 each, the next chunk in
+    // flight while this one is compared); words past Lw in the last chunk meet 0x7e in `mine`
+    // and always count as 4 mismatches, which the threshold absorbs.
+    struct Chunk { u32 v[16]; };
+    u32 c7f = 0x7f7f7f7fu;
+    asm volatile("" : "+v"(c7f));   // keep the constant in a VGPR (VOP3 takes one SGPR, no literal)
+    const int nch = (Lw + 15) / 16;
+    const int max_mism = 4 * Lw - thresh_padded + 4 * (16 * nch - Lw);
+    int cnt = 0;
+    for (int t = tb0; t < tb1; ++t) {
+        const Chunk *__restrict__ trow = (const Chunk *)(msa32 + (size_t)t * Lw);
+        int mism = 0;
+        Chunk cur = trow[0];
+#pragma unroll
+        for (int c = 0; c < LW / 16; c++) {
+            if (c < nch) {
+                Chunk nxt = cur;
+                if (c + 1 < nch) nxt = trow[c + 1];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    u32 y;   // (mine ^ partner) + 0x7f7f7f7f in one VALU op: bit 7 of a byte set <=> sites differ
+                    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(y) : "v"(mine[16 * c + k]), "s"(cur.v[k]), "v"(c7f));
+                    mism += __builtin_popcount(y & 0x80808080u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+        }
+        cnt += (mism <= max_mism) ? 1 : 0;
+    }
+    if (s < N && cnt) atomicAdd(&counts[s], cnt);
+}
+
 hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thresh, int32_t *counts,
                                hipStream_t st) {
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * d.Np, st);
@@ -179,6 +236,19 @@ hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thres
     const int Lw = d.Lp32 / 4;
     // padded columns (value 127 in every row) always match: shift the threshold instead
     const int thr = thresh + (d.Lp32 - d.L);
+    if (Lw <= 192) {
+        int tsplit = std::max(1, (4096 + d.nstiles - 1) / d.nstiles);
+        int tper = (d.N + tsplit - 1) / tsplit;
+        tsplit = (d.N + tper - 1) / tper;
+        const dim3 grid(d.nstiles, tsplit), block(256);
+        const u32 *m32 = (const u32 *)msa_rm;
+        if (Lw <= 32) hipLaunchKernelGGL(k_reweight_reg<32>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
+        else if (Lw <= 64) hipLaunchKernelGGL(k_reweight_reg<64>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
+        else if (Lw <= 96) hipLaunchKernelGGL(k_reweight_reg<96>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
+        else if (Lw <= 128) hipLaunchKernelGGL(k_reweight_reg<128>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
+        else hipLaunchKernelGGL(k_reweight_reg<192>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
+        return hipGetLastError();
+    }
     int tsplit = (2048 + d.nstiles - 1) / d.nstiles;
     int tper = (d.N + tsplit - 1) / tsplit;
     tper = ((tper + RW_TT - 1) / RW_TT) * RW_TT;

@@ -268,3 +268,31 @@ def test_evaluation_is_bit_reproducible_at_scale(plm):
             else:
                 assert fx == ref[0] and nll == ref[1]
                 assert np.array_equal(g, ref[2])
+
+
+def test_torch_exchange_zero_copy_and_nccl_single_rank(plm):
+    """the RCCL exchange path of evcouplings_amd.dist on one GPU: zero-copy torch view of a raw device
+    pointer, all_gather_into_tensor through the 'nccl' backend (world size 1), fit_distributed == fit."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from evcouplings_amd import dist as pdist
+    assert torch.cuda.is_available()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        buf = torch.arange(4096, dtype=torch.int64, device="cuda").to(torch.uint8)
+        keep = buf.clone()
+        view = torch.as_tensor(pdist._DeviceBytes(buf.data_ptr(), buf.numel()), device="cuda")
+        assert view.data_ptr() == buf.data_ptr()            # zero copy
+        view[:16] = 7
+        assert bool((buf[:16] == 7).all())
+        buf.copy_(keep)
+        assert pdist.make_torch_exchange()(buf.data_ptr(), buf.numel(), 1, 0) == 0
+        assert bool((buf == keep).all())
+        msa, _ = synthetic_msa(300, 20, seed=3)
+        a = pdist.fit_distributed(msa, q=Q, max_iter=10, epsilon=1e-12)
+        b = plm.fit(msa, Q, max_iter=10, epsilon=1e-12)
+        np.testing.assert_array_equal(a["cn"], b["cn"])
+    finally:
+        dist.destroy_process_group()
