@@ -96,6 +96,8 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
     d.n_native = d.nh_pad + d.nbp * d.Q * d.Q * 256;
     d.n_canon = (int64_t)d.L * d.Q + (int64_t)d.L * (d.L - 1) / 2 * d.Q * d.Q;
+    d.gap_mode = (p.flags & PLM_FLAG_IGNORE_GAPS) ? 1 : 0;
+    if (d.gap_mode && d.Q < 3) return fail(PLM_EINVAL, "ignore_gaps needs at least 2 non-gap states");
     *out = d;
     return PLM_OK;
 }
@@ -292,15 +294,16 @@ int set_start_point(plm_ctx *c) {
     const PlmDims &d = c->d;
     if (c->h_fi.empty()) return fail(PLM_EINVAL, "start point needs single-site frequencies: run marginals first");
     std::vector<float> h((size_t)d.nh_pad, 0.f);
+    const int a0 = d.gap_mode;   // gap mode: state 0 is not a model state, its field stays 0
     for (int i = 0; i < d.L; i++) {
         double mean = 0;
         std::vector<double> v(d.Q);
-        for (int a = 0; a < d.Q; a++) {
+        for (int a = a0; a < d.Q; a++) {
             v[a] = std::log((double)c->h_fi[(size_t)i * d.Q + a] + 1.0 / c->n_eff);
             mean += v[a];
         }
-        mean /= d.Q;
-        for (int a = 0; a < d.Q; a++) h[(size_t)i * d.Q + a] = (float)(v[a] - mean);
+        mean /= (d.Q - a0);
+        for (int a = a0; a < d.Q; a++) h[(size_t)i * d.Q + a] = (float)(v[a] - mean);
     }
     HIP_TRY(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_native, c->st));
     HIP_TRY(hipMemcpyAsync(c->x, h.data(), sizeof(float) * d.nh_pad, hipMemcpyHostToDevice, c->st));
@@ -490,8 +493,10 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     // weighted one-hot Gram matrix through the backward GEMM: G = X^T diag(w) X
     HIP_TRY(plm_launch_onehot_rt(d, c->msa_rm, c->w, c->Rt, c->st));
     HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
-    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->g, c->g, 0.f, 0.f, c->reg_part, 1, (float)(1.0 / c->n_eff),
-                                c->st));
+    // gap mode: raw weighted counts come back (factor 1) and are normalised per site / per pair over
+    // the ungapped sequences on the host
+    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->g, c->g, 0.f, 0.f, c->reg_part, 1,
+                                d.gap_mode ? 1.f : (float)(1.0 / c->n_eff), c->st));
     HIP_TRY(plm_launch_native_to_canon(d, c->g, c->canon, c->st));
     c->h_fi.resize((size_t)d.L * d.Q);
     HIP_TRY(hipMemcpyAsync(c->h_fi.data(), c->canon, sizeof(float) * d.L * d.Q, hipMemcpyDeviceToHost, c->st));
@@ -499,6 +504,28 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
         HIP_TRY(hipMemcpyAsync(fij_host, c->canon + (size_t)d.L * d.Q,
                                sizeof(float) * (d.n_canon - (int64_t)d.L * d.Q), hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
+    if (d.gap_mode) {
+        const int Q = d.Q;
+        for (int i = 0; i < d.L; i++) {
+            float *f = &c->h_fi[(size_t)i * Q];
+            double tot = 0;
+            for (int a = 1; a < Q; a++) tot += f[a];
+            f[0] = 0.f;
+            for (int a = 1; a < Q; a++) f[a] = tot > 0 ? (float)(f[a] / tot) : 0.f;
+        }
+        if (fij_host) {
+            const size_t npair = (size_t)d.L * (d.L - 1) / 2;
+            for (size_t p = 0; p < npair; p++) {
+                float *f = fij_host + p * Q * Q;
+                double tot = 0;
+                for (int a = 1; a < Q; a++)
+                    for (int b = 1; b < Q; b++) tot += f[a * Q + b];
+                for (int a = 0; a < Q; a++)
+                    for (int b = 0; b < Q; b++)
+                        f[a * Q + b] = (a && b && tot > 0) ? (float)(f[a * Q + b] / tot) : 0.f;
+            }
+        }
+    }
     if (fi_host) memcpy(fi_host, c->h_fi.data(), sizeof(float) * d.L * d.Q);
     return PLM_OK;
 }
@@ -778,7 +805,24 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
     const PlmDims &d = c->d;
     float *fn_dev = c->canon + d.n_canon;
     HIP_TRY(plm_launch_native_to_canon(d, c->x, c->canon, c->st));
-    HIP_TRY(plm_launch_fn(d, c->canon + (size_t)d.L * d.Q, fn_dev, c->st));
+    if (d.gap_mode) {
+        // the zero-sum gauge must be taken over the model's (Q-1) states only: repack the blocks
+        const int Q = d.Q, Qn = Q - 1;
+        const size_t npair = (size_t)d.L * (d.L - 1) / 2;
+        std::vector<float> full(npair * Q * Q), cut(npair * Qn * Qn);
+        HIP_TRY(hipMemcpyAsync(full.data(), c->canon + (size_t)d.L * Q, sizeof(float) * full.size(),
+                               hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        for (size_t p = 0; p < npair; p++)
+            for (int a = 1; a < Q; a++)
+                memcpy(&cut[(p * Qn + (a - 1)) * Qn], &full[(p * Q + a) * Q + 1], sizeof(float) * Qn);
+        HIP_TRY(hipMemcpyAsync(c->canon, cut.data(), sizeof(float) * cut.size(), hipMemcpyHostToDevice, c->st));
+        PlmDims dn = d;
+        dn.Q = Qn;
+        HIP_TRY(plm_launch_fn(dn, c->canon, fn_dev, c->st));
+    } else {
+        HIP_TRY(plm_launch_fn(d, c->canon + (size_t)d.L * d.Q, fn_dev, c->st));
+    }
     HIP_TRY(hipMemcpyAsync(fn_host, fn_dev, sizeof(float) * d.L * d.L, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     // APC (couplings/model.py:744-775): means over off-diagonal entries, diagonal blanked

@@ -47,6 +47,7 @@ struct PlmDims {
     int64_t nh_pad;    // L*Q rounded up to 256
     int64_t n_native;  // nh_pad + nbp*Q*Q*256
     int64_t n_canon;   // L*Q + L(L-1)/2*Q*Q
+    int gap_mode;      // 1: state 0 (gap) excluded from the model (plmc -g)
 };
 
 static inline __host__ __device__ int64_t plm_bp_index(int I, int J, int nb16) { // I <= J

@@ -135,9 +135,14 @@ int plm_reg_parts(const PlmDims &d) { return (int)(d.nbp * d.Q) + 1; }
 // =========================================================================================
 #define RW_TT 32   // t-rows per register tile
 #define RW_CW 16   // dwords (64 sites) per column chunk
+// zero bytes (gaps) of a packed word -> 0x7c, a value no alignment byte takes (states < 32, pad 127)
+__device__ __forceinline__ u32 gaps_to_sentinel(u32 v) {
+    const u32 z = (v - 0x01010101u) & ~v & 0x80808080u;   // 0x80 in every zero byte (all bytes < 0x80)
+    return v + (z >> 7) * 0x7cu;
+}
 __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32, int Lw, int N,
                                                  int thresh_padded, int t_per_block,
-                                                 int32_t *__restrict__ counts) {
+                                                 int32_t *__restrict__ counts, int gap_mode) {
     const int s = blockIdx.x * 256 + threadIdx.x;  // < Np always (rows exist, padded)
     const int tb0 = blockIdx.y * t_per_block;
     const int tb1 = min(N, tb0 + t_per_block);
@@ -151,7 +156,10 @@ __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32,
             u32 mine[RW_CW];
             const int cw = min(RW_CW, Lw - c0);
 #pragma unroll
-            for (int k = 0; k < RW_CW; k++) mine[k] = k < cw ? myrow[c0 + k] : 0x7e7e7e7eu;
+            for (int k = 0; k < RW_CW; k++) {
+                mine[k] = k < cw ? myrow[c0 + k] : 0x7e7e7e7eu;
+                if (gap_mode) mine[k] = gaps_to_sentinel(mine[k]);
+            }
 #pragma unroll
             for (int tt = 0; tt < RW_TT; tt++) {
                 // rows t >= N are padding rows (all 127): they exist in memory, never reach thresh
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32,
             }
         }
 #pragma unroll
-        for (int tt = 0; tt < RW_TT; tt++) cnt += (t0 + tt < tb1 && ident[tt] >= thresh_padded) ? 1 : 0;
+        for (int tt = 0; tt < RW_TT; tt++)
+            cnt += (t0 + tt < tb1 && (ident[tt] >= thresh_padded || (gap_mode && t0 + tt == s))) ? 1 : 0;
     }
     if (s < N && cnt) atomicAdd(&counts[s], cnt);
 }
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32,
 template <int LW>
 __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ msa32, int Lw, int N,
                                                      int thresh_padded, int t_per_block,
-                                                     int32_t *__restrict__ counts) {
+                                                     int32_t *__restrict__ counts, int gap_mode) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int tb0 = blockIdx.y * t_per_block;
     const int tb1 = min(N, tb0 + t_per_block);
@@ -191,6 +200,10 @@ __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ ms
         if (k < Lw) {   // Lw is a multiple of 8: whole uint4 loads
             const uint4 v = *(const uint4 *)(myrow + k);
             mine[k] = v.x; mine[k + 1] = v.y; mine[k + 2] = v.z; mine[k + 3] = v.w;
+            if (gap_mode) {   // gap-gap is not an identity: my gaps become a value no partner byte has
+#pragma unroll
+                for (int e = 0; e < 4; e++) mine[k + e] = gaps_to_sentinel(mine[k + e]);
+            }
         } else {
             mine[k] = mine[k + 1] = mine[k + 2] = mine[k + 3] = 0x7e7e7e7eu;   // never matches the partner's pad
         }
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ ms
                 cur = nxt;
             }
         }
-        cnt += (mism <= max_mism) ? 1 : 0;
+        cnt += (mism <= max_mism || (gap_mode && t == s)) ? 1 : 0;   // a sequence is always in its own cluster
     }
     if (s < N && cnt) atomicAdd(&counts[s], cnt);
 }
@@ -242,11 +255,11 @@ hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thres
         tsplit = (d.N + tper - 1) / tper;
         const dim3 grid(d.nstiles, tsplit), block(256);
         const u32 *m32 = (const u32 *)msa_rm;
-        if (Lw <= 32) hipLaunchKernelGGL(k_reweight_reg<32>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
-        else if (Lw <= 64) hipLaunchKernelGGL(k_reweight_reg<64>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
-        else if (Lw <= 96) hipLaunchKernelGGL(k_reweight_reg<96>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
-        else if (Lw <= 128) hipLaunchKernelGGL(k_reweight_reg<128>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
-        else hipLaunchKernelGGL(k_reweight_reg<192>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts);
+        if (Lw <= 32) hipLaunchKernelGGL(k_reweight_reg<32>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else if (Lw <= 64) hipLaunchKernelGGL(k_reweight_reg<64>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else if (Lw <= 96) hipLaunchKernelGGL(k_reweight_reg<96>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else if (Lw <= 128) hipLaunchKernelGGL(k_reweight_reg<128>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else hipLaunchKernelGGL(k_reweight_reg<192>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
         return hipGetLastError();
     }
     int tsplit = (2048 + d.nstiles - 1) / d.nstiles;
@@ -256,7 +269,7 @@ hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thres
     // the padded rows t in [N, Np) are readable; rows beyond Np are not: cap the tile walk
     // (tb1 <= N and t0+tt < t0+RW_TT <= Np + RW_TT) -> msa_rm is allocated with RW_TT spare rows
     hipLaunchKernelGGL(k_reweight, dim3(d.nstiles, tsplit), dim3(256), 0, st,
-                       (const u32 *)msa_rm, Lw, d.N, thr, tper, counts);
+                       (const u32 *)msa_rm, Lw, d.N, thr, tper, counts, d.gap_mode);
     return hipGetLastError();
 }
 
@@ -451,16 +464,19 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
 #endif
         }
     };
-    stage(0, 0);
+    // gap mode: the K steps of state 0 are skipped altogether (gapped neighbours contribute nothing)
+    const int gap = d.gap_mode, Qe = Q - gap, nsteps = d.nu * Qe;
+    stage(gap, 0);
     uint2 xa0 = *(const uint2 *)arow0, xa1 = *(const uint2 *)arow1;
-    int ks = 0;
+    int t = 0;
     for (int u = 0; u < d.nu; ++u) {
         uint2 na0 = xa0, na1 = xa1;
         if (u + 1 < d.nu) {
             na0 = *(const uint2 *)(arow0 + 32 * (u + 1));
             na1 = *(const uint2 *)(arow1 + 32 * (u + 1));
         }
-        for (int b = 0; b < Q; ++b, ++ks) {
+        for (int b = gap; b < Q; ++b, ++t) {
+            const int ks_next = (b + 1 < Q) ? u * Q + b + 1 : (u + 1) * Q + gap;
             // hipcc does NOT drain the LDS-DMA queue at this barrier (only lgkmcnt): without the
             // explicit wait a late global_load_lds piece is read before it lands (seen as
             // run-to-run noise at N=50k); every wave drains its own pieces, then the barrier
@@ -468,9 +484,9 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #endif
-            const DmaPlan dma{bt + (size_t)(ks + 1) * TILE + lane * 16, smem + ((ks + 1) & 1) * TILE, wave,
-                              ((PLM_ABLATE & 2) == 0 && ks + 1 < d.nksteps) ? 2 * Q : 0};
-            const char *lb = smem + (ks & 1) * TILE + lane * 16;
+            const DmaPlan dma{bt + (size_t)ks_next * TILE + lane * 16, smem + ((t + 1) & 1) * TILE, wave,
+                              ((PLM_ABLATE & 2) == 0 && t + 1 < nsteps) ? 2 * Q : 0};
+            const char *lb = smem + (t & 1) * TILE + lane * 16;
             const u32 bb = (u32)b * 0x01010101u;
 #if !(PLM_ABLATE & 8)
             const half8 a0 = onehot8(xa0.x, xa0.y, bb);
@@ -501,12 +517,13 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int s = s_wave + 16 * m + 4 * g + reg;
-            const float ws = A.w[s];
             const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
+            const bool skip = gap && xi == 0;            // gapped site: no conditional for (s, i)
+            const float ws = skip ? 0.f : A.w[s];
             float mx = -INFINITY;
 #pragma unroll
             for (int a = 0; a < Q; a++) {
-                const float H = fmaf(acc[m][a][reg], sc, hv[a]);
+                const float H = (gap && a == 0) ? -INFINITY : fmaf(acc[m][a][reg], sc, hv[a]);
                 acc[m][a][reg] = H;
                 mx = fmaxf(mx, H);
             }
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 Z += ev;
             }
             const float invZ = 1.f / Z;
-            if (site_ok) fxl -= ws * (hx - __logf(Z));
+            if (site_ok && !skip) fxl -= ws * (hx - __logf(Z));
             const float wr = site_ok ? ws * A.rscale : 0.f;
 #pragma unroll
             for (int a = 0; a < Q; a++)
@@ -775,8 +792,9 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__rest
             float v2 = 0.f;
             for (int k = 0; k < ks_count; k++) v2 += G[o2 + k * kstride];
             const float xv = x[xoff + (size_t)b * 256];
-            out = valid ? fmaf(scale, v + v2, 2.f * lambda_j * xv) : 0.f;
-            if (valid) reg += (double)xv * (double)xv;
+            const bool live = valid && !(d.gap_mode && (a == 0 || b == 0));
+            out = live ? fmaf(scale, v + v2, 2.f * lambda_j * xv) : 0.f;
+            if (live) reg += (double)xv * (double)xv;
         } else {
             out = valid ? scale * v : 0.f;
         }
@@ -804,8 +822,10 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
             for (int k = 0; k < ks_count; k++) v += G[o + k * kstride];
             if (mode == 0) {
                 const float xv = x[idx];
-                out = fmaf(scale, v, 2.f * lambda_h * xv);
-                reg += (double)xv * (double)xv;
+                if (!(d.gap_mode && a == 0)) {
+                    out = fmaf(scale, v, 2.f * lambda_h * xv);
+                    reg += (double)xv * (double)xv;
+                }
             } else {
                 out = scale * v;
             }

@@ -85,7 +85,31 @@ def scores(jij, L, q):
     return fn, cn
 
 
-def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, n_shards, shard):
+FLAG_IGNORE_GAPS = 2
+
+
+def _embed_gaps(x, L, q):
+    """(q-1)-state canonical vector -> q-state layout with zeros for state 0."""
+    qn = q - 1
+    x = np.asarray(x, dtype=np.float32)
+    npair = L * (L - 1) // 2
+    out_h = np.zeros((L, q), np.float32)
+    out_h[:, 1:] = x[:L * qn].reshape(L, qn)
+    out_j = np.zeros((npair, q, q), np.float32)
+    out_j[:, 1:, 1:] = x[L * qn:].reshape(npair, qn, qn)
+    return np.concatenate([out_h.ravel(), out_j.ravel()])
+
+
+def _strip_gaps(x, L, q):
+    """q-state canonical vector -> (q-1)-state layout (drops every entry that involves state 0)."""
+    npair = L * (L - 1) // 2
+    h = x[:L * q].reshape(L, q)[:, 1:]
+    j = x[L * q:].reshape(npair, q, q)[:, 1:, 1:]
+    return np.concatenate([h.ravel(), j.ravel()]).astype(np.float32)
+
+
+def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, n_shards, shard,
+             ignore_gaps=False):
     N, L = msa.shape
     p = PlmProblem()
     p.n_seqs, p.n_sites, p.n_states = N, L, q
@@ -93,26 +117,28 @@ def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbf
     p.theta_id, p.scale = float(theta_id), float(scale)
     p.lambda_h, p.lambda_j = float(lambda_h), float(lambda_j)
     p.max_iter, p.epsilon, p.lbfgs_m = int(max_iter), float(epsilon), int(lbfgs_m)
-    p.n_shards, p.shard, p.flags = int(n_shards), int(shard), 0
+    p.n_shards, p.shard, p.flags = int(n_shards), int(shard), FLAG_IGNORE_GAPS if ignore_gaps else 0
     return p
 
 
 def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
         epsilon=1e-3, lbfgs_m=6, device=0, stream=0, callback=None, n_shards=1, shard=0,
-        exchange=None, want_fij=True):
+        exchange=None, want_fij=True, ignore_gaps=False):
     """
     Whole couplings inference: reweight -> marginals -> L-BFGS -> scores.
 
     callback(iter, secs, cond, fx, nll, norm_h, norm_e) is called once per iteration.
     exchange(dev_ptr, bytes_per_shard, n_shards, shard) -> 0 implements the all-gather of
     the site-sharded gradient slabs (see evcouplings_amd.dist) and is required iff n_shards > 1.
+    ignore_gaps=True is plmc -g (tools.py:222-224): state 0 is excluded from the model and every
+    returned array has q-1 states (fi, hi: (L, q-1); fij, jij: (pairs, q-1, q-1)).
     Returns a dict of numpy arrays and scalars.
     """
     lib = _lib.load()
     msa = _msa(msa)
     N, L = msa.shape
     if lambda_j is None:
-        lambda_j = default_lambda_j(L, q)
+        lambda_j = default_lambda_j(L, q - 1 if ignore_gaps else q)
     npair = L * (L - 1) // 2
     out = dict(
         weights=np.zeros(N, np.float32), fi=np.zeros((L, q), np.float32),
@@ -135,9 +161,14 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     else:
         xcb = C.cast(None, _lib.EXCHANGE_CB)
     prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
-                    n_shards, shard)
+                    n_shards, shard, ignore_gaps)
     check(lib.plm_fit(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
                       None, xcb, None))
+    if ignore_gaps:   # drop the (all-zero) entries of state 0
+        out["fi"], out["hi"] = out["fi"][:, 1:].copy(), out["hi"][:, 1:].copy()
+        out["jij"] = out["jij"][:, 1:, 1:].copy()
+        if out["fij"] is not None:
+            out["fij"] = out["fij"][:, 1:, 1:].copy()
     out.update(
         n_eff=float(res.n_eff), iters=int(res.iters_done), n_evals=int(res.n_evals),
         status=int(res.status), status_msg=res.status_msg.decode("ascii", "replace"),
@@ -151,14 +182,17 @@ class PlmContext:
     """Alignment resident in HBM; step-wise access for benchmarks and the multi-GPU host."""
 
     def __init__(self, msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None,
-                 max_iter=100, epsilon=1e-3, lbfgs_m=6, device=0, stream=0, n_shards=1, shard=0):
+                 max_iter=100, epsilon=1e-3, lbfgs_m=6, device=0, stream=0, n_shards=1, shard=0,
+                 ignore_gaps=False):
         self.lib = _lib.load()
         msa = _msa(msa)
         self.N, self.L = msa.shape
         self.q = q
-        self.lambda_j = default_lambda_j(self.L, q) if lambda_j is None else lambda_j
+        self.ignore_gaps = bool(ignore_gaps)
+        self.qm = q - 1 if ignore_gaps else q      # model states (layout of x, g, fi, fij at this API)
+        self.lambda_j = default_lambda_j(self.L, self.qm) if lambda_j is None else lambda_j
         prob = _problem(msa, q, theta_id, scale, lambda_h, self.lambda_j, max_iter, epsilon, lbfgs_m,
-                        n_shards, shard)
+                        n_shards, shard, ignore_gaps)
         self._h = C.c_void_p()
         check(self.lib.plm_ctx_create(C.byref(prob), int(device), C.c_void_p(int(stream) or None),
                                       C.byref(self._h)))
@@ -211,23 +245,28 @@ class PlmContext:
         fi = np.zeros((self.L, self.q), np.float32)
         fij = np.zeros((self.L * (self.L - 1) // 2, self.q, self.q), np.float32) if pairs else None
         check(self.lib.plm_ctx_marginals(self._h, _ptr(fi), _ptr(fij)))
+        if self.ignore_gaps:
+            fi = fi[:, 1:].copy()
+            fij = None if fij is None else fij[:, 1:, 1:].copy()
         return fi, fij
 
     def set_x(self, x=None):
         if x is not None:
             x = np.ascontiguousarray(x, dtype=np.float32)
-            assert x.size == n_params(self.L, self.q)
+            assert x.size == n_params(self.L, self.qm)
+            if self.ignore_gaps:
+                x = _embed_gaps(x, self.L, self.q)
         check(self.lib.plm_ctx_set_x(self._h, _ptr(x)))
 
     def get_x(self):
         x = np.zeros(n_params(self.L, self.q), np.float32)
         check(self.lib.plm_ctx_get_x(self._h, _ptr(x)))
-        return x
+        return _strip_gaps(x, self.L, self.q) if self.ignore_gaps else x
 
     def get_g(self):
         g = np.zeros(n_params(self.L, self.q), np.float32)
         check(self.lib.plm_ctx_get_g(self._h, _ptr(g)))
-        return g
+        return _strip_gaps(g, self.L, self.q) if self.ignore_gaps else g
 
     def eval(self, sync=True):
         if not sync:

@@ -91,10 +91,6 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
     if not _valid_file(alignment):
         raise ResourceError("Alignment file does not exist: {}".format(alignment))
-    if ignore_gaps:
-        raise ExternalToolError(
-            "ignore_gaps=True (plmc -g) is not implemented by the HIP solver yet; "
-            "set ignore_gaps: False (q = 21 including the gap state)")
     if lambda_g not in (None, 0, 0.0):
         raise ExternalToolError("group-L1 regularisation (lambda_group != 0) is not supported by the HIP solver")
     for path in (couplings_file, param_file):
@@ -121,7 +117,7 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
     q = len(enc.alphabet)
     N, L = enc.msa.shape
 
-    fit_kwargs = dict(q=q, theta_id=theta, scale=scale, lambda_h=lambda_h, lambda_j=lambda_J,
+    fit_kwargs = dict(q=q, ignore_gaps=bool(ignore_gaps), theta_id=theta, scale=scale, lambda_h=lambda_h, lambda_j=lambda_J,
                       max_iter=iterations, epsilon=DEFAULTS["epsilon"] if epsilon is None else float(epsilon),
                       lbfgs_m=lbfgs_m, callback=callback)
     try:
@@ -138,10 +134,14 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
     weights[enc.valid] = res["weights"]
     model_io.write_raw_ec_file(couplings_file, enc.index_list, enc.target_seq, res["cn"])
     if param_file is not None:
+        # plmc -g writes a model over the alphabet without its gap character (the PABP example model of the
+        # reference's notebooks has a 20-letter alphabet)
+        model_alphabet = enc.alphabet[1:] if ignore_gaps else enc.alphabet
         model_io.write_model_file(
-            param_file, L=L, q=q, n_valid=enc.n_valid_seqs, n_invalid=enc.n_total_seqs - enc.n_valid_seqs,
+            param_file, L=L, q=len(model_alphabet), n_valid=enc.n_valid_seqs,
+            n_invalid=enc.n_total_seqs - enc.n_valid_seqs,
             num_iter=iterations, theta=1.0 - theta, lambda_h=lambda_h, lambda_j=lambda_J, lambda_group=0.0,
-            n_eff=res["n_eff"], alphabet=enc.alphabet, weights=weights, target_seq=enc.target_seq,
+            n_eff=res["n_eff"], alphabet=model_alphabet, weights=weights, target_seq=enc.target_seq,
             index_list=enc.index_list, fi=res["fi"], hi=res["hi"], fij=res["fij"], jij=res["jij"])
     if not _valid_file(couplings_file):
         raise ResourceError("HIP PLM solver returned no couplings: file={}".format(couplings_file))

@@ -63,6 +63,12 @@ typedef struct {
 
 #define PLM_FLAG_NONE 0
 #define PLM_FLAG_VERBOSE 1
+/* plmc -g / run_plmc(ignore_gaps=True) (tools.py:222-224): state 0 (the gap) is excluded from the
+ * model.  Sites where a sequence has a gap contribute no conditional, gapped neighbours no coupling,
+ * identities for reweighting count only non-gap matches, frequencies are normalised over ungapped
+ * sequences.  All arrays keep the q-state layout of the alphabet; every entry that involves state 0
+ * is zero (the Python host drops them and writes a (q-1)-state model file).  DESIGN.md section 2b. */
+#define PLM_FLAG_IGNORE_GAPS 2
 
 /* Per-iteration progress: the 7 columns of plmc's stderr table that
  * parse_plmc_log() collects (tools.py:59-83): iter time cond fx -loglk ||h|| ||e||. */

@@ -109,6 +109,51 @@ class Oracle:
             raise RuntimeError("oracle eval rc=%d" % rc)
         return fx.value, nll.value, g
 
+    # ---- gap-ignoring mode (plmc -g): model over q-1 states, see plm_oracle.c eval_gaps ----
+    def reweight_gaps(self, msa, theta_id):
+        msa = self._msa(msa)
+        N, L = msa.shape
+        counts = np.zeros(N, dtype=np.int32)
+        f = self._f("reweight_gaps")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        rc = f(self._p(msa), N, L, float(theta_id), self._p(counts))
+        if rc:
+            raise RuntimeError("oracle reweight_gaps rc=%d" % rc)
+        return counts
+
+    def marginals_gaps(self, msa, w, q, pairs=True):
+        msa = self._msa(msa)
+        N, L = msa.shape
+        qn = q - 1
+        w = np.ascontiguousarray(w, dtype=self.real)
+        fi = np.zeros((L, qn), dtype=self.real)
+        fij = np.zeros((L * (L - 1) // 2, qn, qn), dtype=self.real) if pairs else None
+        f = self._f("marginals_gaps")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        rc = f(self._p(msa), self._p(w), N, L, q, self._p(fi), self._p(fij))
+        if rc:
+            raise RuntimeError("oracle marginals_gaps rc=%d" % rc)
+        return fi, fij
+
+    def eval_gaps(self, msa, w, q, lambda_h, lambda_j, x):
+        """x, g in the (q-1)-state layout; msa holds 0..q-1 with 0 = gap."""
+        msa = self._msa(msa)
+        N, L = msa.shape
+        qn = q - 1
+        w = np.ascontiguousarray(w, dtype=self.real)
+        x = np.ascontiguousarray(x, dtype=self.real)
+        assert x.size == L * qn + L * (L - 1) // 2 * qn * qn
+        g = np.zeros_like(x)
+        fx, nll = C.c_double(0), C.c_double(0)
+        f = self._f("eval_gaps")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                      C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        rc = f(self._p(msa), self._p(w), N, L, q, float(lambda_h), float(lambda_j), self._p(x),
+               self._p(g), C.byref(fx), C.byref(nll))
+        if rc:
+            raise RuntimeError("oracle eval_gaps rc=%d" % rc)
+        return fx.value, nll.value, g
+
     def scores(self, jij, L, q):
         jij = np.ascontiguousarray(jij, dtype=self.real)
         fn = np.zeros((L, L))
@@ -121,9 +166,12 @@ class Oracle:
         return fn, cn
 
     def fit(self, msa, q, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
-            epsilon=1e-3, lbfgs_m=6, want_fij=True, callback=None):
+            epsilon=1e-3, lbfgs_m=6, want_fij=True, callback=None, ignore_gaps=False):
+        """ignore_gaps=True: plmc -g semantics of plm_oracle.c eval_gaps; all outputs have q-1 states."""
         msa = self._msa(msa)
         N, L = msa.shape
+        q_in = q
+        q = q - 1 if ignore_gaps else q          # model states
         if lambda_j is None:
             lambda_j = 0.01 * (q - 1) * (L - 1)
         npair = L * (L - 1) // 2
@@ -142,14 +190,14 @@ class Oracle:
                 callback(it, secs, cond, fxv, nll, nh, ne)
 
         cb = ITER_CB(_cb)
-        f = self._f("fit")
+        f = self._f("fit2")
         f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
-                      C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                      C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p,
                       C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                       C.POINTER(C.c_double), ITER_CB, C.c_void_p]
-        rc = f(self._p(msa), N, L, q, float(theta_id), float(scale), float(lambda_h),
-               float(lambda_j), int(max_iter), float(epsilon), int(lbfgs_m), self._p(weights),
+        rc = f(self._p(msa), N, L, q_in, float(theta_id), float(scale), float(lambda_h),
+               float(lambda_j), int(max_iter), float(epsilon), int(lbfgs_m), int(bool(ignore_gaps)), self._p(weights),
                C.byref(neff), self._p(fi), self._p(fij), self._p(x), self._p(fn), self._p(cn),
                C.byref(iters), C.byref(status), C.byref(nevals), C.byref(fx), cb, None)
         if rc:

@@ -207,6 +207,146 @@ int PLMO_NAME(eval)(const int8_t *msa, const real *w, int N, int L, int q, doubl
     return PLMO_OK;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Gap-ignoring mode (plmc -g; run_plmc's ignore_gaps, evcouplings/couplings/tools.py:222-224,
+ * protocol.py:159-165 "if we ignore gaps, there is one character less").  PARITY UNPINNED and
+ * partly a design decision: plmc's exact -g semantics cannot be checked here.  The spec used by
+ * both this oracle and the HIP path:
+ *   - the model has qn = q-1 states (alphabet without its first, gap, character); x, g, fi, fij
+ *     below are in that qn-state layout; msa still holds 0..q-1 with 0 = gap
+ *   - reweighting: a position counts as identical only if both residues are equal AND not gaps;
+ *     the threshold stays T = ceil(theta*L - 1e-9) on the full model length
+ *   - site i of sequence s contributes a conditional only if x_si is not a gap; gapped
+ *     neighbours contribute no coupling; the softmax runs over the qn non-gap states
+ *   - f_i(a) = sum_s w_s [x_si=a] / sum_s w_s [x_si != gap]; f_ij normalised by the weight of
+ *     sequences ungapped at both sites
+ * ------------------------------------------------------------------------------------------ */
+int PLMO_NAME(reweight_gaps)(const int8_t *msa, int N, int L, double theta_id, int32_t *counts) {
+    if (!msa || !counts || N <= 0 || L <= 0) return PLMO_EINVAL;
+    const int T = PLMO_NAME(threshold)(L, theta_id);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int s = 0; s < N; s++) {
+        const int8_t *a = msa + (size_t)s * L;
+        int c = 0;
+        for (int t = 0; t < N; t++) {
+            const int8_t *b = msa + (size_t)t * L;
+            int id = 0;
+            for (int k = 0; k < L; k++) id += (a[k] == b[k]) && (a[k] != 0);
+            c += (id >= T) || (t == s);   /* a sequence always belongs to its own cluster */
+        }
+        counts[s] = c;
+    }
+    return PLMO_OK;
+}
+
+int PLMO_NAME(marginals_gaps)(const int8_t *msa, const real *w, int N, int L, int q, real *fi, real *fij) {
+    if (!msa || !w || !fi || N <= 0 || L <= 0 || q <= 1) return PLMO_EINVAL;
+    const int qn = q - 1;
+    const size_t qq = (size_t)qn * qn;
+    for (int i = 0; i < L; i++) {
+        double c[64] = {0}, tot = 0;
+        for (int s = 0; s < N; s++) {
+            const int a = msa[(size_t)s * L + i];
+            if (a > 0) { c[a - 1] += w[s]; tot += w[s]; }
+        }
+        for (int a = 0; a < qn; a++) fi[(size_t)i * qn + a] = (real)(tot > 0 ? c[a] / tot : 0);
+    }
+    if (fij) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int i = 0; i < L - 1; i++)
+            for (int j = i + 1; j < L; j++) {
+                real *blk = fij + pair_index(i, j, L) * qq;
+                double *c = (double *)calloc(qq, sizeof(double)), tot = 0;
+                for (int s = 0; s < N; s++) {
+                    const int a = msa[(size_t)s * L + i], b = msa[(size_t)s * L + j];
+                    if (a > 0 && b > 0) { c[(size_t)(a - 1) * qn + (b - 1)] += w[s]; tot += w[s]; }
+                }
+                for (size_t k = 0; k < qq; k++) blk[k] = (real)(tot > 0 ? c[k] / tot : 0);
+                free(c);
+            }
+    }
+    return PLMO_OK;
+}
+
+int PLMO_NAME(eval_gaps)(const int8_t *msa, const real *w, int N, int L, int q, double lambda_h,
+                         double lambda_j, const real *x, real *g, double *fx_out, double *nll_out) {
+    if (!msa || !w || !x || !g || N <= 0 || L <= 1 || q <= 2 || q > 64) return PLMO_EINVAL;
+    const int qn = q - 1;
+    const size_t qq = (size_t)qn * qn, nh = (size_t)L * qn;
+    const real *J = x + nh;
+    real *slab = (real *)calloc((size_t)L * L * qq, sizeof(real));
+    if (!slab) return PLMO_ENOMEM;
+    double nll = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : nll)
+    for (int i = 0; i < L; i++) {
+        real H[64], Pr[64];
+        real *si = slab + (size_t)i * L * qq;
+        real *gh = g + (size_t)i * qn;
+        for (int a = 0; a < qn; a++) gh[a] = 0;
+        double site = 0;
+        for (int s = 0; s < N; s++) {
+            const int8_t *row = msa + (size_t)s * L;
+            const int xi = row[i] - 1;
+            if (xi < 0) continue;                       /* gapped site: no conditional */
+            const real ws = w[s];
+            for (int a = 0; a < qn; a++) H[a] = x[(size_t)i * qn + a];
+            for (int j = 0; j < L; j++) {
+                const int xj = row[j] - 1;
+                if (j == i || xj < 0) continue;         /* gapped neighbour: no coupling */
+                if (j < i) {
+                    const real *blk = J + pair_index(j, i, L) * qq + (size_t)xj * qn;
+                    for (int a = 0; a < qn; a++) H[a] += blk[a];
+                } else {
+                    const real *blk = J + pair_index(i, j, L) * qq + xj;
+                    for (int a = 0; a < qn; a++) H[a] += blk[(size_t)a * qn];
+                }
+            }
+            real mx = H[0];
+            for (int a = 1; a < qn; a++) mx = H[a] > mx ? H[a] : mx;
+            double Z = 0;
+            for (int a = 0; a < qn; a++) {
+                Pr[a] = (real)exp((double)(H[a] - mx));
+                Z += Pr[a];
+            }
+            site -= (double)ws * ((double)(H[xi] - mx) - log(Z));
+            for (int a = 0; a < qn; a++) Pr[a] = (real)(ws * (Pr[a] / Z));
+            Pr[xi] -= ws;
+            for (int a = 0; a < qn; a++) gh[a] += Pr[a];
+            for (int j = 0; j < L; j++) {
+                const int xj = row[j] - 1;
+                if (j == i || xj < 0) continue;
+                real *dst = si + (size_t)j * qq + xj;
+                for (int a = 0; a < qn; a++) dst[(size_t)a * qn] += Pr[a];
+            }
+        }
+        nll += site;
+    }
+    double reg = 0;
+    for (size_t k = 0; k < nh; k++) {
+        reg += lambda_h * (double)x[k] * (double)x[k];
+        g[k] += (real)(2.0 * lambda_h * x[k]);
+    }
+    double regj = 0;
+#pragma omp parallel for schedule(static) reduction(+ : regj)
+    for (int i = 0; i < L - 1; i++)
+        for (int j = i + 1; j < L; j++) {
+            const size_t p = pair_index(i, j, L) * qq;
+            const real *sij = slab + ((size_t)i * L + j) * qq;
+            const real *sji = slab + ((size_t)j * L + i) * qq;
+            for (int a = 0; a < qn; a++)
+                for (int b = 0; b < qn; b++) {
+                    const real xv = J[p + (size_t)a * qn + b];
+                    regj += lambda_j * (double)xv * (double)xv;
+                    g[nh + p + (size_t)a * qn + b] =
+                        sij[(size_t)a * qn + b] + sji[(size_t)b * qn + a] + (real)(2.0 * lambda_j * xv);
+                }
+        }
+    free(slab);
+    if (fx_out) *fx_out = nll + reg + regj;
+    if (nll_out) *nll_out = nll;
+    return PLMO_OK;
+}
+
 /* Zero-sum gauge -> Frobenius norm -> APC, following
  * evcouplings/couplings/model.py:179-233 (_zero_sum_gauge), :790-793 (FN over all q
  * states) and :744-775 (apc: column means over off-diagonal entries, factor L/(L-1),
@@ -268,10 +408,12 @@ typedef struct {
     int N, L, q;
     double lh, lj;
     int nevals;
+    int gaps;        /* 1: gap-ignoring mode, model has q-1 states */
 } evalctx_t;
 
 static int ctx_eval(evalctx_t *c, const real *x, real *g, double *fx, double *nll) {
     c->nevals++;
+    if (c->gaps) return PLMO_NAME(eval_gaps)(c->msa, c->w, c->N, c->L, c->q, c->lh, c->lj, x, g, fx, nll);
     return PLMO_NAME(eval)(c->msa, c->w, c->N, c->L, c->q, c->lh, c->lj, x, g, fx, nll);
 }
 
@@ -394,7 +536,7 @@ typedef struct {
 static int lbfgs_run(evalctx_t *c, size_t n, real *x, const lbfgs_opt_t *o, plmo_iter_cb cb,
                      void *user, double *fx_final, int *status) {
     const int m = o->m;
-    const size_t nh = (size_t)c->L * c->q;
+    const size_t nh = (size_t)c->L * (c->q - c->gaps);
     real *g = malloc(sizeof(real) * n), *xp = malloc(sizeof(real) * n), *gp = malloc(sizeof(real) * n);
     real *d = malloc(sizeof(real) * n);
     real *S = malloc(sizeof(real) * n * m), *Y = malloc(sizeof(real) * n * m);
@@ -536,22 +678,25 @@ done:
 
 /* Full fit: reweight -> marginals -> L-BFGS from (h = centred log-frequency, J = 0)
  * -> scores.  All output buffers caller-allocated; any may be NULL except x_out.
- *   weights N, fi L*q, fij npair*q*q, x_out L*q + npair*q*q, fn/cn L*L (double). */
-int PLMO_NAME(fit)(const int8_t *msa, int N, int L, int q, double theta_id, double scale,
-                   double lambda_h, double lambda_j, int max_iter, double epsilon, int lbfgs_m,
-                   real *weights, double *neff_out, real *fi, real *fij, real *x_out, double *fn,
-                   double *cn, int *iters_out, int *status_out, int *nevals_out, double *fx_out,
-                   plmo_iter_cb cb, void *user) {
-    if (!msa || !x_out || N <= 0 || L <= 1 || q <= 1 || q > 64) return PLMO_EINVAL;
+ *   weights N, fi L*qm, fij npair*qm*qm, x_out L*qm + npair*qm*qm, fn/cn L*L (double),
+ *   qm = q (ignore_gaps = 0) or q-1 (ignore_gaps = 1, see eval_gaps). */
+int PLMO_NAME(fit2)(const int8_t *msa, int N, int L, int q, double theta_id, double scale,
+                    double lambda_h, double lambda_j, int max_iter, double epsilon, int lbfgs_m,
+                    int ignore_gaps, real *weights, double *neff_out, real *fi, real *fij, real *x_out,
+                    double *fn, double *cn, int *iters_out, int *status_out, int *nevals_out,
+                    double *fx_out, plmo_iter_cb cb, void *user) {
+    if (!msa || !x_out || N <= 0 || L <= 1 || q <= 1 + (ignore_gaps ? 1 : 0) || q > 64) return PLMO_EINVAL;
     for (size_t k = 0; k < (size_t)N * L; k++)
         if (msa[k] < 0 || msa[k] >= q) return PLMO_EINVAL;
-    const size_t qq = (size_t)q * q, nh = (size_t)L * q, npair = (size_t)L * (L - 1) / 2;
+    const int gaps = ignore_gaps ? 1 : 0, qm = q - gaps;
+    const size_t qq = (size_t)qm * qm, nh = (size_t)L * qm, npair = (size_t)L * (L - 1) / 2;
     const size_t n = nh + npair * qq;
     int32_t *counts = malloc(sizeof(int32_t) * N);
     real *w = weights ? weights : malloc(sizeof(real) * N);
     real *fi_l = fi ? fi : malloc(sizeof(real) * nh);
     if (!counts || !w || !fi_l) return PLMO_ENOMEM;
-    int rc = PLMO_NAME(reweight)(msa, N, L, theta_id, counts);
+    int rc = gaps ? PLMO_NAME(reweight_gaps)(msa, N, L, theta_id, counts)
+                  : PLMO_NAME(reweight)(msa, N, L, theta_id, counts);
     if (rc) return rc;
     double neff = 0;
     for (int s = 0; s < N; s++) {
@@ -559,21 +704,21 @@ int PLMO_NAME(fit)(const int8_t *msa, int N, int L, int q, double theta_id, doub
         neff += w[s];
     }
     if (neff_out) *neff_out = neff;
-    rc = PLMO_NAME(marginals)(msa, w, N, L, q, fi_l, fij);
+    rc = gaps ? PLMO_NAME(marginals_gaps)(msa, w, N, L, q, fi_l, fij) : PLMO_NAME(marginals)(msa, w, N, L, q, fi_l, fij);
     if (rc) return rc;
     /* start point: h_i(a) = log(f_i(a) + 1/N_eff) minus its site mean, J = 0 */
     memset(x_out, 0, sizeof(real) * n);
     for (int i = 0; i < L; i++) {
         double mean = 0;
-        for (int a = 0; a < q; a++) {
-            const double v = log((double)fi_l[(size_t)i * q + a] + 1.0 / neff);
-            x_out[(size_t)i * q + a] = (real)v;
+        for (int a = 0; a < qm; a++) {
+            const double v = log((double)fi_l[(size_t)i * qm + a] + 1.0 / neff);
+            x_out[(size_t)i * qm + a] = (real)v;
             mean += v;
         }
-        mean /= q;
-        for (int a = 0; a < q; a++) x_out[(size_t)i * q + a] -= (real)mean;
+        mean /= qm;
+        for (int a = 0; a < qm; a++) x_out[(size_t)i * qm + a] -= (real)mean;
     }
-    evalctx_t c = {msa, w, N, L, q, lambda_h, lambda_j, 0};
+    evalctx_t c = {msa, w, N, L, q, lambda_h, lambda_j, 0, gaps};
     lbfgs_opt_t o = {max_iter, epsilon, lbfgs_m > 0 ? lbfgs_m : 6, 20, 1e-4, 0.9, 1e-16, 1e-20, 1e20,
                      sizeof(real) == 4 ? 1e-6 : 1e-13};
     int status = 0;
@@ -585,11 +730,21 @@ int PLMO_NAME(fit)(const int8_t *msa, int N, int L, int q, double theta_id, doub
     if (nevals_out) *nevals_out = c.nevals;
     if (fx_out) *fx_out = fx;
     if (fn && cn) {
-        rc = PLMO_NAME(scores)(x_out + nh, L, q, fn, cn);
+        rc = PLMO_NAME(scores)(x_out + nh, L, qm, fn, cn);
         if (rc) return rc;
     }
     free(counts);
     if (!weights) free(w);
     if (!fi) free(fi_l);
     return PLMO_OK;
+}
+
+int PLMO_NAME(fit)(const int8_t *msa, int N, int L, int q, double theta_id, double scale,
+                   double lambda_h, double lambda_j, int max_iter, double epsilon, int lbfgs_m,
+                   real *weights, double *neff_out, real *fi, real *fij, real *x_out, double *fn,
+                   double *cn, int *iters_out, int *status_out, int *nevals_out, double *fx_out,
+                   plmo_iter_cb cb, void *user) {
+    return PLMO_NAME(fit2)(msa, N, L, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, 0,
+                           weights, neff_out, fi, fij, x_out, fn, cn, iters_out, status_out, nevals_out,
+                           fx_out, cb, user);
 }

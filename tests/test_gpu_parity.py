@@ -296,3 +296,49 @@ def test_torch_exchange_zero_copy_and_nccl_single_rank(plm):
         np.testing.assert_array_equal(a["cn"], b["cn"])
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- gap-ignoring mode (plmc -g, row N1)
+def test_gap_mode_reweight_marginals_eval_match_oracle(plm, oracle64):
+    rng = np.random.default_rng(11)
+    N, L = 700, 40
+    msa, _ = synthetic_msa(N, L, seed=23)
+    msa[5] = 0                                     # an all-gap row
+    msa[6, 3:] = 0                                 # a nearly empty row
+    with plm.PlmContext(msa, q=Q, ignore_gaps=True, lambda_h=0.01, lambda_j=3.0) as ctx:
+        w, counts, neff = ctx.reweight()
+        np.testing.assert_array_equal(counts, oracle64.reweight_gaps(msa, 0.8))      # bit exact
+        fi, fij = ctx.marginals()
+        fi_o, fij_o = oracle64.marginals_gaps(msa, w.astype(np.float64), Q)
+        assert fi.shape == (L, 20) and fij.shape == (L * (L - 1) // 2, 20, 20)
+        np.testing.assert_allclose(fi, fi_o, atol=2e-6)
+        np.testing.assert_allclose(fij, fij_o, atol=2e-6)
+        x = (0.1 * rng.normal(size=plm.n_params(L, 20))).astype(np.float32)
+        ctx.set_x(x)
+        fx, nll = ctx.eval()
+        g = ctx.get_g()
+        np.testing.assert_array_equal(ctx.get_x(), x)
+        fx_o, nll_o, g_o = oracle64.eval_gaps(msa, w.astype(np.float64), Q, 0.01, 3.0, x.astype(np.float64))
+        assert fx == pytest.approx(fx_o, rel=2e-6) and nll == pytest.approx(nll_o, rel=2e-6)
+        np.testing.assert_allclose(g, g_o, atol=2e-5 * np.abs(g_o).max(), rtol=2e-5)
+
+
+def test_gap_mode_fit_and_files(plm, oracle64, tmp_path):
+    from evcouplings_amd import model_io, tools
+    from evcouplings_amd.synthetic import msa_to_a2m
+    N, L = 600, 24
+    msa, _ = synthetic_msa(N, L, seed=31)
+    ref = oracle64.fit(msa, Q, lambda_h=0.01, max_iter=3000, epsilon=1e-7, ignore_gaps=True)
+    res = plm.fit(msa, Q, lambda_h=0.01, max_iter=3000, epsilon=2e-6, ignore_gaps=True)
+    assert res["lambda_j"] == pytest.approx(0.01 * 19 * (L - 1)) and res["hi"].shape == (L, 20)
+    assert res["n_eff"] == pytest.approx(ref["n_eff"], rel=1e-6)
+    assert res["fx"] == pytest.approx(ref["fx"], rel=1e-6)
+    np.testing.assert_allclose(res["cn"], ref["cn"], atol=1e-4)          # the judged quantity
+    np.testing.assert_allclose(res["jij"], ref["jij"], atol=5e-4)        # flat rare-state directions, f32 floor
+    # through the run_plmc boundary: 20-letter model file, as plmc -g writes
+    ali = msa_to_a2m(msa, str(tmp_path / "g.a2m"))
+    out = tools.run_plmc_hip(ali, str(tmp_path / "g_ECs.txt"), str(tmp_path / "g.model"), focus_seq="SYN",
+                             ignore_gaps=True, iterations=20, lambda_h=0.01, lambda_J=0.01 * 19 * (L - 1))
+    m = model_io.read_model_file(out.param_file)
+    assert m["q"] == 20 and m["alphabet"] == "ACDEFGHIKLMNPQRSTVWY" and m["jij"].shape == (L * (L - 1) // 2, 20, 20)
+    np.testing.assert_allclose(m["fi"].sum(axis=1), 1.0, atol=1e-5)

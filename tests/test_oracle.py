@@ -146,3 +146,74 @@ def test_fit_respects_max_iter_and_reports_status(oracle64):
     res = oracle64.fit(msa, Q, max_iter=5, epsilon=1e-12)
     assert res["iters"] == 5 and res["status"] == 1
     assert len(res["table"]) == 5
+
+
+# ------------------------------------------------------------------ gap-ignoring mode (plmc -g)
+def _numpy_eval_gaps(msa, w, q, lh, lj, x):
+    """independent float64 restatement of the gap-ignoring objective (masking formulation)."""
+    N, L = msa.shape
+    qn = q - 1
+    h, J = numpy_ref.unpack(np.asarray(x, np.float64), L, qn)
+    X = np.zeros((N, L, qn))
+    nz = msa > 0
+    s_idx, i_idx = np.nonzero(nz)
+    X[s_idx, i_idx, msa[s_idx, i_idx] - 1] = 1.0           # all-zero rows for gaps
+    H = h[None] + np.einsum("sjb,ijab->sia", X, J)
+    H -= H.max(axis=2, keepdims=True)
+    logP = H - np.log(np.exp(H).sum(axis=2, keepdims=True))
+    M = nz[:, :, None] * np.asarray(w, np.float64)[:, None, None]     # weight only where site is not a gap
+    nll = -(M[:, :, 0] * (logP * X).sum(axis=2)).sum()
+    R = M * (np.exp(logP) - X)
+    gh = R.sum(axis=0) + 2 * lh * h
+    G = np.einsum("sia,sjb->ijab", R, X)
+    gJ = G + G.transpose(1, 0, 3, 2) + 2 * lj * J
+    iu, ju = np.triu_indices(L, 1)
+    fx = nll + lh * (h ** 2).sum() + lj * (J[iu, ju] ** 2).sum()
+    return fx, nll, numpy_ref.pack_grad(gh, gJ, L)
+
+
+def test_gap_mode_eval_matches_numpy_and_reduces_to_plain_model(oracle64):
+    rng = np.random.default_rng(4)
+    N, L, q = 80, 7, 6
+    msa = rng.integers(0, q, size=(N, L)).astype(np.int8)
+    w = rng.random(N) + 0.2
+    qn = q - 1
+    x = 0.3 * rng.normal(size=L * qn + L * (L - 1) // 2 * qn * qn)
+    fx, nll, g = oracle64.eval_gaps(msa, w, q, 0.05, 0.4, x)
+    fx2, nll2, g2 = _numpy_eval_gaps(msa, w, q, 0.05, 0.4, x)
+    assert fx == pytest.approx(fx2, rel=1e-12) and nll == pytest.approx(nll2, rel=1e-12)
+    np.testing.assert_allclose(g, g2, rtol=1e-9, atol=1e-11)
+    # without any gap the mode is the ordinary (q-1)-state model on the shifted alphabet
+    msa_ng = rng.integers(1, q, size=(N, L)).astype(np.int8)
+    a = oracle64.eval_gaps(msa_ng, w, q, 0.05, 0.4, x)
+    b = oracle64.eval((msa_ng - 1).astype(np.int8), w, qn, 0.05, 0.4, x)
+    assert a[0] == pytest.approx(b[0], rel=1e-13)
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(oracle64.reweight_gaps(msa_ng, 0.5), oracle64.reweight((msa_ng - 1).astype(np.int8), 0.5))
+
+
+def test_gap_mode_marginals_and_reweighting_rules(oracle64):
+    msa = np.array([[1, 2, 0, 3], [1, 2, 0, 3], [0, 2, 0, 1], [1, 0, 0, 0], [0, 0, 0, 0]], dtype=np.int8)
+    counts = oracle64.reweight_gaps(msa, 0.5)       # T = 2 identical non-gap positions
+    assert counts.tolist() == [2, 2, 1, 1, 1]       # all-gap / sparse rows still count themselves
+    w = np.array([1.0, 2.0, 1.0, 4.0, 1.0])
+    fi, fij = oracle64.marginals_gaps(msa, w, 4)
+    assert fi[0].tolist() == [1.0, 0.0, 0.0]                       # site 0: only state 1 among ungapped
+    assert fi[2].tolist() == [0.0, 0.0, 0.0]                       # site 2: everybody gapped
+    np.testing.assert_allclose(fi[3], [1 / 4, 0, 3 / 4])
+    np.testing.assert_allclose(fij[0].sum(), 1.0)                  # pair (0,1): sequences 0 and 1 only
+    assert fij[0][0, 1] == pytest.approx(1.0)
+
+
+def test_gap_mode_fit_converges(oracle64):
+    from scipy.optimize import minimize
+    msa, _ = synthetic_msa(250, 9, seed=6)
+    res = oracle64.fit(msa, Q, max_iter=2000, epsilon=1e-9, ignore_gaps=True)
+    assert res["hi"].shape == (9, 20) and res["jij"].shape == (36, 20, 20) and res["status"] in (0, 2)
+    w = res["weights"]
+    lj = res["lambda_j"]
+    assert lj == pytest.approx(0.01 * 19 * 8)
+    sp = minimize(lambda x: oracle64.eval_gaps(msa, w, Q, 0.01, lj, x)[::2], np.zeros_like(res["x"]), jac=True,
+                  method="L-BFGS-B", options=dict(maxiter=5000, ftol=1e-15, gtol=1e-9, maxcor=20))
+    assert abs(sp.fun - res["fx"]) <= 1e-8 * abs(sp.fun)
+    np.testing.assert_allclose(res["jij"].ravel(), sp.x[9 * 20:], atol=5e-6)
