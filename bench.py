@@ -34,6 +34,18 @@ PEAK_F32_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pmc_traffic_bytes(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary, or None."""
     import csv
@@ -201,6 +213,9 @@ def main():
                         "iterations and then creeps; the f32 line search stops at its rounding floor"}
         # --- CPU baseline: oracle f32 + OpenMP on a bounded sample ---------------------------
         if not args.no_cpu:
+            # one OpenMP thread per usable core (the box shows 256 CPUs but runs under a 16-core quota)
+            os.environ["OMP_NUM_THREADS"] = str(usable_cores())
+            os.environ.setdefault("OMP_PROC_BIND", "false")
             from oracle.oracle import Oracle
             orc = Oracle("f32")
             ns = min(N, 1500)

@@ -190,9 +190,15 @@ template <int LW>
 __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ msa32, int Lw, int N,
                                                      int thresh_padded, int t_per_block,
                                                      int32_t *__restrict__ counts, int gap_mode) {
+    // Symmetric: only pairs t > s are compared; a hit is credited to s (per-lane counter) and to t
+    // (wave ballot -> one LDS atomic per wave and t, flushed to HBM once per block).
+    extern __shared__ int tcount[];
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int tb0 = blockIdx.y * t_per_block;
     const int tb1 = min(N, tb0 + t_per_block);
+    if (tb1 <= (int)blockIdx.x * 256 + 1) return;          // whole T range at or below this S tile
+    for (int k = threadIdx.x; k < tb1 - tb0; k += 256) tcount[k] = 0;
+    __syncthreads();
     const u32 *__restrict__ myrow = msa32 + (size_t)s * Lw;
     u32 mine[LW];
 #pragma unroll
@@ -217,8 +223,8 @@ __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ ms
     asm volatile("" : "+v"(c7f));   // keep the constant in a VGPR (VOP3 takes one SGPR, no literal)
     const int nch = (Lw + 15) / 16;
     const int max_mism = 4 * Lw - thresh_padded + 4 * (16 * nch - Lw);
-    int cnt = 0;
-    for (int t = tb0; t < tb1; ++t) {
+    int cnt = 0;   // the sequence itself is pre-counted: the launcher fills counts[] with 1
+    for (int t = max(tb0, (int)blockIdx.x * 256 + 1); t < tb1; ++t) {
         const Chunk *__restrict__ trow = (const Chunk *)(msa32 + (size_t)t * Lw);
         int mism = 0;
         Chunk cur = trow[0];
@@ -237,29 +243,39 @@ __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ ms
                 cur = nxt;
             }
         }
-        cnt += (mism <= max_mism || (gap_mode && t == s)) ? 1 : 0;   // a sequence is always in its own cluster
+        const bool hit = t > s && s < N && mism <= max_mism;
+        cnt += hit ? 1 : 0;
+        const unsigned long long m = __ballot(hit);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&tcount[t - tb0], __popcll(m));
     }
     if (s < N && cnt) atomicAdd(&counts[s], cnt);
+    __syncthreads();
+    for (int k = threadIdx.x; k < tb1 - tb0; k += 256)
+        if (tcount[k]) atomicAdd(&counts[tb0 + k], tcount[k]);
 }
 
 hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thresh, int32_t *counts,
                                hipStream_t st) {
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * d.Np, st);
-    if (e != hipSuccess) return e;
     const int Lw = d.Lp32 / 4;
+    // symmetric kernel: every sequence starts with itself counted; fallback kernel: self is a match
+    hipError_t e = (Lw <= 192) ? hipMemsetD32Async((hipDeviceptr_t)counts, 1, (size_t)d.Np, st)
+                               : hipMemsetAsync(counts, 0, sizeof(int32_t) * d.Np, st);
+    if (e != hipSuccess) return e;
     // padded columns (value 127 in every row) always match: shift the threshold instead
     const int thr = thresh + (d.Lp32 - d.L);
     if (Lw <= 192) {
-        int tsplit = std::max(1, (4096 + d.nstiles - 1) / d.nstiles);
+        int tsplit = std::max(1, (8192 + d.nstiles - 1) / d.nstiles);   // ~half the blocks exit at once
+        tsplit = std::max(tsplit, (d.N + 8191) / 8192);                    // LDS column counters <= 32 KB
         int tper = (d.N + tsplit - 1) / tsplit;
         tsplit = (d.N + tper - 1) / tper;
         const dim3 grid(d.nstiles, tsplit), block(256);
+        const size_t lds = sizeof(int) * (size_t)tper;
         const u32 *m32 = (const u32 *)msa_rm;
-        if (Lw <= 32) hipLaunchKernelGGL(k_reweight_reg<32>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else if (Lw <= 64) hipLaunchKernelGGL(k_reweight_reg<64>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else if (Lw <= 96) hipLaunchKernelGGL(k_reweight_reg<96>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else if (Lw <= 128) hipLaunchKernelGGL(k_reweight_reg<128>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else hipLaunchKernelGGL(k_reweight_reg<192>, grid, block, 0, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        if (Lw <= 32) hipLaunchKernelGGL(k_reweight_reg<32>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else if (Lw <= 64) hipLaunchKernelGGL(k_reweight_reg<64>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else if (Lw <= 96) hipLaunchKernelGGL(k_reweight_reg<96>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else if (Lw <= 128) hipLaunchKernelGGL(k_reweight_reg<128>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        else hipLaunchKernelGGL(k_reweight_reg<192>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
         return hipGetLastError();
     }
     int tsplit = (2048 + d.nstiles - 1) / d.nstiles;
