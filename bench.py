@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--n-seqs", type=int, default=HEADLINE["N"])
     ap.add_argument("--n-sites", type=int, default=HEADLINE["L"])
     ap.add_argument("--no-fit", action="store_true", help="skip the whole-fit timing")
-    ap.add_argument("--fit-cap", type=int, default=3000, help="iteration cap of the fit-to-epsilon leg")
+    ap.add_argument("--fit-cap", type=int, default=4000, help="iteration cap of the fit-to-epsilon leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -206,11 +206,20 @@ def main():
             t1 = time.perf_counter()
             fit = plm.fit(msa, q, lambda_h=0.01, lambda_j=lam_j, max_iter=args.fit_cap, epsilon=1e-3,
                           device=local_rank, want_fij=False)
+            reach = {}
+            for thr in (1.0, 1e-1, 1e-2, 3e-3, 1e-3):
+                hit = [r for r in fit["table"] if r[2] < thr]
+                reach["%g" % thr] = {"iteration": hit[0][0], "seconds": hit[0][1]} if hit else None
+            fx_end = fit["table"][-1][3]
+            fx_hit = [r for r in fit["table"] if abs(r[3] - fx_end) <= 1e-8 * abs(fx_end)]
             out["fit"]["to_epsilon_1e-3"] = {
                 "seconds_total": time.perf_counter() - t1, "iterations": fit["iters"], "evaluations": fit["n_evals"],
                 "status": fit["status_msg"], "final_cond": fit["table"][-1][2], "iteration_cap": args.fit_cap,
-                "note": "lambda_h = 0.01 leaves rare-state fields almost flat: |g|/|x| falls below 1e-1 within ~1800 "
-                        "iterations and then creeps; the f32 line search stops at its rounding floor"}
+                "first_time_cond_below": reach,
+                "objective_within_1e-8_of_final": {"iteration": fx_hit[0][0], "seconds": fx_hit[0][1]},
+                "note": "cond = |g|/max(1,|x|). lambda_h = 0.01 leaves rare-state fields almost flat, so cond creeps "
+                        "after ~1e-1 and sits at the f32 noise floor of the gradient (2e-3..5e-3) once the objective "
+                        "has stopped changing in its 8th digit"}
         # --- CPU baseline: oracle f32 + OpenMP on a bounded sample ---------------------------
         if not args.no_cpu:
             # one OpenMP thread per usable core (the box shows 256 CPUs but runs under a 16-core quota)

@@ -661,7 +661,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     }
     double fx = c->h_scal[SL_FX], nll = c->h_scal[SL_NLL];
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
-    int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0;
+    int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
     if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) > eps) {
         double step = 1.0 / std::sqrt(gg);
         for (k = 1;; k++) {
@@ -728,17 +728,26 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     fprintf(stderr, "[plm]   trial %d: stp=%.9e  f-f0=%.6e  dg=%.6e\n", t, trace[t][0], trace[t][1], trace[t][2]);
             }
             if (lsrc < 0) {
-                if (!(fx <= finit)) {  // the last accepted point is still in (xp, gp): make it current again
-                    std::swap(c->x, c->xp);
-                    std::swap(c->g, c->gp);
-                    fx = finit;
-                    nll = nllinit;
+                // the last accepted point is still in (xp, gp): make it current again
+                std::swap(c->x, c->xp);
+                std::swap(c->g, c->gp);
+                fx = finit;
+                nll = nllinit;
+                k--;
+                if (stored > 0 && restarts < 2) {
+                    // a stale quasi-Newton model is the usual reason near the f32 floor: drop the history
+                    // and retry once from steepest descent before giving up
+                    restarts++;
+                    stored = 0;
+                    end = 0;
+                    step = 1.0 / std::sqrt(gg);
+                    continue;
                 }
                 status = PLM_STATUS_LINESEARCH;
                 ls_reason = -lsrc;
-                k--;
                 break;
             }
+            restarts = 0;
             step = stp;
             // new pair into slot `end`, then ONE pass: rows of the Gram matrix for s, y, g + norms
             float *s = S + (size_t)end * n, *y = Y + (size_t)end * n;

@@ -151,6 +151,7 @@ def test_fit_reaches_oracle_optimum_cn_within_1e4(plm, oracle64):
     np.testing.assert_allclose(res["weights"], ref["weights"], rtol=1e-6)
     assert res["fx"] == pytest.approx(ref["fx"], rel=1e-6)
     np.testing.assert_allclose(res["cn"], ref["cn"], atol=1e-4)
+    assert np.abs(res["cn"] - ref["cn"]).max() < 2e-5          # measured 6e-7: keep a wide margin under the bar
     np.testing.assert_allclose(res["jij"], ref["jij"], atol=1e-4)
     np.testing.assert_allclose(res["hi"], ref["hi"], atol=2e-3)
     fxs = [r[3] for r in res["table"]]
@@ -342,3 +343,48 @@ def test_gap_mode_fit_and_files(plm, oracle64, tmp_path):
     m = model_io.read_model_file(out.param_file)
     assert m["q"] == 20 and m["alphabet"] == "ACDEFGHIKLMNPQRSTVWY" and m["jij"].shape == (L * (L - 1) // 2, 20, 20)
     np.testing.assert_allclose(m["fi"].sum(axis=1), 1.0, atol=1e-5)
+
+
+# ---------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("N,L,q", [(1, 2, 21), (3, 17, 21), (33, 33, 21), (300, 47, 20), (260, 16, 5), (64, 50, 4)])
+def test_edge_shapes_eval_and_reweight(plm, oracle64, N, L, q):
+    """single sequence, L below/above the 16- and 32-site tiles, every instantiated alphabet size"""
+    rng = np.random.default_rng(N * 1000 + L)
+    msa = rng.integers(0, q, size=(N, L)).astype(np.int8)
+    msa[:, L // 2] = 0                                   # a column of gaps only
+    np.testing.assert_array_equal(plm.reweight(msa, 0.8), oracle64.reweight(msa, 0.8))
+    w = (1.0 / oracle64.reweight(msa, 0.8)).astype(np.float32)
+    x = (0.2 * rng.normal(size=plm.n_params(L, q))).astype(np.float32)
+    fx, nll, g = plm.evaluate(msa, w, q, 0.02, 1.3, x)
+    fx_o, nll_o, g_o = oracle64.eval(msa, w.astype(np.float64), q, 0.02, 1.3, x.astype(np.float64))
+    assert fx == pytest.approx(fx_o, rel=3e-6)
+    np.testing.assert_allclose(g, g_o, atol=3e-5 * max(1e-3, np.abs(g_o).max()), rtol=3e-5)
+    fi, fij = plm.marginals(msa, w, q)
+    fi_o, fij_o = oracle64.marginals(msa, w.astype(np.float64), q)
+    np.testing.assert_allclose(fi, fi_o, atol=3e-6)
+    np.testing.assert_allclose(fij, fij_o, atol=3e-6)
+
+
+def test_reweight_long_rows_use_the_chunked_kernel(plm, oracle64):
+    """L > 768 (row longer than 192 dwords) takes the column-chunked fallback kernel"""
+    msa, _ = synthetic_msa(300, 800, seed=2)
+    msa[7] = msa[3]
+    np.testing.assert_array_equal(plm.reweight(msa, 0.7), oracle64.reweight(msa, 0.7))
+    with plm.PlmContext(msa, q=Q, ignore_gaps=True) as ctx:
+        _, counts, _ = ctx.reweight()
+    np.testing.assert_array_equal(counts, oracle64.reweight_gaps(msa, 0.8))
+
+
+def test_invalid_inputs_fail_with_error_codes(plm):
+    from evcouplings_amd._lib import PlmError
+    good = np.zeros((8, 6), np.int8)
+    bad = good.copy()
+    bad[2, 3] = 21
+    for call, code in ((lambda: plm.fit(bad, q=21, max_iter=1), -1),          # state outside 0..q-1
+                       (lambda: plm.fit(good, q=7, max_iter=1), -4),           # alphabet size not instantiated
+                       (lambda: plm.fit(good[:, :1], q=21, max_iter=1), -1),   # fewer than 2 sites
+                       (lambda: plm.evaluate(good, -np.ones(8, np.float32), 21, 0.01, 1.0,
+                                             np.zeros(plm.n_params(6, 21), np.float32)), -1)):   # negative weights
+        with pytest.raises(PlmError) as info:
+            call()
+        assert info.value.code == code, str(info.value)
