@@ -79,11 +79,18 @@ template <int N> __device__ __forceinline__ void lds_wait(half8 &a, half8 &b) {
 struct DmaPlan {
     const char *src;   // global address of this lane's 16 B of piece 0
     char *dst;         // LDS base of the target buffer (wave-uniform)
-    int first;         // this wave's first piece (= wave id); pieces first + 8*PI
+    int first;         // this wave's first piece; pieces first + PLM_DMA_WAVES*PI
     int limit;         // number of pieces to copy (0 = nothing to stage)
 };
+// Waves w and w+4 of a 512-thread workgroup share a SIMD.  PLM_DMA_WAVES = 8: every wave stages its
+// share of the tile right after the barrier.  PLM_DMA_WAVES = 4 (one loader wave per SIMD, the
+// partner computing meanwhile) was measured on MI355X and is much slower (k_fwd 5.3 -> 6.2 ms,
+// k_bwd 5.8 -> 9.7 ms): the serial issue of 7-11 LDS-DMA pieces by one wave outlasts the step.
+#ifndef PLM_DMA_WAVES
+#define PLM_DMA_WAVES 8
+#endif
 template <int PI> __device__ __forceinline__ void dma_issue(const DmaPlan &P) {
-    const int p = P.first + 8 * PI;
+    const int p = P.first + PLM_DMA_WAVES * PI;
     if (p < P.limit) {
 #if PLM_STAGE_GLDS
         __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
@@ -433,7 +440,7 @@ __device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, c
 #endif
     acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh[A % 3], acc[0][A], 0, 0, 0);
     acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[A % 3], acc[1][A], 0, 0, 0);
-    dma_slot<(2 * Q + 7) / 8, Q, A>(dma);
+    dma_slot<(2 * Q + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, Q, A>(dma);
     acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[A % 3], acc[0][A], 0, 0, 0);
     acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[A % 3], acc[1][A], 0, 0, 0);
 }
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             __syncthreads();
 #endif
             const DmaPlan dma{bt + (size_t)ks_next * TILE + lane * 16, smem + ((t + 1) & 1) * TILE, wave,
-                              ((PLM_ABLATE & 2) == 0 && t + 1 < nsteps) ? 2 * Q : 0};
+                              ((PLM_ABLATE & 2) == 0 && t + 1 < nsteps && wave < PLM_DMA_WAVES) ? 2 * Q : 0};
             const char *lb = smem + (t & 1) * TILE + lane * 16;
             const u32 bb = (u32)b * 0x01010101u;
 #if !(PLM_ABLATE & 8)
@@ -631,7 +638,7 @@ __device__ __forceinline__ void bwd_col(f32x4 (&acc)[FM][FN], const half8 (&af)[
     lds_wait<(C + 1 < FN) ? 2 : 0>(bh[C & 1], bl[C & 1]);
 #pragma unroll
     for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh[C & 1], acc[f][C], 0, 0, 0);
-    dma_slot<(4 * FN + 7) / 8, FN, C>(dma);
+    dma_slot<(4 * FN + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, FN, C>(dma);
 #pragma unroll
     for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl[C & 1], acc[f][C], 0, 0, 0);
 }
@@ -696,7 +703,8 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
         if (ss + 1 < k1) nx = *(const uint2 *)(acol + (size_t)32 * (ss + 1));
         const int np_valid = min(4 * FN, 2 * (d.nnfl - nfl0));
         const DmaPlan dma{Rt + ((size_t)(ss + 1) * d.nnfl + nfl0) * 2048 + lane * 16,
-                          smem + ((ss + 1 - k0) & 1) * TILE, wave, (ss + 1 < k1) ? np_valid : 0};
+                          smem + ((ss + 1 - k0) & 1) * TILE, wave,
+                          (ss + 1 < k1 && wave < PLM_DMA_WAVES) ? np_valid : 0};
         if (row_ok) {
             const char *lb = smem + ((ss - k0) & 1) * TILE + (wn * FN) * 2048 + lane * 16;
             half8 af[FM];
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
             for (int f = 0; f < FM; f++) af[f] = onehot8(xa.x, xa.y, (u32)(b0 + f) * 0x01010101u);
             bwd_kstep<FM, FN>(acc, af, lds_addr(lb), dma, std::make_integer_sequence<int, FN>{});
         } else {
-            dma_slot<(4 * FN + 7) / 8, 1, 0>(dma);   // idle row waves still copy their share of the tile
+            dma_slot<(4 * FN + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, 1, 0>(dma);   // idle row waves still copy their share
         }
         xa = nx;
     }
