@@ -227,6 +227,7 @@ def main():
             os.environ.setdefault("OMP_PROC_BIND", "false")
             from oracle.oracle import Oracle
             orc = Oracle("f32")
+            orc.set_num_threads(usable_cores())
             ns = min(N, 1500)
             sub = np.ascontiguousarray(msa[:ns])
             wsub = w[:ns].astype(np.float32)

@@ -62,6 +62,13 @@ class Oracle:
     def num_threads(self):
         return int(self._f("num_threads")())
 
+    def set_num_threads(self, n):
+        """libgomp may have read OMP_NUM_THREADS long before this library was loaded (torch bundles it)."""
+        f = self._f("set_num_threads")
+        f.argtypes = [C.c_int]
+        f.restype = None
+        f(int(n))
+
     def threshold(self, L, theta_id):
         f = self._f("threshold")
         f.argtypes = [C.c_int, C.c_double]

@@ -62,6 +62,14 @@ static inline size_t pair_index(int i, int j, int L) { /* i < j */
 
 int PLMO_NAME(sizeof_real)(void) { return (int)sizeof(real); }
 
+void PLMO_NAME(set_num_threads)(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int PLMO_NAME(num_threads)(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
