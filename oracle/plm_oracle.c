@@ -17,7 +17,12 @@
  *     - the symmetric L2-regularised PLM objective + gradient
  *     - the L-BFGS driver
  *   For those two the oracle is pinned only by first principles: brute-force
- *   enumeration, finite differences and convexity (tests/test_oracle.py).
+ *   enumeration, finite differences and convexity (tests/test_oracle.py) -- with one
+ *   exception the reference does provide: the scaling convention of the field part
+ *   (unnormalised N_eff-weighted log-likelihood + lambda_h |h|^2, no 1/2) is the one
+ *   CouplingsModel.to_independent_model minimises (couplings/model.py:894-910); its
+ *   optimum is checked to be a stationary point of this objective at J = 0
+ *   (tests/golden/independent_model_a.npz).
  *
  * Build:  gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC            -> double (parity)
  *         gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC -DPLMO_F32 -> float  (timed

@@ -190,6 +190,26 @@ def main():
             assert fields[0] is None and fields[3] is None and fields[5] == 1
     with open(os.path.join(HERE, "plmc_log.json"), "w") as f:
         json.dump(out, f, indent=1)
+
+    # ---- (5) scaling convention of the objective: the reference states the field
+    # part itself in CouplingsModel.to_independent_model (model.py:894-910):  N_eff (logZ - f.x) + lambda_h |x|^2.
+    # Its optimum for the frequencies of golden alignment "a" must be a stationary point of our objective
+    # at J = 0 (tests/test_oracle.py, tests/test_gpu_parity.py).
+    za = np.load(os.path.join(HERE, "reweight_freqs.npz"))
+    ca = {f: za["a_" + f] for f in ("msa", "counts", "fi", "fij")}
+    La = ca["msa"].shape[1]
+    wa = 1.0 / ca["counts"]
+    iu2 = np.triu_indices(La, 1)
+    ind_path = os.path.join(HERE, "_tmp_indep.model")
+    model_io.write_model_file(
+        ind_path, L=La, q=q, n_valid=len(wa), n_invalid=0, num_iter=1, theta=0.2, lambda_h=0.01, lambda_j=1.0,
+        lambda_group=0.0, n_eff=float(wa.sum()), alphabet=ALPHABET_PROTEIN, weights=wa.astype(np.float32),
+        target_seq="A" * La, index_list=np.arange(1, La + 1), fi=ca["fi"], hi=np.zeros((La, q)),
+        fij=ca["fij"][iu2], jij=np.zeros((La * (La - 1) // 2, q, q)))
+    mi = model_mod.CouplingsModel(ind_path).to_independent_model()
+    os.remove(ind_path)
+    np.savez_compressed(os.path.join(HERE, "independent_model_a.npz"), h_ref=mi.h_i, lambda_h=0.01,
+                        n_eff=np.float32(wa.sum()).astype(np.float64), fi32=ca["fi"].astype(np.float32))
     print("golden vectors written to", HERE)
 
 

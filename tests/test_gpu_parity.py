@@ -388,3 +388,18 @@ def test_invalid_inputs_fail_with_error_codes(plm):
         with pytest.raises(PlmError) as info:
             call()
         assert info.value.code == code, str(info.value)
+
+
+def test_field_objective_scaling_matches_reference_independent_model(plm, golden_dir):
+    """same pin as tests/test_oracle.py, through the HIP path: the reference's regularised single-site
+    optimum (model.py:882-919) is a stationary point of the field gradient at J = 0"""
+    z = np.load(os.path.join(golden_dir, "independent_model_a.npz"))
+    c = _golden_cases(golden_dir)["a"]
+    msa, w = c["msa"], (1.0 / c["counts"]).astype(np.float32)
+    N, L = msa.shape
+    x = np.concatenate([z["h_ref"].ravel(), np.zeros(L * (L - 1) // 2 * Q * Q)]).astype(np.float32)
+    fx, nll, g = plm.evaluate(msa, w, Q, 0.01, 7.0, x)
+    assert np.abs(g[:L * Q]).max() < 2e-4
+    logZ = np.log(np.exp(z["h_ref"]).sum(axis=1))
+    ref_val = (w.sum() * (logZ - (c["fi"] * z["h_ref"]).sum(axis=1)) + 0.01 * (z["h_ref"] ** 2).sum(axis=1)).sum()
+    assert fx == pytest.approx(ref_val, rel=2e-6)

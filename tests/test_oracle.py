@@ -217,3 +217,27 @@ def test_gap_mode_fit_converges(oracle64):
                   method="L-BFGS-B", options=dict(maxiter=5000, ftol=1e-15, gtol=1e-9, maxcor=20))
     assert abs(sp.fun - res["fx"]) <= 1e-8 * abs(sp.fun)
     np.testing.assert_allclose(res["jij"].ravel(), sp.x[9 * 20:], atol=5e-6)
+
+
+def test_field_objective_scaling_matches_reference_independent_model(oracle64, golden_dir):
+    """App. D-2 pinned by reference code: to_independent_model (model.py:894-910) minimises
+    N_eff (logZ - f.x) + lambda_h |x|^2 per site; its optimum must be stationary for our objective at J = 0."""
+    z = np.load(os.path.join(golden_dir, "independent_model_a.npz"))
+    c = _golden_cases(golden_dir)["a"]
+    msa, w = c["msa"], 1.0 / c["counts"]
+    N, L = msa.shape
+    h_ref = z["h_ref"]
+    x = np.concatenate([h_ref.ravel(), np.zeros(L * (L - 1) // 2 * Q * Q)])
+    fx, nll, g = oracle64.eval(msa, w, Q, float(z["lambda_h"]), 7.0, x)
+    gh = g[:L * Q]
+    assert np.abs(gh).max() < 1e-4, np.abs(gh).max()          # fmin_bfgs stopped at gtol 1e-5 in f32-rounded inputs
+    assert np.abs(gh).max() < 1e-3 * np.abs(2 * 0.01 * h_ref).max() + 1e-4
+    # and the value is the reference's formula summed over sites (model.py:899-900)
+    neff = w.sum()
+    logZ = np.log(np.exp(h_ref).sum(axis=1))
+    ref_val = (neff * (logZ - (c["fi"] * h_ref).sum(axis=1)) + 0.01 * (h_ref ** 2).sum(axis=1)).sum()
+    assert fx == pytest.approx(ref_val, rel=1e-12)
+    # moving away from it along any field direction increases the objective
+    d = np.random.default_rng(0).normal(size=L * Q)
+    xp = x.copy(); xp[:L * Q] += 1e-2 * d
+    assert oracle64.eval(msa, w, Q, 0.01, 7.0, xp)[0] > fx
