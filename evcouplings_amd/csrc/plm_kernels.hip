@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void k_onehot_rt(PlmDims d, const int8_t *__re
 }
 hipError_t plm_launch_onehot_rt(const PlmDims &d, const int8_t *msa_rm, const float *w, void *Rt,
                                 hipStream_t st) {
+    if (d.b16_hi <= d.b16_lo) return hipSuccess;   // a trailing shard may own no site block
     hipLaunchKernelGGL(k_onehot_rt, dim3(d.nssteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, msa_rm, w,
                        (_Float16 *)Rt, ldexpf(1.f, PLM_R_EXP));
     return hipGetLastError();
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
     }
 }
 hipError_t plm_launch_expand(const PlmDims &d, const float *x, const int32_t *jexp, void *Bt, hipStream_t st) {
+    if (d.b16_hi <= d.b16_lo) return hipSuccess;
     hipLaunchKernelGGL(k_expand, dim3(d.nksteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, jexp,
                        (_Float16 *)Bt);
     return hipGetLastError();
@@ -592,6 +594,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
 
 hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
                               const float *x, const int32_t *jexp, void *Rt, double *fx_part, hipStream_t st) {
+    if (d.b16_hi <= d.b16_lo) return hipSuccess;
     FwdArgs A{msa_rm, w, (const char *)Bt, x, jexp, (_Float16 *)Rt, fx_part, ldexpf(1.f, PLM_R_EXP)};
     const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
     const size_t lds = (size_t)2 * 2 * d.Q * 1024;

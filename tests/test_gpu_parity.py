@@ -179,7 +179,7 @@ def test_sharded_evaluation_matches_single(plm, oracle64):
     w = (1.0 / oracle64.reweight(msa, 0.8)).astype(np.float32)
     x = (0.1 * np.random.default_rng(5).normal(size=plm.n_params(L, Q))).astype(np.float32)
     fx1, nll1, g1 = plm.evaluate(msa, w, Q, 0.01, 7.8, x)
-    for n_shards in (2, 3):
+    for n_shards in (2, 3, 4):      # L = 40 -> 3 site blocks: with 4 shards the last one owns none
         fx, nll, g = LoopbackShards(msa, w, Q, 0.01, 7.8, n_shards).evaluate(x)
         assert fx == pytest.approx(fx1, rel=1e-6)
         np.testing.assert_allclose(g, g1, atol=1e-5 * np.abs(g1).max(), rtol=1e-5)
