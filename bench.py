@@ -104,13 +104,15 @@ def main():
     ctx1.marginals(pairs=False)
     ctx1.set_x(None)
     if world > 1:
-        from evcouplings_amd.dist import make_torch_exchange
+        # sharded-state mode: parameters, gradient and L-BFGS state split by owning site block; per
+        # evaluation two all-to-alls of neighbour blocks + scalar all-reduces over RCCL
+        from evcouplings_amd.dist import make_torch_collective
         x0 = ctx1.get_x()
         ctx1.close()
         ctx = plm.PlmContext(msa, q=q, lambda_h=0.01, lambda_j=lam_j, device=local_rank, n_shards=world,
-                             shard=rank, max_iter=args.warmup, epsilon=1e-12)
+                             shard=rank, max_iter=args.warmup, epsilon=1e-12, sharded_state=True)
+        ctx.set_collective(make_torch_collective())
         ctx.set_weights(w)
-        ctx.set_exchange(make_torch_exchange())
         ctx.set_x(x0)
     else:
         ctx = ctx1
@@ -159,7 +161,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "headline: synthetic MSA L=%d q=%d N=%d, theta=0.8, lambda_h=0.01, lambda_J=%.1f"
                                % (L, q, N, lam_j),
-                   "n_eff": n_eff, "parallelism": "sites sharded x%d" % world,
+                   "n_eff": n_eff,
+                   "parallelism": "single GPU" if world == 1 else "sites + state sharded x%d (RCCL all-to-all)" % world,
                    "evals_per_iteration": res["n_evals"] / max(1, res["iters"])},
     }
 

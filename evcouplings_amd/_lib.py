@@ -19,6 +19,9 @@ K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_COUNT = 0, 1
 ITER_CB = C.CFUNCTYPE(None, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                       C.c_double, C.c_double, C.c_void_p)
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p)
+COLLECTIVE_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
+                            C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_void_p)
+COLL_ALLTOALL, COLL_ALLREDUCE_F64, COLL_ALLREDUCE_F32 = 1, 2, 3
 
 
 class PlmProblem(C.Structure):
@@ -53,6 +56,8 @@ SYMBOLS = [
     ("plm_last_error", C.c_char_p, []),
     ("plm_fit", C.c_int, [C.POINTER(PlmProblem), C.POINTER(PlmResult), C.c_int, _P, ITER_CB, _P,
                           EXCHANGE_CB, _P]),
+    ("plm_fit_sharded", C.c_int, [C.POINTER(PlmProblem), C.POINTER(PlmResult), C.c_int, _P, ITER_CB, _P,
+                                  COLLECTIVE_CB, _P]),
     ("plm_reweight", C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P]),
     ("plm_marginals", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("plm_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P,
@@ -61,6 +66,7 @@ SYMBOLS = [
     ("plm_ctx_create", C.c_int, [C.POINTER(PlmProblem), C.c_int, _P, C.POINTER(_P)]),
     ("plm_ctx_destroy", None, [_P]),
     ("plm_ctx_set_exchange", C.c_int, [_P, EXCHANGE_CB, _P]),
+    ("plm_ctx_set_collective", C.c_int, [_P, COLLECTIVE_CB, _P]),
     ("plm_ctx_set_options", C.c_int, [_P, C.c_int32, C.c_double, C.c_int32]),
     ("plm_ctx_native_size", C.c_int64, [_P]),
     ("plm_ctx_reweight", C.c_int, [_P]),

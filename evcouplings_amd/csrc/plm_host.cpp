@@ -97,6 +97,21 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.n_native = d.nh_pad + d.nbp * d.Q * d.Q * 256;
     d.n_canon = (int64_t)d.L * d.Q + (int64_t)d.L * (d.L - 1) / 2 * d.Q * d.Q;
     d.gap_mode = (p.flags & PLM_FLAG_IGNORE_GAPS) ? 1 : 0;
+    d.sharded = ((p.flags & PLM_FLAG_SHARDED_STATE) && nshards > 1) ? 1 : 0;
+    d.own_lo = d.sharded ? d.b16_lo : 0;
+    d.own_hi = d.sharded ? d.b16_hi : d.nb16;
+    d.nblk_own = d.own_hi - d.own_lo;
+    d.h_site0 = d.own_lo * 16;
+    d.bp_base = plm_bp_index(d.own_lo, d.own_lo, d.nb16);
+    d.np_own = plm_bp_index(d.own_hi, d.own_hi, d.nb16) - d.bp_base;
+    {
+        const int site_end = std::min(d.L, d.own_hi * 16);
+        const int64_t nhl = (int64_t)std::max(0, site_end - d.h_site0) * d.Q;
+        d.nh_pad_l = d.sharded ? std::max<int64_t>(256, (nhl + 255) / 256 * 256) : d.nh_pad;
+    }
+    d.n_local = d.nh_pad_l + d.np_own * d.Q * d.Q * 256;
+    d.nx_halo = (int64_t)d.own_lo * d.nblk_own;
+    d.ng_halo = (int64_t)d.nblk_own * (d.nb16 - d.own_hi);
     if (d.gap_mode && d.Q < 3) return fail(PLM_EINVAL, "ignore_gaps needs at least 2 non-gap states");
     *out = d;
     return PLM_OK;
@@ -117,7 +132,11 @@ struct plm_ctx {
     int32_t *counts = nullptr;
     void *Bt = nullptr, *Rt = nullptr;
     float *G = nullptr;        // split-K partial slabs (local)
-    float *gather = nullptr;   // exchange buffer [nshards][slab] (nshards > 1 only)
+    float *gather = nullptr;   // exchange buffer [nshards][slab] (replicated multi-shard mode only)
+    plm_collective_cb collective = nullptr;   // sharded-state mode
+    void *collective_user = nullptr;
+    float *xhalo = nullptr, *ghalo = nullptr, *xsend = nullptr, *gsend = nullptr;
+    std::vector<int64_t> x_send, x_recv, g_send, g_recv;   // all-to-all byte counts per rank
     double *fx_part = nullptr, *reg_part = nullptr, *dot_scratch = nullptr, *scal = nullptr;
     uint32_t *maxbits = nullptr;
     int32_t *jexp = nullptr;
@@ -146,7 +165,7 @@ template <typename T> int dalloc(T **p, size_t n_elems) {
 
 int ctx_alloc_lbfgs(plm_ctx *c, int m) {
     if (c->xp && c->hist_m >= m) return PLM_OK;
-    const size_t n = (size_t)c->d.n_native;
+    const size_t n = (size_t)c->d.n_local;
     if (!c->xp) {
         PLM_TRY(dalloc(&c->xp, n));
         PLM_TRY(dalloc(&c->gp, n));
@@ -160,10 +179,47 @@ int ctx_alloc_lbfgs(plm_ctx *c, int m) {
 }
 
 // enqueue one objective+gradient evaluation at c->x -> c->g, scal[0] = fx, scal[1] = nll
+// one collective of the sharded-state mode (stream is synchronised first: the host runs it with RCCL)
+int ctx_collective(plm_ctx *c, int op, void *send, void *recv, const int64_t *scounts, const int64_t *rcounts) {
+    if (!c->collective) return fail(PLM_EINVAL, "sharded-state mode needs a collective callback");
+    HIP_TRY(hipStreamSynchronize(c->st));
+    if (c->collective(op, send, recv, scounts, rcounts, c->d.nshards, c->d.shard, c->collective_user) != 0)
+        return fail(PLM_ECALLBACK, "collective callback failed (op %d)", op);
+    return PLM_OK;
+}
+// in-place sum over the shards of c->scal[first .. first+count)
+int ctx_allreduce_scalars(plm_ctx *c, int first, int count) {
+    if (!c->d.sharded) return PLM_OK;
+    const int64_t bytes = (int64_t)sizeof(double) * count;
+    return ctx_collective(c, PLM_COLL_ALLREDUCE_F64, c->scal + first, c->scal + first, &bytes, &bytes);
+}
+
+// sharded-state evaluation: local x (+ halo from lower shards) -> local g; scal[0..1] = this shard's
+// part of fx and nll (summed over shards by the caller together with its dot products)
+int ctx_eval_enqueue_sharded(plm_ctx *c) {
+    const PlmDims &d = c->d;
+    HIP_TRY(plm_launch_pack_x(d, c->x, c->xsend, c->st));
+    PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
+    HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
+                               d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, c->st));
+    HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
+    HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
+    if (d.nblk_own > 0) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
+    PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
+    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->ghalo, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
+                                c->reg_part, 0, 0.f, c->st));
+    HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d), c->scal,
+                                 c->st));
+    c->n_evals++;
+    return PLM_OK;
+}
+
 int ctx_eval_enqueue(plm_ctx *c) {
     const PlmDims &d = c->d;
+    if (d.sharded) return ctx_eval_enqueue_sharded(c);
     HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
-    HIP_TRY(plm_launch_expand(d, c->x, c->jexp, c->Bt, c->st));
+    HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
     HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
     HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
     const float *Gsrc = c->G;
@@ -183,8 +239,8 @@ int ctx_eval_enqueue(plm_ctx *c) {
         n_shard_nll = d.nshards;
         shard_nll = (const double *)((char *)c->gather + slab - 256);
     }
-    HIP_TRY(plm_launch_assemble(d, Gsrc, ks_count, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j, c->reg_part, 0,
-                                0.f, c->st));
+    HIP_TRY(plm_launch_assemble(d, Gsrc, ks_count, nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
+                                c->reg_part, 0, 0.f, c->st));
     HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), shard_nll, n_shard_nll, c->reg_part,
                                  plm_reg_parts(d), c->scal, c->st));
     c->n_evals++;
@@ -293,9 +349,9 @@ int set_start_point(plm_ctx *c) {
     // h_i(a) = log(f_i(a) + 1/N_eff) minus the site mean, J = 0
     const PlmDims &d = c->d;
     if (c->h_fi.empty()) return fail(PLM_EINVAL, "start point needs single-site frequencies: run marginals first");
-    std::vector<float> h((size_t)d.nh_pad, 0.f);
+    std::vector<float> h((size_t)d.nh_pad_l, 0.f);
     const int a0 = d.gap_mode;   // gap mode: state 0 is not a model state, its field stays 0
-    for (int i = 0; i < d.L; i++) {
+    for (int i = d.h_site0; i < std::min(d.L, d.own_hi * 16); i++) {
         double mean = 0;
         std::vector<double> v(d.Q);
         for (int a = a0; a < d.Q; a++) {
@@ -303,10 +359,10 @@ int set_start_point(plm_ctx *c) {
             mean += v[a];
         }
         mean /= (d.Q - a0);
-        for (int a = a0; a < d.Q; a++) h[(size_t)i * d.Q + a] = (float)(v[a] - mean);
+        for (int a = a0; a < d.Q; a++) h[(size_t)(i - d.h_site0) * d.Q + a] = (float)(v[a] - mean);
     }
-    HIP_TRY(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_native, c->st));
-    HIP_TRY(hipMemcpyAsync(c->x, h.data(), sizeof(float) * d.nh_pad, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_local, c->st));
+    HIP_TRY(hipMemcpyAsync(c->x, h.data(), sizeof(float) * d.nh_pad_l, hipMemcpyHostToDevice, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     return PLM_OK;
 }
@@ -344,7 +400,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     hipSetDevice(c->device);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon};
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);
@@ -390,10 +446,27 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
         (rc = dalloc(&c->dot_scratch, (size_t)4 * PLM_MAX_BASIS * PLM_DOT_BLOCKS)) ||
         (rc = dalloc(&c->scal, (size_t)256)) ||
         (rc = dalloc(&c->maxbits, (size_t)1)) || (rc = dalloc(&c->jexp, (size_t)1)) ||
-        (rc = dalloc(&c->x, (size_t)d.n_native)) || (rc = dalloc(&c->g, (size_t)d.n_native)) ||
+        (rc = dalloc(&c->x, (size_t)d.n_local)) || (rc = dalloc(&c->g, (size_t)d.n_local)) ||
         (rc = dalloc(&c->canon, (size_t)d.n_canon + (size_t)d.L * d.L)))
         return bail(rc);
-    if (d.nshards > 1 && (rc = dalloc((char **)&c->gather, plm_slab_bytes(d) * d.nshards))) return bail(rc);
+    if (d.nshards > 1 && !d.sharded && (rc = dalloc((char **)&c->gather, plm_slab_bytes(d) * d.nshards)))
+        return bail(rc);
+    if (d.sharded) {
+        const size_t blk = PLM_BLOCK_FLOATS(d);
+        if ((rc = dalloc(&c->xhalo, (size_t)d.nx_halo * blk)) || (rc = dalloc(&c->gsend, (size_t)d.nx_halo * blk)) ||
+            (rc = dalloc(&c->ghalo, (size_t)d.ng_halo * blk)) || (rc = dalloc(&c->xsend, (size_t)d.ng_halo * blk)))
+            return bail(rc);
+        // all-to-all byte counts: blocks exchanged with shard r = (own blocks) x (blocks of r), towards
+        // higher shards for couplings, towards lower shards for gradient fragments
+        c->x_send.assign(d.nshards, 0); c->x_recv.assign(d.nshards, 0);
+        c->g_send.assign(d.nshards, 0); c->g_recv.assign(d.nshards, 0);
+        for (int r = 0; r < d.nshards; r++) {
+            const int lo = std::min(d.nb16, r * d.blk_per_shard), hi = std::min(d.nb16, lo + d.blk_per_shard);
+            const int64_t bytes = (int64_t)d.nblk_own * (hi - lo) * (int64_t)blk * 4;
+            if (r > d.shard) { c->x_send[r] = bytes; c->g_recv[r] = bytes; }
+            if (r < d.shard) { c->x_recv[r] = bytes; c->g_send[r] = bytes; }
+        }
+    }
     hipError_t e;
     if ((e = hipHostMalloc((void **)&c->h_scal, sizeof(double) * 256)) != hipSuccess)
         return bail(fail(PLM_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e)));
@@ -404,8 +477,8 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     CT(hipMemcpyAsync(c->msa_cm, cm.data(), cm.size(), hipMemcpyHostToDevice, c->st));
     CT(hipMemsetAsync(c->w, 0, sizeof(float) * d.Np, c->st));
     CT(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(d), c->st));
-    CT(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_native, c->st));
-    CT(hipMemsetAsync(c->g, 0, sizeof(float) * d.n_native, c->st));
+    CT(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_local, c->st));
+    CT(hipMemsetAsync(c->g, 0, sizeof(float) * d.n_local, c->st));
     if (c->gather) CT(hipMemsetAsync(c->gather, 0, plm_slab_bytes(d) * d.nshards, c->st));
     CT(hipStreamSynchronize(c->st));
 #undef CT
@@ -420,6 +493,13 @@ int plm_ctx_set_exchange(plm_ctx_t *c, plm_exchange_cb exchange, void *user) {
     return PLM_OK;
 }
 
+int plm_ctx_set_collective(plm_ctx_t *c, plm_collective_cb collective, void *user) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    c->collective = collective;
+    c->collective_user = user;
+    return PLM_OK;
+}
+
 int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, double epsilon, int32_t lbfgs_m) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (max_iter >= 0) c->prob.max_iter = max_iter;
@@ -428,7 +508,7 @@ int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, double epsilon, int32_t 
     return PLM_OK;
 }
 
-int64_t plm_ctx_native_size(const plm_ctx_t *c) { return c ? c->d.n_native : 0; }
+int64_t plm_ctx_native_size(const plm_ctx_t *c) { return c ? c->d.n_local : 0; }
 
 int plm_ctx_set_weights(plm_ctx_t *c, const float *weights_host) {
     if (!c || !weights_host) return fail(PLM_EINVAL, "NULL argument");
@@ -495,7 +575,7 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
     // gap mode: raw weighted counts come back (factor 1) and are normalised per site / per pair over
     // the ungapped sequences on the host
-    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->g, c->g, 0.f, 0.f, c->reg_part, 1,
+    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->g, c->g, 0.f, 0.f, c->reg_part, 1,
                                 d.gap_mode ? 1.f : (float)(1.0 / c->n_eff), c->st));
     HIP_TRY(plm_launch_native_to_canon(d, c->g, c->canon, c->st));
     c->h_fi.resize((size_t)d.L * d.Q);
@@ -541,10 +621,22 @@ int plm_ctx_set_x(plm_ctx_t *c, const float *x_canonical_host) {
     return PLM_OK;
 }
 
+// c->canon <- the FULL canonical vector of a local (native-layout) vector; in sharded-state mode every
+// shard contributes its own entries and an all-reduce (sum) puts the whole vector on every rank
+static int canon_full(plm_ctx_t *c, const float *native) {
+    const PlmDims &d = c->d;
+    if (d.sharded) HIP_TRY(hipMemsetAsync(c->canon, 0, sizeof(float) * d.n_canon, c->st));
+    HIP_TRY(plm_launch_native_to_canon(d, native, c->canon, c->st));
+    if (d.sharded) {
+        const int64_t bytes = (int64_t)sizeof(float) * d.n_canon;
+        PLM_TRY(ctx_collective(c, PLM_COLL_ALLREDUCE_F32, c->canon, c->canon, &bytes, &bytes));
+    }
+    return PLM_OK;
+}
 static int get_vec(plm_ctx_t *c, const float *native, float *out_host) {
     if (!c || !out_host) return fail(PLM_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(plm_launch_native_to_canon(c->d, native, c->canon, c->st));
+    PLM_TRY(canon_full(c, native));
     HIP_TRY(hipMemcpyAsync(out_host, c->canon, sizeof(float) * c->d.n_canon, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     return PLM_OK;
@@ -557,6 +649,7 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
     HIP_TRY(hipSetDevice(c->device));
     PLM_TRY(ctx_eval_enqueue(c));
+    if (c->d.sharded) PLM_TRY(ctx_allreduce_scalars(c, 0, 2));   // every shard must call eval together
     if (fx_out || nll_out) {
         PLM_TRY(fetch_scalars(c, 0, 2));
         if (fx_out) *fx_out = c->h_scal[0];
@@ -577,7 +670,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
     HIP_TRY(hipSetDevice(c->device));
     const PlmDims &d = c->d;
-    const int64_t n = d.n_native;
+    const int64_t n = d.n_local;
     const int m = std::min(20, c->prob.lbfgs_m > 0 ? c->prob.lbfgs_m : 6);
     const int max_iter = c->prob.max_iter;
     const double eps = c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3;
@@ -595,12 +688,14 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     std::vector<double> alpha(m), cs(m), cy(m);
     const double t0 = now_s();
     c->n_evals = 0;
-    enum { SL_FX = 0, SL_NLL = 1, SL_XX = 2, SL_HH = 3, SL_DG = 4, SL_MD = 8 };
+    // device scalar slots; in sharded-state mode each fetch is preceded by a sum over the shards of
+    // exactly the slots that were just written ([FX..DG] after an evaluation, [XX..MD+..] after the pass)
+    enum { SL_FX = 0, SL_NLL = 1, SL_DG = 2, SL_XX = 3, SL_HH = 4, SL_MD = 8 };
 
     auto norm_dots = [&]() -> int {   // x.x (all) and x.x (fields only)
         const float *a[1] = {c->x};
         PLM_TRY(dots(c, 1, a, a, n, SL_XX));
-        PLM_TRY(dots(c, 1, a, a, d.nh_pad, SL_HH));
+        PLM_TRY(dots(c, 1, a, a, d.nh_pad_l, SL_HH));
         return PLM_OK;
     };
     auto direction = [&](int stored, int end, double *dginit) -> int {
@@ -654,6 +749,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         const float *a[1] = {c->g};
         PLM_TRY(dots(c, 1, a, a, n, SL_DG));
         PLM_TRY(norm_dots());
+        PLM_TRY(ctx_allreduce_scalars(c, 0, 8));
         PLM_TRY(fetch_scalars(c, 0, 8));
         gg = c->h_scal[SL_DG];
         xx = c->h_scal[SL_XX];
@@ -688,7 +784,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 {
                     const float *a[1] = {c->g}, *b[1] = {c->dir};
                     PLM_TRY(dots(c, 1, a, b, n, SL_DG));
-                    PLM_TRY(fetch_scalars(c, 0, 8));
+                    PLM_TRY(ctx_allreduce_scalars(c, SL_FX, 3));
+                    PLM_TRY(fetch_scalars(c, SL_FX, 3));
                 }
                 double dg = c->h_scal[SL_DG];
                 fx = c->h_scal[SL_FX];
@@ -762,7 +859,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             B.v[B.n++] = c->g;
             HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, c->st));
             PLM_TRY(norm_dots());
-            PLM_TRY(fetch_scalars(c, 0, SL_MD + 3 * B.n));
+            PLM_TRY(ctx_allreduce_scalars(c, SL_XX, SL_MD + 3 * B.n - SL_XX));
+            PLM_TRY(fetch_scalars(c, SL_XX, SL_MD + 3 * B.n - SL_XX));
             const double *md = c->h_scal + SL_MD;
             const int nbv = B.n, e = end;
             for (int j = 0; j < nst; j++) {
@@ -813,7 +911,7 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
     HIP_TRY(hipSetDevice(c->device));
     const PlmDims &d = c->d;
     float *fn_dev = c->canon + d.n_canon;
-    HIP_TRY(plm_launch_native_to_canon(d, c->x, c->canon, c->st));
+    PLM_TRY(canon_full(c, c->x));
     if (d.gap_mode) {
         // the zero-sum gauge must be taken over the model's (Q-1) states only: repack the blocks
         const int Q = d.Q, Qn = Q - 1;
@@ -864,14 +962,14 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     for (int r = 0; r < reps; r++) {
         HIP_TRY(hipEventRecord(ev[0], c->st));
         HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
-        HIP_TRY(plm_launch_expand(d, c->x, c->jexp, c->Bt, c->st));
+        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
         HIP_TRY(hipEventRecord(ev[1], c->st));
         HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
         HIP_TRY(hipEventRecord(ev[2], c->st));
         HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
         HIP_TRY(hipEventRecord(ev[3], c->st));
-        HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j, c->reg_part,
-                                    0, 0.f, c->st));
+        HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
+                                    c->reg_part, 0, 0.f, c->st));
         HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d),
                                      c->scal, c->st));
         HIP_TRY(hipEventRecord(ev[4], c->st));
@@ -1008,8 +1106,9 @@ int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_ou
     return PLM_OK;
 }
 
-int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,
-            void *iter_user, plm_exchange_cb exchange, void *exchange_user) {
+static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,
+                    void *iter_user, plm_exchange_cb exchange, void *exchange_user, plm_collective_cb collective,
+                    void *collective_user) {
     if (!problem || !result) return fail(PLM_EINVAL, "NULL problem / result");
     const double t0 = now_s();
     const int nshards = problem->n_shards > 0 ? problem->n_shards : 1;
@@ -1039,6 +1138,7 @@ int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void
         if (!rc) {
             c->h_fi = c1->h_fi;
             plm_ctx_set_exchange(c, exchange, exchange_user);
+            plm_ctx_set_collective(c, collective, collective_user);
         }
         plm_ctx_destroy(c1);
         c1 = nullptr;
@@ -1060,6 +1160,22 @@ int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void
     if (c) plm_ctx_destroy(c);
     result->seconds_total = now_s() - t0;
     return rc;
+}
+
+int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,
+            void *iter_user, plm_exchange_cb exchange, void *exchange_user) {
+    if (problem && (problem->flags & PLM_FLAG_SHARDED_STATE) && problem->n_shards > 1)
+        return fail(PLM_EINVAL, "PLM_FLAG_SHARDED_STATE needs plm_fit_sharded (collective callback)");
+    return fit_impl(problem, result, device, stream, iter_cb, iter_user, exchange, exchange_user, nullptr, nullptr);
+}
+
+int plm_fit_sharded(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
+                    plm_iter_cb iter_cb, void *iter_user, plm_collective_cb collective, void *collective_user) {
+    if (!problem || !result) return fail(PLM_EINVAL, "NULL problem / result");
+    if (problem->n_shards > 1 && !collective) return fail(PLM_EINVAL, "n_shards > 1 needs a collective callback");
+    plm_problem_t p = *problem;
+    p.flags |= PLM_FLAG_SHARDED_STATE;
+    return fit_impl(&p, result, device, stream, iter_cb, iter_user, nullptr, nullptr, collective, collective_user);
 }
 
 }  // extern "C"

@@ -48,6 +48,19 @@ struct PlmDims {
     int64_t n_native;  // nh_pad + nbp*Q*Q*256
     int64_t n_canon;   // L*Q + L(L-1)/2*Q*Q
     int gap_mode;      // 1: state 0 (gap) excluded from the model (plmc -g)
+    // ---- sharded-state mode (PLM_FLAG_SHARDED_STATE): parameters, gradient and L-BFGS vectors are
+    // split by owning site block; the "local" vector is [h of own sites | pairs (I own, J >= I)].
+    // In every other mode the local vector IS the native vector (own_lo = 0, own_hi = nb16).
+    int sharded;       // 1 in sharded-state mode
+    int own_lo, own_hi;   // blocks whose parameters live in the local vector
+    int nblk_own;      // own_hi - own_lo
+    int h_site0;       // first site of the local field part
+    int64_t bp_base;   // plm_bp_index(own_lo, own_lo): first own block pair
+    int64_t np_own;    // own block pairs
+    int64_t nh_pad_l;  // local field part, padded to 256 floats
+    int64_t n_local;   // nh_pad_l + np_own*Q*Q*256
+    int64_t nx_halo;   // coupling blocks received per evaluation: own_lo * nblk_own   (pairs (J'<own_lo, I own))
+    int64_t ng_halo;   // gradient blocks received per evaluation: nblk_own * (nb16 - own_hi)
 };
 
 static inline __host__ __device__ int64_t plm_bp_index(int I, int J, int nb16) { // I <= J
@@ -65,8 +78,8 @@ hipError_t plm_launch_onehot_rt(const PlmDims &d, const int8_t *msa_rm, const fl
                                 hipStream_t st);
 hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, uint32_t *maxbits, int32_t *jexp,
                              hipStream_t st);
-hipError_t plm_launch_expand(const PlmDims &d, const float *x, const int32_t *jexp, void *Bt,
-                             hipStream_t st);
+hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhalo, const int32_t *jexp,
+                             void *Bt, hipStream_t st);
 hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
                               const float *x, const int32_t *jexp, void *Rt, double *fx_part,
                               hipStream_t st);
@@ -74,9 +87,15 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
                                hipStream_t st);
 hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab, hipStream_t st);
 // g = 2^-R_EXP * (G + G^T) + 2 lambda x ; mode 1: marginals (out = G / neff, no symmetrisation)
-hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *x,
-                               float *g, float lambda_h, float lambda_j, double *reg_part,
+hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *ghalo,
+                               const float *x, float *g, float lambda_h, float lambda_j, double *reg_part,
                                int mode, float inv_neff, hipStream_t st);
+// sharded-state exchange staging: blocks of Q*Q*256 floats
+#define PLM_BLOCK_FLOATS(d) ((size_t)(d).Q * (d).Q * 256)
+hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, hipStream_t st);
+hipError_t plm_launch_pack_g(const PlmDims &d, const float *G, float *sendbuf, hipStream_t st);
+hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_t nb, uint32_t *maxbits,
+                              int32_t *jexp, hipStream_t st);
 hipError_t plm_launch_finish_fx(const PlmDims &d, const double *fx_part, int n_fx_part,
                                 const double *shard_nll, int n_shard_nll, const double *reg_part,
                                 int n_reg_part, double *out2 /* fx, nll */, hipStream_t st);

@@ -132,7 +132,7 @@ size_t plm_bt_bytes(const PlmDims &d) { return (size_t)d.blk_per_shard * d.nkste
 size_t plm_rt_bytes(const PlmDims &d) { return (size_t)d.nssteps * d.nnfl * 2 * 1024; }
 size_t plm_g_bytes(const PlmDims &d) { return (size_t)d.ksplit * d.nmf * d.nnfl * 1024; }
 size_t plm_slab_bytes(const PlmDims &d) { return (size_t)d.nmf * d.nnfl * 1024 + 256; }
-int plm_reg_parts(const PlmDims &d) { return (int)(d.nbp * d.Q) + 1; }
+int plm_reg_parts(const PlmDims &d) { return (int)(d.np_own * d.Q) + 1; }
 
 // =========================================================================================
 // K1  sequence reweighting (row a4; twin: align/alignment.py:1193-1233)
@@ -347,11 +347,20 @@ __global__ void k_scale_from_max(const u32 *maxbits, int32_t *jexp) {
     s = max(-100, min(100, s));
     *jexp = (mx > 0.f) ? s : 0;
 }
+hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_t nb, u32 *maxbits, int32_t *jexp,
+                              hipStream_t st) {
+    hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(u32), st);
+    if (e != hipSuccess) return e;
+    if (na > 0) hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, a, na, maxbits);
+    if (nb > 0) hipLaunchKernelGGL(k_maxabs, dim3(256), dim3(256), 0, st, b, nb, maxbits);
+    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp);
+    return hipGetLastError();
+}
 hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int32_t *jexp, hipStream_t st) {
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(u32), st);
     if (e != hipSuccess) return e;
-    const int64_t n = d.n_native - d.nh_pad;
-    hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, x + d.nh_pad, n, maxbits);
+    const int64_t n = d.n_local - d.nh_pad_l;
+    hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, x + d.nh_pad_l, n, maxbits);
     hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp);
     return hipGetLastError();
 }
@@ -361,22 +370,29 @@ hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int
 //   Bt[b16l][kstep=(u,b)][plane][a][lane=(kg,r)][e] = 2^jexp * J_{i,j}(a,b)
 //   i = 16*b16 + r (state a),  j = 32u + 8kg + perm8(e) (state b);  0 when i == j / padding
 // =========================================================================================
-__device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__restrict__ xj, int I, int ii,
-                                               int a, int J, int jj, int b) {
-    // coupling between (site 16I+ii, state a) and (site 16J+jj, state b)
+__device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__restrict__ xj,
+                                               const float *__restrict__ xhalo, int I, int ii, int a, int J, int jj,
+                                               int b) {
+    // coupling between (site 16I+ii, state a) and (site 16J+jj, state b); I is one of this shard's column
+    // blocks.  xj = coupling part of the LOCAL vector (own pairs, offset by bp_base); pairs (J, I) with
+    // J below the own range live in the halo received from their owner (sharded-state mode only).
     const int QQ = d.Q * d.Q;
-    if (I < J) return xj[(plm_bp_index(I, J, d.nb16) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
-    if (I > J) return xj[(plm_bp_index(J, I, d.nb16) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
-    if (ii < jj) return xj[(plm_bp_index(I, I, d.nb16) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
-    if (ii > jj) return xj[(plm_bp_index(I, I, d.nb16) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
+    if (I < J) return xj[((plm_bp_index(I, J, d.nb16) - d.bp_base) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
+    if (I > J) {
+        if (J >= d.own_lo) return xj[((plm_bp_index(J, I, d.nb16) - d.bp_base) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
+        return xhalo[(((size_t)J * d.nblk_own + (I - d.own_lo)) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
+    }
+    if (ii < jj) return xj[((plm_bp_index(I, I, d.nb16) - d.bp_base) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
+    if (ii > jj) return xj[((plm_bp_index(I, I, d.nb16) - d.bp_base) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
     return 0.f;
 }
 __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restrict__ x,
+                                               const float *__restrict__ xhalo,
                                                const int32_t *__restrict__ jexp, _Float16 *__restrict__ Bt) {
     const int kstep = blockIdx.x, b16l = blockIdx.y, b16 = d.b16_lo + b16l;
     const int u = kstep / d.Q, b = kstep % d.Q;
     const float sc = ldexpf(1.f, *jexp);
-    const float *__restrict__ xj = x + d.nh_pad;
+    const float *__restrict__ xj = x + d.nh_pad_l;
     _Float16 *tile = Bt + ((size_t)b16l * d.nksteps + kstep) * (size_t)(2 * d.Q * 512);
     for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
         const int a = idx >> 6, lane = idx & 63, kg = lane >> 4, r = lane & 15;
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
             const int jj = 8 * (kg & 1) + perm8(e);
             const int j = J * 16 + jj;
             float v = 0.f;
-            if (i < d.L && j < d.L && i != j) v = sc * load_coupling(d, xj, b16, r, a, J, jj, b);
+            if (i < d.L && j < d.L && i != j) v = sc * load_coupling(d, xj, xhalo, b16, r, a, J, jj, b);
             const _Float16 h = (_Float16)v;
             hi[e] = h;
             lo[e] = (_Float16)(v - (float)h);
@@ -397,9 +413,10 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
         *(half8 *)(tile + (size_t)(d.Q + a) * 512 + lane * 8) = lo;
     }
 }
-hipError_t plm_launch_expand(const PlmDims &d, const float *x, const int32_t *jexp, void *Bt, hipStream_t st) {
+hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhalo, const int32_t *jexp, void *Bt,
+                             hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_expand, dim3(d.nksteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, jexp,
+    hipLaunchKernelGGL(k_expand, dim3(d.nksteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
                        (_Float16 *)Bt);
     return hipGetLastError();
 }
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     const bool site_ok = i < d.L;
     float hv[Q];
 #pragma unroll
-    for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)i * Q + a] : 0.f;
+    for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
     float fxl = 0.f;
 #pragma unroll
     for (int m = 0; m < 2; m++) {
@@ -791,13 +808,14 @@ __device__ __forceinline__ size_t g_frag(const PlmDims &d, int ks_count, size_t 
     return (size_t)sh * slab_stride + ((size_t)mf * d.nnfl + nfl) * 256;
 }
 __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__restrict__ G, int ks_count,
-                                                 size_t slab_stride, const float *__restrict__ x,
+                                                 size_t slab_stride, const float *__restrict__ ghalo,
+                                                 const float *__restrict__ x,
                                                  float *__restrict__ gout, float lambda_j,
                                                  double *__restrict__ reg_part, int mode, float scale) {
     __shared__ double red[4];
     const int a = blockIdx.y;
-    // decode block pair
-    int I = 0;
+    // decode the own block pair number blockIdx.x (pairs are numbered I-major from (own_lo, own_lo))
+    int I = d.own_lo;
     int64_t rem = blockIdx.x;
     while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
     const int J = I + (int)rem;
@@ -807,7 +825,11 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__rest
     const int t1 = ((jj >> 2) * 16 + ii) * 4 + (jj & 3);   // element [row=jj][col=ii]
     const int t2 = ((ii >> 2) * 16 + jj) * 4 + (ii & 3);   // element [row=ii][col=jj]
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
-    const size_t xoff = d.nh_pad + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
+    const size_t xoff = d.nh_pad_l + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
+    // sharded-state: the transposed fragments of a pair whose J block belongs to a higher shard arrive
+    // already summed over split-K in ghalo[(J - own_hi) * nblk_own + (I - own_lo)][a][b][256]
+    const bool remote = d.sharded && J >= d.own_hi;
+    const size_t hoff = remote ? (((size_t)(J - d.own_hi) * d.nblk_own + (I - d.own_lo)) * d.Q + a) * d.Q * 256 + t2 : 0;
     double reg = 0;
     for (int b = 0; b < d.Q; b++) {
         const size_t o1 = g_frag(d, ks_count, slab_stride, I, a, J * d.Q + b) + t1;
@@ -815,9 +837,13 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__rest
         for (int k = 0; k < ks_count; k++) v += G[o1 + k * kstride];
         float out;
         if (mode == 0) {
-            const size_t o2 = g_frag(d, ks_count, slab_stride, J, b, I * d.Q + a) + t2;
             float v2 = 0.f;
-            for (int k = 0; k < ks_count; k++) v2 += G[o2 + k * kstride];
+            if (remote) {
+                v2 = ghalo[hoff + (size_t)b * 256];
+            } else {
+                const size_t o2 = g_frag(d, ks_count, slab_stride, J, b, I * d.Q + a) + t2;
+                for (int k = 0; k < ks_count; k++) v2 += G[o2 + k * kstride];
+            }
             const float xv = x[xoff + (size_t)b * 256];
             const bool live = valid && !(d.gap_mode && (a == 0 || b == 0));
             out = live ? fmaf(scale, v + v2, 2.f * lambda_j * xv) : 0.f;
@@ -840,10 +866,11 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
     __shared__ double red[4];
     double reg = 0;
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
-    for (int64_t idx = threadIdx.x; idx < d.nh_pad; idx += 256) {
+    const int site_end = min(d.L, d.own_hi * 16);      // local field part: sites [h_site0, site_end)
+    for (int64_t idx = threadIdx.x; idx < d.nh_pad_l; idx += 256) {
         float out = 0.f;
-        if (idx < (int64_t)d.L * d.Q) {
-            const int i = (int)(idx / d.Q), a = (int)(idx % d.Q);
+        if (idx < (int64_t)(site_end - d.h_site0) * d.Q) {
+            const int i = d.h_site0 + (int)(idx / d.Q), a = (int)(idx % d.Q);
             const size_t o = g_frag(d, ks_count, slab_stride, i >> 4, a, d.nb16 * d.Q) + (size_t)(i & 15) * 4;
             float v = 0.f;
             for (int k = 0; k < ks_count; k++) v += G[o + k * kstride];
@@ -861,16 +888,18 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
     }
     if (mode == 0) {
         const double t = block_reduce_sum(reg, red);
-        if (threadIdx.x == 0) reg_part[d.nbp * d.Q] = (double)lambda_h * t;
+        if (threadIdx.x == 0) reg_part[d.np_own * d.Q] = (double)lambda_h * t;
     }
 }
-hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *x, float *g,
-                               float lambda_h, float lambda_j, double *reg_part, int mode, float inv_neff,
+hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *ghalo, const float *x,
+                               float *g, float lambda_h, float lambda_j, double *reg_part, int mode, float inv_neff,
                                hipStream_t st) {
-    const size_t slab_stride = plm_slab_bytes(d) / 4;
+    // replicated multi-shard mode reads the gathered slabs (one per shard); otherwise G is this shard's own
+    const size_t slab_stride = d.sharded ? 0 : plm_slab_bytes(d) / 4;
     const float scale = ldexpf(1.f, -PLM_R_EXP) * (mode == 1 ? inv_neff : 1.f);
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.nbp, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride, x,
-                       g, lambda_j, reg_part, mode, scale);
+    if (d.np_own > 0)
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride,
+                           ghalo, x, g, lambda_j, reg_part, mode, scale);
     hipLaunchKernelGGL(k_assemble_h, dim3(1), dim3(256), 0, st, d, G, ks_count, slab_stride, x, g, lambda_h,
                        reg_part, mode, scale);
     return hipGetLastError();
@@ -1001,7 +1030,7 @@ hipError_t plm_launch_lincomb(float *out, float ca, const float *a, float cb, co
 __global__ __launch_bounds__(256) void k_canon_to_native(PlmDims d, const float *__restrict__ xc,
                                                         float *__restrict__ xn) {
     const int a = blockIdx.y;
-    int I = 0;
+    int I = d.own_lo;
     int64_t rem = blockIdx.x;
     while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
     const int J = I + (int)rem;
@@ -1010,28 +1039,34 @@ __global__ __launch_bounds__(256) void k_canon_to_native(PlmDims d, const float 
     const bool valid = i < d.L && j < d.L && i < j;
     const size_t QQ = (size_t)d.Q * d.Q;
     const size_t src = valid ? (size_t)d.L * d.Q + (size_t)plm_pair_index(i, j, d.L) * QQ + (size_t)a * d.Q : 0;
-    const size_t dst = d.nh_pad + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
+    const size_t dst = d.nh_pad_l + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
     for (int b = 0; b < d.Q; b++) xn[dst + (size_t)b * 256] = valid ? xc[src + b] : 0.f;
 }
 __global__ __launch_bounds__(256) void k_copy_h(PlmDims d, const float *__restrict__ src, float *__restrict__ dst,
                                                int to_native) {
-    const int64_t n = to_native ? d.nh_pad : (int64_t)d.L * d.Q;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        dst[i] = (i < (int64_t)d.L * d.Q) ? src[i] : 0.f;
+    // canonical fields [L][Q] <-> local field part (sites h_site0 .. min(L, 16*own_hi))
+    const int64_t nloc = (int64_t)(min(d.L, d.own_hi * 16) - d.h_site0) * d.Q, off = (int64_t)d.h_site0 * d.Q;
+    const int64_t n = to_native ? d.nh_pad_l : nloc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (to_native) dst[i] = (i < nloc) ? src[off + i] : 0.f;
+        else dst[off + i] = src[i];
+    }
 }
 __global__ __launch_bounds__(64) void k_native_to_canon(PlmDims d, const float *__restrict__ xn,
                                                        float *__restrict__ xc) {
     const int i = blockIdx.x, j = blockIdx.y;
     if (j <= i) return;
     const int I = i >> 4, J = j >> 4;
+    if (I < d.own_lo || I >= d.own_hi) return;          // not an own pair: left untouched (sharded-state)
     const int QQ = d.Q * d.Q;
-    const size_t src = d.nh_pad + (size_t)plm_bp_index(I, J, d.nb16) * QQ * 256 + (i & 15) * 16 + (j & 15);
+    const size_t src = d.nh_pad_l + (size_t)(plm_bp_index(I, J, d.nb16) - d.bp_base) * QQ * 256 + (i & 15) * 16 + (j & 15);
     const size_t dst = (size_t)d.L * d.Q + (size_t)plm_pair_index(i, j, d.L) * QQ;
     for (int ab = threadIdx.x; ab < QQ; ab += 64) xc[dst + ab] = xn[src + (size_t)ab * 256];
 }
 hipError_t plm_launch_canon_to_native(const PlmDims &d, const float *xc, float *xn, hipStream_t st) {
     hipLaunchKernelGGL(k_copy_h, dim3(64), dim3(256), 0, st, d, xc, xn, 1);
-    hipLaunchKernelGGL(k_canon_to_native, dim3((unsigned)d.nbp, d.Q), dim3(256), 0, st, d, xc, xn);
+    if (d.np_own > 0)
+        hipLaunchKernelGGL(k_canon_to_native, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, xc, xn);
     return hipGetLastError();
 }
 hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *xc, hipStream_t st) {
@@ -1082,6 +1117,54 @@ __global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict
 }
 hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, hipStream_t st) {
     hipLaunchKernelGGL(k_fn, dim3(d.L, d.L), dim3(64), 0, st, d.L, d.Q, jij_canon, fn);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// sharded-state exchange staging.  A "block" is the Q*Q*256 floats of one 16x16-site block pair.
+//   x halo : owner of J' (lower shard) -> owner of I (higher shard), pairs (J', I); receiver layout
+//            xhalo[J' * nblk_own + (I - own_lo)]
+//   g halo : owner of column block J (higher shard) -> owner of I (lower shard): the fragments
+//            G[(I,a),(J,b)] summed over split-K; receiver layout ghalo[(J - own_hi) * nblk_own + (I - own_lo)]
+// Messages are contiguous per destination, destinations in rank order (all_to_all_single).
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_pack_x(PlmDims d, const float4 *__restrict__ xj, float4 *__restrict__ out) {
+    const int nhigh = d.nb16 - d.own_hi;
+    const int jp = blockIdx.x / nhigh, I = d.own_hi + blockIdx.x % nhigh;      // pair (own_lo + jp, I)
+    const int rdst = I / d.blk_per_shard, lo_r = rdst * d.blk_per_shard;
+    const int n_r = min(d.nb16, lo_r + d.blk_per_shard) - lo_r;
+    const size_t blk4 = PLM_BLOCK_FLOATS(d) / 4;
+    const size_t dst = ((size_t)d.nblk_own * (lo_r - d.own_hi) + (size_t)jp * n_r + (I - lo_r)) * blk4;
+    const size_t src = (size_t)(plm_bp_index(d.own_lo + jp, I, d.nb16) - d.bp_base) * blk4;
+    for (size_t k = (size_t)blockIdx.y * 256 + threadIdx.x; k < blk4; k += (size_t)gridDim.y * 256)
+        out[dst + k] = xj[src + k];
+}
+hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, hipStream_t st) {
+    const int nhigh = d.nb16 - d.own_hi;
+    if (d.nblk_own <= 0 || nhigh <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_x, dim3(d.nblk_own * nhigh, 8), dim3(256), 0, st, d, (const float4 *)(x + d.nh_pad_l),
+                       (float4 *)sendbuf);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void k_pack_g(PlmDims d, const float *__restrict__ G, float *__restrict__ out) {
+    // one block per (own column block J, lower block I, state a); thread t = fragment element
+    const int a = blockIdx.y;
+    const int jl = blockIdx.x / d.own_lo, I = blockIdx.x % d.own_lo;            // J = own_lo + jl
+    const int rdst = I / d.blk_per_shard;                                        // lower shards are all full
+    const size_t blkf = PLM_BLOCK_FLOATS(d);
+    const size_t dst = ((size_t)rdst * d.blk_per_shard * d.nblk_own + (size_t)jl * d.blk_per_shard +
+                        (I - rdst * d.blk_per_shard)) * blkf + (size_t)a * d.Q * 256 + threadIdx.x;
+    const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
+    for (int b = 0; b < d.Q; b++) {
+        const size_t o = ((size_t)(I * d.Q + a) * d.nnfl + (size_t)jl * d.Q + b) * 256 + threadIdx.x;
+        float v = 0.f;
+        for (int k = 0; k < d.ksplit; k++) v += G[o + k * kstride];
+        out[dst + (size_t)b * 256] = v;
+    }
+}
+hipError_t plm_launch_pack_g(const PlmDims &d, const float *G, float *sendbuf, hipStream_t st) {
+    if (d.nblk_own <= 0 || d.own_lo <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_g, dim3(d.nblk_own * d.own_lo, d.Q), dim3(256), 0, st, d, G, sendbuf);
     return hipGetLastError();
 }
 

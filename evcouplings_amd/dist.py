@@ -81,15 +81,62 @@ def make_torch_exchange(group=None):
     return exchange
 
 
-def fit_distributed(msa, q=21, group=None, **kwargs):
-    """plm.fit on every rank of an initialised process group, sites sharded across ranks."""
+def collective_on_tensors(op, send, recv, send_counts, recv_counts, group=None):
+    """
+    The three collectives of the sharded-state mode on torch tensors (CPU/gloo or GPU/nccl):
+    send/recv are 1-D uint8 tensors; counts are bytes per rank.
+    """
+    import torch
+    import torch.distributed as dist
+    from evcouplings_amd import _lib
+    if op == _lib.COLL_ALLTOALL:
+        dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
+                               group=group)
+    elif op in (_lib.COLL_ALLREDUCE_F64, _lib.COLL_ALLREDUCE_F32):
+        dtype = torch.float64 if op == _lib.COLL_ALLREDUCE_F64 else torch.float32
+        dist.all_reduce(send.view(dtype), op=dist.ReduceOp.SUM, group=group)
+    else:
+        raise ValueError("unknown collective op %r" % (op,))
+
+
+def make_torch_collective(group=None):
+    """Collective callback for plm.fit(..., collective=...): RCCL on the library's device buffers."""
+    import torch
+    from evcouplings_amd import _lib
+
+    def collective(op, send_ptr, recv_ptr, send_counts, recv_counts, n_shards, shard):
+        if op == _lib.COLL_ALLTOALL:
+            send = torch.as_tensor(_DeviceBytes(send_ptr, max(1, sum(send_counts))), device="cuda")[:sum(send_counts)]
+            recv = torch.as_tensor(_DeviceBytes(recv_ptr, max(1, sum(recv_counts))), device="cuda")[:sum(recv_counts)]
+        else:
+            send = torch.as_tensor(_DeviceBytes(send_ptr, send_counts[0]), device="cuda")
+            recv = None
+        collective_on_tensors(op, send, recv, send_counts, recv_counts, group=group)
+        torch.cuda.current_stream().synchronize()
+        return 0
+
+    return collective
+
+
+def fit_distributed(msa, q=21, group=None, sharded_state=True, **kwargs):
+    """
+    plm.fit on every rank of an initialised process group, sites sharded across ranks.
+    sharded_state=True (default): parameters, gradient and L-BFGS state are split by owning site block;
+    per evaluation two all-to-alls of neighbour blocks + scalar all-reduces.  False: replicated state,
+    one all-gather of the gradient slabs per evaluation.
+    """
     import torch
     import torch.distributed as dist
     from evcouplings_amd import plm
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     device = kwargs.pop("device", torch.cuda.current_device())
-    return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device,
-                   exchange=make_torch_exchange(group) if world > 1 else None, **kwargs)
+    if world == 1:
+        return plm.fit(msa, q=q, device=device, **kwargs)
+    if sharded_state:
+        return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device,
+                       collective=make_torch_collective(group), **kwargs)
+    return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device, exchange=make_torch_exchange(group),
+                   **kwargs)
 
 
 # --------------------------------------------------------------------------------------------
@@ -143,3 +190,100 @@ class LoopbackShards:
             else:
                 assert fx == out[0] and np.array_equal(g, out[2]), "shards disagree"
         return out
+
+
+class ThreadedShards:
+    """
+    Sharded-state mode with every shard on the SAME GPU, one Python thread per shard, collectives
+    emulated through host memory and barriers (gpurun offers one GPU).  The C library code that runs is
+    exactly what runs under torch.distributed; only the transport differs.
+    """
+
+    def __init__(self, n_shards, device=0):
+        import threading
+        from evcouplings_amd import _lib
+        self._lib = _lib
+        self.n = n_shards
+        self.device = device
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipSetDevice.argtypes = [C.c_int]
+        self.barrier = threading.Barrier(n_shards)
+        self.slots = [None] * n_shards
+        self.n_calls = {"alltoall": 0, "allreduce": 0}
+
+    def _d2h(self, ptr, nbytes):
+        host = np.empty(max(1, nbytes), np.uint8)
+        if nbytes:
+            assert self.hip.hipMemcpy(host.ctypes.data, C.c_void_p(ptr), nbytes, 2) == 0
+        return host[:nbytes]
+
+    def _h2d(self, ptr, host):
+        if host.size:
+            host = np.ascontiguousarray(host)
+            assert self.hip.hipMemcpy(C.c_void_p(ptr), host.ctypes.data, host.size, 1) == 0
+
+    def collective_for(self, shard):
+        lib = self._lib
+
+        def collective(op, send_ptr, recv_ptr, send_counts, recv_counts, n_shards, me):
+            assert me == shard and n_shards == self.n
+            self.hip.hipSetDevice(self.device)
+            if op == lib.COLL_ALLTOALL:
+                self.slots[me] = (self._d2h(send_ptr, sum(send_counts)), list(send_counts))
+                self.barrier.wait()
+                parts = []
+                for r in range(self.n):
+                    buf, cnt = self.slots[r]
+                    off = sum(cnt[:me])
+                    assert cnt[me] == recv_counts[r], "all-to-all split mismatch %d -> %d" % (r, me)
+                    parts.append(buf[off:off + cnt[me]])
+                self._h2d(recv_ptr, np.concatenate(parts) if parts else np.empty(0, np.uint8))
+                if me == 0:
+                    self.n_calls["alltoall"] += 1
+            else:
+                dtype = np.float64 if op == lib.COLL_ALLREDUCE_F64 else np.float32
+                self.slots[me] = self._d2h(send_ptr, send_counts[0]).view(dtype)
+                self.barrier.wait()
+                total = self.slots[0].copy()
+                for r in range(1, self.n):
+                    total += self.slots[r]
+                self._h2d(send_ptr, total.view(np.uint8))
+                if me == 0:
+                    self.n_calls["allreduce"] += 1
+            self.barrier.wait()   # everyone has read the slots before the next collective overwrites them
+            return 0
+
+        return collective
+
+    def run(self, fn):
+        """fn(shard, collective) is called in one thread per shard; returns the list of results."""
+        import threading
+        out, err = [None] * self.n, [None] * self.n
+
+        def work(r):
+            try:
+                out[r] = fn(r, self.collective_for(r))
+            except BaseException as exc:   # noqa: BLE001 - reported below, and the barrier is broken for the others
+                err[r] = exc
+                self.barrier.abort()
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(self.n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        real = [e for e in err if e is not None]
+        if real:
+            # prefer the first non-barrier error
+            import threading as _t
+            for e in real:
+                if not isinstance(e, _t.BrokenBarrierError):
+                    raise e
+            raise real[0]
+        return out
+
+    def fit(self, msa, q=21, **kwargs):
+        from evcouplings_amd import plm
+        return self.run(lambda r, coll: plm.fit(msa, q=q, n_shards=self.n, shard=r, device=self.device,
+                                                collective=coll, **kwargs))

@@ -86,6 +86,21 @@ def scores(jij, L, q):
 
 
 FLAG_IGNORE_GAPS = 2
+FLAG_SHARDED_STATE = 4
+
+
+def _wrap_collective(collective):
+    """python callable(op, send_ptr, recv_ptr, send_counts, recv_counts, n_shards, shard) -> 0  =>  C callback"""
+    def _cb(op, send, recv, scounts, rcounts, n, shard, user):
+        try:
+            return int(collective(int(op), send, recv, [int(scounts[k]) for k in range(n)],
+                                  [int(rcounts[k]) for k in range(n)] if op == _lib.COLL_ALLTOALL else None,
+                                  int(n), int(shard)))
+        except Exception as exc:   # never let an exception cross the C boundary
+            import sys
+            print("plm collective failed: %r" % (exc,), file=sys.stderr)
+            return 1
+    return _lib.COLLECTIVE_CB(_cb)
 
 
 def _embed_gaps(x, L, q):
@@ -109,7 +124,7 @@ def _strip_gaps(x, L, q):
 
 
 def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, n_shards, shard,
-             ignore_gaps=False):
+             ignore_gaps=False, sharded_state=False):
     N, L = msa.shape
     p = PlmProblem()
     p.n_seqs, p.n_sites, p.n_states = N, L, q
@@ -117,19 +132,22 @@ def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbf
     p.theta_id, p.scale = float(theta_id), float(scale)
     p.lambda_h, p.lambda_j = float(lambda_h), float(lambda_j)
     p.max_iter, p.epsilon, p.lbfgs_m = int(max_iter), float(epsilon), int(lbfgs_m)
-    p.n_shards, p.shard, p.flags = int(n_shards), int(shard), FLAG_IGNORE_GAPS if ignore_gaps else 0
+    p.n_shards, p.shard = int(n_shards), int(shard)
+    p.flags = (FLAG_IGNORE_GAPS if ignore_gaps else 0) | (FLAG_SHARDED_STATE if sharded_state else 0)
     return p
 
 
 def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
         epsilon=1e-3, lbfgs_m=6, device=0, stream=0, callback=None, n_shards=1, shard=0,
-        exchange=None, want_fij=True, ignore_gaps=False):
+        exchange=None, want_fij=True, ignore_gaps=False, collective=None):
     """
     Whole couplings inference: reweight -> marginals -> L-BFGS -> scores.
 
     callback(iter, secs, cond, fx, nll, norm_h, norm_e) is called once per iteration.
     exchange(dev_ptr, bytes_per_shard, n_shards, shard) -> 0 implements the all-gather of
-    the site-sharded gradient slabs (see evcouplings_amd.dist) and is required iff n_shards > 1.
+    the site-sharded gradient slabs (see evcouplings_amd.dist) and is required iff n_shards > 1
+    in the replicated mode; pass `collective` instead to run the sharded-state mode
+    (parameters, gradient and optimiser state split across the shards, see evcouplings_amd.dist).
     ignore_gaps=True is plmc -g (tools.py:222-224): state 0 is excluded from the model and every
     returned array has q-1 states (fi, hi: (L, q-1); fij, jij: (pairs, q-1, q-1)).
     Returns a dict of numpy arrays and scalars.
@@ -161,9 +179,14 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     else:
         xcb = C.cast(None, _lib.EXCHANGE_CB)
     prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
-                    n_shards, shard, ignore_gaps)
-    check(lib.plm_fit(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
-                      None, xcb, None))
+                    n_shards, shard, ignore_gaps, sharded_state=collective is not None)
+    if collective is not None:
+        ccb = _wrap_collective(collective)
+        check(lib.plm_fit_sharded(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
+                                  None, ccb, None))
+    else:
+        check(lib.plm_fit(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
+                          None, xcb, None))
     if ignore_gaps:   # drop the (all-zero) entries of state 0
         out["fi"], out["hi"] = out["fi"][:, 1:].copy(), out["hi"][:, 1:].copy()
         out["jij"] = out["jij"][:, 1:, 1:].copy()
@@ -183,7 +206,7 @@ class PlmContext:
 
     def __init__(self, msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None,
                  max_iter=100, epsilon=1e-3, lbfgs_m=6, device=0, stream=0, n_shards=1, shard=0,
-                 ignore_gaps=False):
+                 ignore_gaps=False, sharded_state=False):
         self.lib = _lib.load()
         msa = _msa(msa)
         self.N, self.L = msa.shape
@@ -192,7 +215,7 @@ class PlmContext:
         self.qm = q - 1 if ignore_gaps else q      # model states (layout of x, g, fi, fij at this API)
         self.lambda_j = default_lambda_j(self.L, self.qm) if lambda_j is None else lambda_j
         prob = _problem(msa, q, theta_id, scale, lambda_h, self.lambda_j, max_iter, epsilon, lbfgs_m,
-                        n_shards, shard, ignore_gaps)
+                        n_shards, shard, ignore_gaps, sharded_state)
         self._h = C.c_void_p()
         check(self.lib.plm_ctx_create(C.byref(prob), int(device), C.c_void_p(int(stream) or None),
                                       C.byref(self._h)))
@@ -215,6 +238,11 @@ class PlmContext:
         cb = _lib.EXCHANGE_CB(lambda buf, nbytes, ns, sh, user: int(exchange(buf, nbytes, ns, sh)))
         self._keep.append(cb)
         check(self.lib.plm_ctx_set_exchange(self._h, cb, None))
+
+    def set_collective(self, collective):
+        cb = _wrap_collective(collective)
+        self._keep.append(cb)
+        check(self.lib.plm_ctx_set_collective(self._h, cb, None))
 
     def set_options(self, max_iter=-1, epsilon=-1.0, lbfgs_m=-1):
         check(self.lib.plm_ctx_set_options(self._h, int(max_iter), float(epsilon), int(lbfgs_m)))

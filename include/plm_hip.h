@@ -69,6 +69,10 @@ typedef struct {
  * sequences.  All arrays keep the q-state layout of the alphabet; every entry that involves state 0
  * is zero (the Python host drops them and writes a (q-1)-state model file).  DESIGN.md section 2b. */
 #define PLM_FLAG_IGNORE_GAPS 2
+/* n_shards > 1 only: parameters, gradient and L-BFGS state are sharded by owning site block instead
+ * of replicated.  Needs a plm_collective_cb; per evaluation two all-to-alls of
+ * neighbour blocks and one scalar all-reduce replace the all-gather of whole gradient slabs. */
+#define PLM_FLAG_SHARDED_STATE 4
 
 /* Per-iteration progress: the 7 columns of plmc's stderr table that
  * parse_plmc_log() collects (tools.py:59-83): iter time cond fx -loglk ||h|| ||e||. */
@@ -82,6 +86,19 @@ typedef void (*plm_iter_cb)(int32_t iter, double secs, double cond, double fx, d
  * context's stream after a stream synchronise; return 0 on success. */
 typedef int (*plm_exchange_cb)(void *dev_buf, size_t bytes_per_shard, int32_t n_shards,
                                int32_t shard, void *user);
+
+/* Collectives of the sharded-state mode, implemented by the host with torch.distributed (RCCL).
+ * All buffers are device pointers of this library; counts are BYTES per rank (arrays of n_shards).
+ *   PLM_COLL_ALLTOALL      send -> recv with per-rank byte counts, messages in rank order
+ *   PLM_COLL_ALLREDUCE_F64 in-place sum over ranks of send_counts[0] bytes of doubles at `send`
+ *   PLM_COLL_ALLREDUCE_F32 in-place sum over ranks of send_counts[0] bytes of floats at `send`
+ * Called after the context's stream has been synchronised; must return 0 on success with the result
+ * visible to later work on that stream. */
+#define PLM_COLL_ALLTOALL 1
+#define PLM_COLL_ALLREDUCE_F64 2
+#define PLM_COLL_ALLREDUCE_F32 3
+typedef int (*plm_collective_cb)(int32_t op, void *send, void *recv, const int64_t *send_counts,
+                                 const int64_t *recv_counts, int32_t n_shards, int32_t shard, void *user);
 
 typedef struct {
     float *weights;      /* [N]            or NULL */
@@ -114,6 +131,11 @@ const char *plm_last_error(void);      /* thread-local message of the last failu
 int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
             plm_iter_cb iter_cb, void *iter_user, plm_exchange_cb exchange, void *exchange_user);
 
+/* Same stage with problem->flags & PLM_FLAG_SHARDED_STATE: every rank calls it with its shard index;
+ * all ranks return the same full result arrays. */
+int plm_fit_sharded(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
+                    plm_iter_cb iter_cb, void *iter_user, plm_collective_cb collective, void *collective_user);
+
 /* -- fine-grained, host buffers (parity tests) ------------------------------------------- */
 /* plmc sequence reweighting; twin: align/alignment.py:1193-1233.  counts[s] = cluster size. */
 int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id,
@@ -134,6 +156,7 @@ int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_ou
 int plm_ctx_create(const plm_problem_t *problem, int device, void *stream, plm_ctx_t **out);
 void plm_ctx_destroy(plm_ctx_t *ctx);
 int plm_ctx_set_exchange(plm_ctx_t *ctx, plm_exchange_cb exchange, void *user);
+int plm_ctx_set_collective(plm_ctx_t *ctx, plm_collective_cb collective, void *user);
 /* change the stop rule / history of later plm_ctx_optimize calls (negative = keep) */
 int plm_ctx_set_options(plm_ctx_t *ctx, int32_t max_iter, double epsilon, int32_t lbfgs_m);
 /* number of floats of the solver's internal ("native", 16-site blocked) parameter vector */

@@ -68,3 +68,65 @@ def test_exchange_all_gather_gloo(world):
                              for r in range(world)])
     for r in range(world):
         np.testing.assert_array_equal(got[r], expect)     # every rank holds every shard's slab
+
+
+def _coll_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from evcouplings_amd import _lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # all-to-all with uneven splits: rank r sends (r + 1) * (d + 2) * 8 bytes to rank d
+        send_counts = [(rank + 1) * (d + 2) * 8 for d in range(world)]
+        recv_counts = [(r + 1) * (rank + 2) * 8 for r in range(world)]
+        send = torch.cat([torch.full((c,), 16 * rank + d, dtype=torch.uint8) for d, c in enumerate(send_counts)])
+        recv = torch.zeros(sum(recv_counts), dtype=torch.uint8)
+        pdist.collective_on_tensors(_lib.COLL_ALLTOALL, send, recv, send_counts, recv_counts)
+        expect = torch.cat([torch.full((c,), 16 * r + rank, dtype=torch.uint8) for r, c in enumerate(recv_counts)])
+        ok_a2a = bool((recv == expect).all())
+        v64 = torch.arange(5, dtype=torch.float64) * (rank + 1)
+        pdist.collective_on_tensors(_lib.COLL_ALLREDUCE_F64, v64.view(torch.uint8), None, [40], None)
+        v32 = torch.ones(7, dtype=torch.float32) * (rank + 1)
+        pdist.collective_on_tensors(_lib.COLL_ALLREDUCE_F32, v32.view(torch.uint8), None, [28], None)
+        q.put((rank, ok_a2a, v64.tolist(), v32.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_state_collectives_gloo(world):
+    """all_to_all_single with uneven byte splits and the f64 / f32 all-reduces of the sharded-state mode"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_coll_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tot = world * (world + 1) / 2
+    for rank, ok, v64, v32 in got:
+        assert ok, "all-to-all payload wrong on rank %d" % rank
+        assert v64 == [k * tot for k in range(5)] and v32 == [tot] * 7
+
+
+def test_sharded_state_exchange_volumes_are_consistent():
+    """what shard r sends to r' equals what r' expects from r (the byte counts the library derives)"""
+    for L, n in ((300, 8), (500, 8), (40, 4), (100, 3)):
+        blocks = pdist.shard_blocks(L, n)
+        own = [hi - lo for lo, hi in blocks]
+        for r in range(n):
+            for rp in range(n):
+                x_send = own[r] * own[rp] if rp > r else 0          # couplings go to higher shards
+                x_recv_at_rp = own[rp] * own[r] if r < rp else 0
+                assert x_send == x_recv_at_rp
+        # every cross-shard block pair is exchanged exactly once in each direction
+        nb = (L + 15) // 16
+        cross = nb * (nb + 1) // 2 - sum(k * (k + 1) // 2 + k * sum(own[i + 1:]) - k * sum(own[i + 1:])
+                                         for i, k in enumerate(own))
+        assert cross == sum(own[r] * own[rp] for r in range(n) for rp in range(r + 1, n))

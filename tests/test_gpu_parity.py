@@ -291,6 +291,16 @@ def test_torch_exchange_zero_copy_and_nccl_single_rank(plm):
         buf.copy_(keep)
         assert pdist.make_torch_exchange()(buf.data_ptr(), buf.numel(), 1, 0) == 0
         assert bool((buf == keep).all())
+        # the sharded-state collectives through RCCL (world size 1: all-to-all = copy, all-reduce = identity)
+        from evcouplings_amd import _lib
+        coll = pdist.make_torch_collective()
+        src = torch.arange(1024, dtype=torch.int64, device="cuda").to(torch.uint8)
+        dst = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+        assert coll(_lib.COLL_ALLTOALL, src.data_ptr(), dst.data_ptr(), [1024], [1024], 1, 0) == 0
+        assert bool((dst == src).all())
+        v = torch.arange(8, dtype=torch.float64, device="cuda")
+        assert coll(_lib.COLL_ALLREDUCE_F64, v.data_ptr(), v.data_ptr(), [64], None, 1, 0) == 0
+        assert v.tolist() == list(range(8))
         msa, _ = synthetic_msa(300, 20, seed=3)
         a = pdist.fit_distributed(msa, q=Q, max_iter=10, epsilon=1e-12)
         b = plm.fit(msa, Q, max_iter=10, epsilon=1e-12)
@@ -403,3 +413,53 @@ def test_field_objective_scaling_matches_reference_independent_model(plm, golden
     logZ = np.log(np.exp(z["h_ref"]).sum(axis=1))
     ref_val = (w.sum() * (logZ - (c["fi"] * z["h_ref"]).sum(axis=1)) + 0.01 * (z["h_ref"] ** 2).sum(axis=1)).sum()
     assert fx == pytest.approx(ref_val, rel=2e-6)
+
+
+# ---------------------------------------------------------------- sharded-state multi-GPU mode on one GPU
+@pytest.mark.parametrize("L,n_shards", [(40, 2), (40, 3), (40, 4), (100, 2), (100, 3), (100, 4)])
+def test_sharded_state_evaluation_matches_single_gpu(plm, oracle64, L, n_shards):
+    """every shard in its own thread on the same GPU, collectives through host memory (dist.ThreadedShards):
+    objective and gradient must equal the single-GPU evaluation (L=40 with 4 shards leaves one shard empty)"""
+    from evcouplings_amd.dist import ThreadedShards
+    N = 400
+    msa, _ = synthetic_msa(N, L, seed=L + n_shards)
+    w = (1.0 / oracle64.reweight(msa, 0.8)).astype(np.float32)
+    x = (0.1 * np.random.default_rng(7).normal(size=plm.n_params(L, Q))).astype(np.float32)
+    fx1, nll1, g1 = plm.evaluate(msa, w, Q, 0.01, 4.2, x)
+
+    def work(r, coll):
+        with plm.PlmContext(msa, q=Q, lambda_h=0.01, lambda_j=4.2, n_shards=n_shards, shard=r,
+                            sharded_state=True) as ctx:
+            ctx.set_collective(coll)
+            ctx.set_weights(w)
+            ctx.set_x(x)
+            fx, nll = ctx.eval()
+            return fx, nll, ctx.get_g(), ctx.get_x(), ctx.native_size()
+
+    ts = ThreadedShards(n_shards)
+    outs = ts.run(work)
+    sizes = [o[4] for o in outs]
+    with plm.PlmContext(msa, q=Q) as single:
+        assert sum(sizes) <= single.native_size() + 256 * n_shards and max(sizes) < single.native_size()   # state is split
+    for fx, nll, g, xb, _ in outs:
+        assert fx == pytest.approx(fx1, rel=1e-6) and nll == pytest.approx(nll1, rel=1e-6)
+        np.testing.assert_array_equal(xb, x)                                          # scatter + gather round trip
+        np.testing.assert_allclose(g, g1, atol=1e-5 * np.abs(g1).max(), rtol=1e-5)
+    assert ts.n_calls["alltoall"] == 2                                               # per evaluation
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_sharded_state_fit_matches_single_gpu(plm, n_shards):
+    from evcouplings_amd.dist import ThreadedShards
+    msa, _ = synthetic_msa(500, 56, seed=19)
+    ref = plm.fit(msa, Q, max_iter=60, epsilon=1e-12)
+    outs = ThreadedShards(n_shards).fit(msa, q=Q, max_iter=60, epsilon=1e-12)
+    for o in outs:
+        assert o["iters"] == 60 and o["n_eff"] == pytest.approx(ref["n_eff"])
+        np.testing.assert_array_equal(o["cn"], outs[0]["cn"])          # every rank returns the same result
+        np.testing.assert_allclose(o["fx"], ref["fx"], rtol=1e-6)
+        np.testing.assert_allclose(o["cn"], ref["cn"], atol=2e-4)      # 60 iterations, summation order differs
+    # and to convergence the two agree tightly
+    ref = plm.fit(msa, Q, max_iter=3000, epsilon=2e-6)
+    outs = ThreadedShards(n_shards).fit(msa, q=Q, max_iter=3000, epsilon=2e-6)
+    np.testing.assert_allclose(outs[0]["cn"], ref["cn"], atol=1e-5)
