@@ -2,12 +2,17 @@
 Site-sharded inference across the GPUs of one node.
 
 One process per GPU.  Shard r owns a contiguous range of 16-site column blocks; its forward
-and backward GEMMs need no communication.  The single exchange step per evaluation is an
-all-gather of the asymmetric gradient slabs (each slab carries its shard's partial -log
-pseudo-likelihood in its tail), done here with torch.distributed -- backend "nccl" is RCCL
-over xGMI on ROCm -- on the device buffer the C library hands to the callback.  After it,
-every rank assembles the same full gradient and takes the same L-BFGS step, so the
-optimiser state stays replicated and bit-identical without further traffic.
+and backward GEMMs need no communication.  Collectives are issued by the C library through
+callbacks implemented here with torch.distributed -- backend "nccl" is RCCL over xGMI on
+ROCm -- directly on the library's device buffers.
+
+Sharded-state mode (default, `make_torch_collective`): parameters, gradient and L-BFGS state
+are split by owning site block; per evaluation two all-to-alls of neighbour blocks (couplings
+towards higher shards, gradient fragments towards lower ones) and one scalar all-reduce, plus
+one scalar all-reduce per iteration for the L-BFGS Gram matrix.
+Replicated mode (`make_torch_exchange`): one all-gather of the gradient slabs per evaluation,
+every rank repeats the same L-BFGS step on the full vectors.
+`ThreadedShards` / `LoopbackShards` run either mode with all shards on ONE GPU for tests.
 
 The reference has nothing to compare with here: plmc parallelises with OpenMP threads
 only (evcouplings/couplings/tools.py:257-259, the `cpu` option).

@@ -707,49 +707,51 @@ int PLMO_NAME(fit2)(const int8_t *msa, int N, int L, int q, double theta_id, dou
     int32_t *counts = malloc(sizeof(int32_t) * N);
     real *w = weights ? weights : malloc(sizeof(real) * N);
     real *fi_l = fi ? fi : malloc(sizeof(real) * nh);
-    if (!counts || !w || !fi_l) return PLMO_ENOMEM;
-    int rc = gaps ? PLMO_NAME(reweight_gaps)(msa, N, L, theta_id, counts)
-                  : PLMO_NAME(reweight)(msa, N, L, theta_id, counts);
-    if (rc) return rc;
-    double neff = 0;
-    for (int s = 0; s < N; s++) {
-        w[s] = (real)(scale / counts[s]);
-        neff += w[s];
-    }
-    if (neff_out) *neff_out = neff;
-    rc = gaps ? PLMO_NAME(marginals_gaps)(msa, w, N, L, q, fi_l, fij) : PLMO_NAME(marginals)(msa, w, N, L, q, fi_l, fij);
-    if (rc) return rc;
-    /* start point: h_i(a) = log(f_i(a) + 1/N_eff) minus its site mean, J = 0 */
-    memset(x_out, 0, sizeof(real) * n);
-    for (int i = 0; i < L; i++) {
-        double mean = 0;
-        for (int a = 0; a < qm; a++) {
-            const double v = log((double)fi_l[(size_t)i * qm + a] + 1.0 / neff);
-            x_out[(size_t)i * qm + a] = (real)v;
-            mean += v;
-        }
-        mean /= qm;
-        for (int a = 0; a < qm; a++) x_out[(size_t)i * qm + a] -= (real)mean;
-    }
+    int rc = (!counts || !w || !fi_l) ? PLMO_ENOMEM : PLMO_OK;
+    int iters = 0, status = 0;
+    double fx = 0, neff = 0;
     evalctx_t c = {msa, w, N, L, q, lambda_h, lambda_j, 0, gaps};
-    lbfgs_opt_t o = {max_iter, epsilon, lbfgs_m > 0 ? lbfgs_m : 6, 20, 1e-4, 0.9, 1e-16, 1e-20, 1e20,
-                     sizeof(real) == 4 ? 1e-6 : 1e-13};
-    int status = 0;
-    double fx = 0;
-    const int iters = lbfgs_run(&c, n, x_out, &o, cb, user, &fx, &status);
-    if (iters < 0) return iters;
-    if (iters_out) *iters_out = iters;
-    if (status_out) *status_out = status;
-    if (nevals_out) *nevals_out = c.nevals;
-    if (fx_out) *fx_out = fx;
-    if (fn && cn) {
-        rc = PLMO_NAME(scores)(x_out + nh, L, qm, fn, cn);
-        if (rc) return rc;
+    if (!rc)
+        rc = gaps ? PLMO_NAME(reweight_gaps)(msa, N, L, theta_id, counts)
+                  : PLMO_NAME(reweight)(msa, N, L, theta_id, counts);
+    if (!rc) {
+        for (int s = 0; s < N; s++) {
+            w[s] = (real)(scale / counts[s]);
+            neff += w[s];
+        }
+        if (neff_out) *neff_out = neff;
+        rc = gaps ? PLMO_NAME(marginals_gaps)(msa, w, N, L, q, fi_l, fij)
+                  : PLMO_NAME(marginals)(msa, w, N, L, q, fi_l, fij);
+    }
+    if (!rc) {
+        /* start point: h_i(a) = log(f_i(a) + 1/N_eff) minus its site mean, J = 0 */
+        memset(x_out, 0, sizeof(real) * n);
+        for (int i = 0; i < L; i++) {
+            double mean = 0;
+            for (int a = 0; a < qm; a++) {
+                const double v = log((double)fi_l[(size_t)i * qm + a] + 1.0 / neff);
+                x_out[(size_t)i * qm + a] = (real)v;
+                mean += v;
+            }
+            mean /= qm;
+            for (int a = 0; a < qm; a++) x_out[(size_t)i * qm + a] -= (real)mean;
+        }
+        lbfgs_opt_t o = {max_iter, epsilon, lbfgs_m > 0 ? lbfgs_m : 6, 20, 1e-4, 0.9, 1e-16, 1e-20, 1e20,
+                         sizeof(real) == 4 ? 1e-6 : 1e-13};
+        iters = lbfgs_run(&c, n, x_out, &o, cb, user, &fx, &status);
+        if (iters < 0) rc = iters;
+    }
+    if (!rc) {
+        if (iters_out) *iters_out = iters;
+        if (status_out) *status_out = status;
+        if (nevals_out) *nevals_out = c.nevals;
+        if (fx_out) *fx_out = fx;
+        if (fn && cn) rc = PLMO_NAME(scores)(x_out + nh, L, qm, fn, cn);
     }
     free(counts);
     if (!weights) free(w);
     if (!fi) free(fi_l);
-    return PLMO_OK;
+    return rc;
 }
 
 int PLMO_NAME(fit)(const int8_t *msa, int N, int L, int q, double theta_id, double scale,
