@@ -2,7 +2,7 @@
 """GPU-side: margins of the CN parity tests (max |cn_hip - cn_oracle|) for several seeds."""
 import os, sys
 os.environ.setdefault("OMP_NUM_THREADS", "8")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa

@@ -3,7 +3,7 @@
 import os, sys, time, json
 os.environ.setdefault("OMP_NUM_THREADS", "16")
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa

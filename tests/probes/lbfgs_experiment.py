@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CPU experiment (oracle eval, python L-BFGS): effect of history m and a diagonal H0."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd.synthetic import synthetic_msa
 from oracle.oracle import Oracle
