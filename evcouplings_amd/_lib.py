@@ -104,6 +104,8 @@ def load():
             "(there is no CPU fallback for the PLM solver)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
+        if os.environ.get("PLM_HIP_LIB") and not hasattr(lib, name):
+            continue              # A/B experiments against an older build: tolerate newer symbols
         fn = getattr(lib, name)   # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args

@@ -27,6 +27,9 @@ typedef unsigned int u32;
 #ifndef PLM_ABLATE
 #define PLM_ABLATE 0
 #endif
+#ifndef PLM_SETPRIO
+#define PLM_SETPRIO 0      // 1: raise wave priority around the MFMA groups (A/B experiment)
+#endif
 #ifndef PLM_STAGE_GLDS
 #define PLM_STAGE_GLDS 1   // 1: global_load_lds (LDS-DMA) staging; 0: register staging (debug A/B)
 #endif
@@ -88,6 +91,11 @@ struct DmaPlan {
 // k_bwd 5.8 -> 9.7 ms): the serial issue of 7-11 LDS-DMA pieces by one wave outlasts the step.
 #ifndef PLM_DMA_WAVES
 #define PLM_DMA_WAVES 8
+#endif
+#if PLM_DMA_WAVES == 8
+#define PLM_IS_LOADER(wave) true
+#else
+#define PLM_IS_LOADER(wave) ((wave) < PLM_DMA_WAVES)
 #endif
 template <int PI> __device__ __forceinline__ void dma_issue(const DmaPlan &P) {
     const int p = P.first + PLM_DMA_WAVES * PI;
@@ -452,6 +460,9 @@ __device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, c
     }
     constexpr int newer = (A + 2 < Q) ? 4 : (A + 1 < Q) ? 2 : 0;
     lds_wait<newer>(bh[A % 3], bl[A % 3]);
+#if PLM_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #else
     if constexpr (A == 0) lds_wait<0>(bh[0], bl[0]);
     if constexpr (A == 0) lds_wait<0>(bh[1], bl[1]);
@@ -462,6 +473,9 @@ __device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, c
     dma_slot<(2 * Q + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, Q, A>(dma);
     acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[A % 3], acc[0][A], 0, 0, 0);
     acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[A % 3], acc[1][A], 0, 0, 0);
+#if PLM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 template <int Q, int... A>
 __device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb,
@@ -527,7 +541,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             __syncthreads();
 #endif
             const DmaPlan dma{bt + (size_t)ks_next * TILE + lane * 16, smem + ((t + 1) & 1) * TILE, wave,
-                              ((PLM_ABLATE & 2) == 0 && t + 1 < nsteps && wave < PLM_DMA_WAVES) ? 2 * Q : 0};
+                              ((PLM_ABLATE & 2) == 0 && t + 1 < nsteps && PLM_IS_LOADER(wave)) ? 2 * Q : 0};
             const char *lb = smem + (t & 1) * TILE + lane * 16;
             const u32 bb = (u32)b * 0x01010101u;
 #if !(PLM_ABLATE & 8)
@@ -656,11 +670,17 @@ __device__ __forceinline__ void bwd_col(f32x4 (&acc)[FM][FN], const half8 (&af)[
         bl[(C + 1) & 1] = lds_read_b128<(C + 1) * 2048 + 1024>(lb);
     }
     lds_wait<(C + 1 < FN) ? 2 : 0>(bh[C & 1], bl[C & 1]);
+#if PLM_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh[C & 1], acc[f][C], 0, 0, 0);
     dma_slot<(4 * FN + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, FN, C>(dma);
 #pragma unroll
     for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl[C & 1], acc[f][C], 0, 0, 0);
+#if PLM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 template <int FM, int FN, int... C>
 __device__ __forceinline__ void bwd_kstep(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb,
@@ -724,7 +744,7 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
         const int np_valid = min(4 * FN, 2 * (d.nnfl - nfl0));
         const DmaPlan dma{Rt + ((size_t)(ss + 1) * d.nnfl + nfl0) * 2048 + lane * 16,
                           smem + ((ss + 1 - k0) & 1) * TILE, wave,
-                          (ss + 1 < k1 && wave < PLM_DMA_WAVES) ? np_valid : 0};
+                          (ss + 1 < k1 && PLM_IS_LOADER(wave)) ? np_valid : 0};
         if (row_ok) {
             const char *lb = smem + ((ss - k0) & 1) * TILE + (wn * FN) * 2048 + lane * 16;
             half8 af[FM];
