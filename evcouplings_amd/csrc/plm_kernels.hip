@@ -30,8 +30,60 @@ typedef unsigned int u32;
 #ifndef PLM_SETPRIO
 #define PLM_SETPRIO 0      // 1: raise wave priority around the MFMA groups (A/B experiment)
 #endif
+// PLM_NBUF: LDS ring depth of the streamed tiles.  2 (default): double buffer, every piece of the next tile
+// issued right after the barrier.  3 (experiment, measured on MI355X: no gain -- k_fwd 5.30 vs 5.28 ms, k_bwd
+// 5.10 vs 5.18 ms -- and kept out of the product build): the tile of step t+2 is copied while step t computes,
+// its pieces spread over the step (PLM_DMA_SPREAD) and allowed to land during step t+1 (counted vmcnt waits).
+#ifndef PLM_NBUF
+#define PLM_NBUF 2
+#endif
+#ifndef PLM_DMA_SPREAD
+#define PLM_DMA_SPREAD (PLM_NBUF == 3)
+#endif
+typedef unsigned long long u64;
+// PLM_ASYNC_A: the alignment bytes of the next K step are fetched by a load the compiler does not track.
+// hipcc cannot count the LDS-DMA pieces issued under branches after an ordinary load, so it waits
+// vmcnt(0) where the loaded value is first used and schedules around that wait; the untracked load lands
+// under the kernel's own vmcnt(0) before the next barrier instead.  The destination is a loop-carried
+// variable updated IN PLACE ("+v": input and output share the register), so no copy of a not-yet-landed
+// value can be emitted; the consumer copies it out only after the wait (vm_landed).
+#ifndef PLM_ASYNC_A
+#define PLM_ASYNC_A 1
+#endif
+__device__ __forceinline__ void load_b64_inplace(u64 &v, const void *p) {
+#if PLM_ASYNC_A
+    asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(v) : "v"(p) : "memory");
+#else
+    v = *(const u64 *)p;
+#endif
+}
+__device__ __forceinline__ void vm_landed(u64 &v) { asm volatile("" : "+v"(v)); }
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `keep` (<= 3 used) of this wave's newest VMEM operations are outstanding
+__device__ __forceinline__ void vm_wait_keep(int keep) {
+    if (keep >= 3) vm_wait<3>();
+    else if (keep == 2) vm_wait<2>();
+    else if (keep == 1) vm_wait<1>();
+    else vm_wait<0>();
+}
 #ifndef PLM_STAGE_GLDS
 #define PLM_STAGE_GLDS 1   // 1: global_load_lds (LDS-DMA) staging; 0: register staging (debug A/B)
+#endif
+// PLM_PROBE=1 (debug build only): per-wave cycle totals of the K-loop phases of k_fwd / k_bwd, summed into
+// plm_probe_acc[kernel][phase]: 0 vmcnt wait, 1 barrier, 2 MFMA section, 3 whole kernel, 4 epilogue, 5 waves
+#ifndef PLM_PROBE
+#define PLM_PROBE 0
+#endif
+#if PLM_PROBE
+__device__ unsigned long long plm_probe_acc[2][8];
+#define PROBE_NOW() __builtin_readcyclecounter()
+extern "C" void plm_probe_read(unsigned long long *out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(plm_probe_acc), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(plm_probe_acc), z, sizeof z);
+    }
+}
 #endif
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
@@ -80,15 +132,16 @@ template <int N> __device__ __forceinline__ void lds_wait(half8 &a, half8 &b) {
 // of the MFMA pipe at the same time; instead piece PI is issued between the MFMA groups of an
 // early fragment of the step (first ~60 % so it has landed before the next barrier).
 struct DmaPlan {
-    const char *src;   // global address of this lane's 16 B of piece 0
+    const char *src;   // global address of piece 0 (wave-uniform: lives in SGPRs)
     char *dst;         // LDS base of the target buffer (wave-uniform)
-    int first;         // this wave's first piece; pieces first + PLM_DMA_WAVES*PI
+    int first;         // this wave's first piece (wave-uniform); pieces first + PLM_DMA_WAVES*PI
     int limit;         // number of pieces to copy (0 = nothing to stage)
+    u32 lane_off;      // lane * 16: the only per-lane part of the address
 };
 // Waves w and w+4 of a 512-thread workgroup share a SIMD.  PLM_DMA_WAVES = 8: every wave stages its
-// share of the tile right after the barrier.  PLM_DMA_WAVES = 4 (one loader wave per SIMD, the
-// partner computing meanwhile) was measured on MI355X and is much slower (k_fwd 5.3 -> 6.2 ms,
-// k_bwd 5.8 -> 9.7 ms): the serial issue of 7-11 LDS-DMA pieces by one wave outlasts the step.
+// share of the tile.  PLM_DMA_WAVES = 4 (one loader wave per SIMD, the partner computing meanwhile)
+// was measured on MI355X and is much slower (k_fwd 5.3 -> 6.2 ms, k_bwd 5.8 -> 9.7 ms): the serial
+// issue of 7-11 LDS-DMA pieces by one wave outlasts the step.
 #ifndef PLM_DMA_WAVES
 #define PLM_DMA_WAVES 8
 #endif
@@ -101,19 +154,20 @@ template <int PI> __device__ __forceinline__ void dma_issue(const DmaPlan &P) {
     const int p = P.first + PLM_DMA_WAVES * PI;
     if (p < P.limit) {
 #if PLM_STAGE_GLDS
-        __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024 + P.lane_off), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
 #else
-        *(float4 *)(P.dst + p * 1024 + (threadIdx.x & 63) * 16) = *(const float4 *)(P.src + p * 1024);
+        *(float4 *)(P.dst + p * 1024 + P.lane_off) = *(const float4 *)(P.src + p * 1024 + P.lane_off);
 #endif
     }
 }
 // issue every piece whose slot is fragment index A; NP pieces per wave, NF fragments per step
 template <int NP, int NF, int A, int PI = 0> __device__ __forceinline__ void dma_slot(const DmaPlan &P) {
     if constexpr (PI < NP) {
-        // measured on MI355X: spreading the pieces over the step (slot = PI * 0.6 NF / NP) made k_bwd
-        // 35 % slower -- late pieces stall the vmcnt(0) before the next barrier -- so all pieces
-        // go out with the first fragment of the step
-        if constexpr (A == 0) dma_issue<PI>(P);
+        // double buffer: spreading the pieces over the step made k_bwd 35 % slower on MI355X (late pieces
+        // stall the vmcnt(0) before the next barrier), so all pieces go out with the first fragment.
+        // Three-deep ring: the pieces have a whole further step to land, so they are spread evenly.
+        constexpr int slot = PLM_DMA_SPREAD ? (PI * NF) / NP : 0;
+        if constexpr (A == slot) dma_issue<PI>(P);
         dma_slot<NP, NF, A, PI + 1>(P);
     }
 }
@@ -495,6 +549,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (guide 5/4a)
     constexpr int TILE = 2 * Q * 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to be wave-uniform
     const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
     const int b16 = d.b16_lo + b16l;
     const int r = lane & 15, g = lane >> 4;
@@ -522,43 +577,81 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     };
     // gap mode: the K steps of state 0 are skipped altogether (gapped neighbours contribute nothing)
     const int gap = d.gap_mode, Qe = Q - gap, nsteps = d.nu * Qe;
+    constexpr int NBUF = PLM_NBUF, AHEAD = NBUF - 1;   // the tile of step t + AHEAD is copied during step t
+    constexpr int KEEP = (2 * Q) / 8;                   // pieces every wave issues per step, at least
+#if PLM_PROBE
+    unsigned long long pr_vm = 0, pr_bar = 0, pr_mm = 0;
+    const unsigned long long pr_t0 = PROBE_NOW();
+#endif
     stage(gap, 0);
-    uint2 xa0 = *(const uint2 *)arow0, xa1 = *(const uint2 *)arow1;
-    int t = 0;
+    int un = 0, bn = gap;              // (u, b) of step t + AHEAD, advanced once per step
+    for (int k = 0; k < AHEAD; k++) {
+        if (++bn == Q) { bn = gap; ++un; }
+        if (k + 1 < AHEAD && k + 1 < nsteps) stage(un * Q + bn, k + 1);
+    }
+    u64 na0 = *(const u64 *)arow0, na1 = *(const u64 *)arow1;   // bytes of the NEXT u (loop carried, in place)
+    int t = 0, cur = 0;
     for (int u = 0; u < d.nu; ++u) {
-        uint2 na0 = xa0, na1 = xa1;
+        // hand over the 32 sites of this u (landed: a vmcnt(0) and a barrier lie between the load and here),
+        // then start fetching the next 32
+        vm_landed(na0);
+        vm_landed(na1);
+        const u64 xa0 = na0, xa1 = na1;
         if (u + 1 < d.nu) {
-            na0 = *(const uint2 *)(arow0 + 32 * (u + 1));
-            na1 = *(const uint2 *)(arow1 + 32 * (u + 1));
+            load_b64_inplace(na0, arow0 + 32 * (u + 1));
+            load_b64_inplace(na1, arow1 + 32 * (u + 1));
         }
         for (int b = gap; b < Q; ++b, ++t) {
-            const int ks_next = (b + 1 < Q) ? u * Q + b + 1 : (u + 1) * Q + gap;
             // hipcc does NOT drain the LDS-DMA queue at this barrier (only lgkmcnt): without the
             // explicit wait a late global_load_lds piece is read before it lands (seen as
-            // run-to-run noise at N=50k); every wave drains its own pieces, then the barrier
+            // run-to-run noise at N=50k); every wave drains its own pieces of THIS step's tile, then
+            // the barrier.  Ring of 3: the >= KEEP pieces issued during the previous step (tile t+1)
+            // are newer than every piece of tile t and may stay in flight.
+#if PLM_PROBE
+            const unsigned long long pa = PROBE_NOW();
+#endif
 #if !(PLM_ABLATE & 1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (NBUF == 3 && t > 0 && t + 1 < nsteps) vm_wait<(KEEP < 1) ? 0 : KEEP>();
+            else vm_wait<0>();
+#endif
+#if PLM_PROBE
+            const unsigned long long pb = PROBE_NOW();
+#endif
+#if !(PLM_ABLATE & 1)
             __syncthreads();
 #endif
-            const DmaPlan dma{bt + (size_t)ks_next * TILE + lane * 16, smem + ((t + 1) & 1) * TILE, wave,
-                              ((PLM_ABLATE & 2) == 0 && t + 1 < nsteps && PLM_IS_LOADER(wave)) ? 2 * Q : 0};
-            const char *lb = smem + (t & 1) * TILE + lane * 16;
+#if PLM_PROBE
+            const unsigned long long pc = PROBE_NOW();
+            pr_vm += pb - pa;
+            pr_bar += pc - pb;
+#endif
+            const int nb = (cur + AHEAD >= NBUF) ? cur + AHEAD - NBUF : cur + AHEAD;
+            const DmaPlan dma{bt + (size_t)(un * Q + bn) * TILE, smem + nb * TILE, wave_s,
+                              ((PLM_ABLATE & 2) == 0 && t + AHEAD < nsteps && PLM_IS_LOADER(wave_s)) ? 2 * Q : 0,
+                              (u32)lane * 16};
+            const char *lb = smem + cur * TILE + lane * 16;
             const u32 bb = (u32)b * 0x01010101u;
 #if !(PLM_ABLATE & 8)
-            const half8 a0 = onehot8(xa0.x, xa0.y, bb);
-            const half8 a1 = onehot8(xa1.x, xa1.y, bb);
+            const half8 a0 = onehot8((u32)xa0, (u32)(xa0 >> 32), bb);
+            const half8 a1 = onehot8((u32)xa1, (u32)(xa1 >> 32), bb);
 #else
             half8 a0, a1;
-            ((u32 *)&a0)[0] = xa0.x; ((u32 *)&a0)[1] = xa0.y; ((u32 *)&a0)[2] = bb; ((u32 *)&a0)[3] = xa1.x;
-            ((u32 *)&a1)[0] = xa1.x; ((u32 *)&a1)[1] = xa1.y; ((u32 *)&a1)[2] = bb; ((u32 *)&a1)[3] = xa0.y;
+            ((u32 *)&a0)[0] = (u32)xa0; ((u32 *)&a0)[1] = (u32)(xa0 >> 32); ((u32 *)&a0)[2] = bb; ((u32 *)&a0)[3] = (u32)xa1;
+            ((u32 *)&a1)[0] = (u32)xa1; ((u32 *)&a1)[1] = (u32)(xa1 >> 32); ((u32 *)&a1)[2] = bb; ((u32 *)&a1)[3] = (u32)xa0;
 #endif
             // software pipeline: the B fragments of state a+PF are in flight while state a computes
             // (without it hipcc waits lgkmcnt(0) before every group of 4 MFMAs: LDS latency x21)
             fwd_kstep<Q>(acc, a0, a1, lds_addr(lb), dma, std::make_integer_sequence<int, Q>{});
+#if PLM_PROBE
+            pr_mm += PROBE_NOW() - pc;
+#endif
+            cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+            if (++bn == Q) { bn = gap; ++un; }
         }
-        xa0 = na0;
-        xa1 = na1;
     }
+#if PLM_PROBE
+    const unsigned long long pr_t1 = PROBE_NOW();
+#endif
 
     // ---- epilogue: softmax over states, residuals, -log P -------------------------------
     const float sc = ldexpf(1.f, -(*A.jexp));
@@ -621,6 +714,14 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     __syncthreads();   // every wave is done with the B tiles: reuse the LDS for the reduction
     const double tot = block_reduce_sum((double)fxl, (double *)smem);
     if (tid == 0) A.fx_part[blockIdx.x] = tot;
+#if PLM_PROBE
+    if (lane == 0) {
+        const unsigned long long pr_t2 = PROBE_NOW();
+        atomicAdd(&plm_probe_acc[0][0], pr_vm); atomicAdd(&plm_probe_acc[0][1], pr_bar);
+        atomicAdd(&plm_probe_acc[0][2], pr_mm); atomicAdd(&plm_probe_acc[0][3], pr_t2 - pr_t0);
+        atomicAdd(&plm_probe_acc[0][4], pr_t2 - pr_t1); atomicAdd(&plm_probe_acc[0][5], 1ull);
+    }
+#endif
 }
 
 hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
@@ -628,7 +729,7 @@ hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const floa
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     FwdArgs A{msa_rm, w, (const char *)Bt, x, jexp, (_Float16 *)Rt, fx_part, ldexpf(1.f, PLM_R_EXP)};
     const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
-    const size_t lds = (size_t)2 * 2 * d.Q * 1024;
+    const size_t lds = (size_t)PLM_NBUF * 2 * d.Q * 1024;
 #define FWD_CASE(QQ)                                                                                   \
     case QQ: {                                                                                         \
         static bool attr_done = false;                                                                 \
@@ -697,6 +798,7 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 2 * FN * 2 * 1024;  // 2*FN col fragments x 2 planes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to be wave-uniform
     const int wm = wave >> 1, wn = wave & 1;
     const int ngroups = d.ncol_tiles * d.ksplit;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -734,28 +836,57 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
             }
         }
     };
-    if (k0 < k1) stage(k0, 0);
-    uint2 xa = (k0 < k1) ? *(const uint2 *)(acol + (size_t)32 * k0) : make_uint2(0, 0);
+#if PLM_PROBE
+    unsigned long long pr_vm = 0, pr_bar = 0, pr_mm = 0;
+    const unsigned long long pr_t0 = PROBE_NOW();
+#endif
+    constexpr int NBUF = PLM_NBUF, AHEAD = NBUF - 1;   // the tile of step ss + AHEAD is copied during step ss
+    const int np_valid = min(4 * FN, 2 * (d.nnfl - nfl0));
+    const int mine = (np_valid > wave_s) ? (np_valid - wave_s + 7) / 8 : 0;   // pieces this wave copies per step
+    for (int k = 0; k < AHEAD; k++)
+        if (k0 + k < k1) stage(k0 + k, k);
+    u64 nx = (k0 < k1) ? *(const u64 *)(acol + (size_t)32 * k0) : 0ull;   // bytes of the next step (in place)
+    int cur = 0;
     for (int ss = k0; ss < k1; ++ss) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed (see k_fwd)
+        // own LDS-DMA pieces of THIS step's tile landed (see k_fwd); with the ring of 3 the pieces issued
+        // during the previous step (tile ss+1) are newer and may stay in flight
+#if PLM_PROBE
+        const unsigned long long pa = PROBE_NOW();
+#endif
+        if (NBUF == 3 && ss > k0 && ss + 1 < k1) vm_wait_keep(mine);
+        else vm_wait<0>();
+#if PLM_PROBE
+        const unsigned long long pb = PROBE_NOW();
+#endif
         __syncthreads();
-        uint2 nx = xa;
-        if (ss + 1 < k1) nx = *(const uint2 *)(acol + (size_t)32 * (ss + 1));
-        const int np_valid = min(4 * FN, 2 * (d.nnfl - nfl0));
-        const DmaPlan dma{Rt + ((size_t)(ss + 1) * d.nnfl + nfl0) * 2048 + lane * 16,
-                          smem + ((ss + 1 - k0) & 1) * TILE, wave,
-                          (ss + 1 < k1 && PLM_IS_LOADER(wave)) ? np_valid : 0};
+#if PLM_PROBE
+        const unsigned long long pc = PROBE_NOW();
+        pr_vm += pb - pa;
+        pr_bar += pc - pb;
+#endif
+        vm_landed(nx);
+        const u64 xa = nx;
+        if (ss + 1 < k1) load_b64_inplace(nx, acol + (size_t)32 * (ss + 1));
+        const int nb = (cur + AHEAD >= NBUF) ? cur + AHEAD - NBUF : cur + AHEAD;
+        const DmaPlan dma{Rt + ((size_t)(ss + AHEAD) * d.nnfl + nfl0) * 2048, smem + nb * TILE, wave_s,
+                          (ss + AHEAD < k1 && PLM_IS_LOADER(wave_s)) ? np_valid : 0, (u32)lane * 16};
         if (row_ok) {
-            const char *lb = smem + ((ss - k0) & 1) * TILE + (wn * FN) * 2048 + lane * 16;
+            const char *lb = smem + cur * TILE + (wn * FN) * 2048 + lane * 16;
             half8 af[FM];
 #pragma unroll
-            for (int f = 0; f < FM; f++) af[f] = onehot8(xa.x, xa.y, (u32)(b0 + f) * 0x01010101u);
+            for (int f = 0; f < FM; f++) af[f] = onehot8((u32)xa, (u32)(xa >> 32), (u32)(b0 + f) * 0x01010101u);
             bwd_kstep<FM, FN>(acc, af, lds_addr(lb), dma, std::make_integer_sequence<int, FN>{});
         } else {
             dma_slot<(4 * FN + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, 1, 0>(dma);   // idle row waves still copy their share
         }
-        xa = nx;
+        cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+#if PLM_PROBE
+        pr_mm += PROBE_NOW() - pc;
+#endif
     }
+#if PLM_PROBE
+    const unsigned long long pr_t1 = PROBE_NOW();
+#endif
     if (!row_ok) return;
 #pragma unroll
     for (int f = 0; f < FM; f++)
@@ -765,6 +896,14 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
             if (nfl < d.nnfl)
                 *(f32x4 *)(G + ((((size_t)ks * d.nmf + mf0 + f) * d.nnfl + nfl) * 64 + lane) * 4) = acc[f][c];
         }
+#if PLM_PROBE
+    if (lane == 0) {
+        const unsigned long long pr_t2 = PROBE_NOW();
+        atomicAdd(&plm_probe_acc[1][0], pr_vm); atomicAdd(&plm_probe_acc[1][1], pr_bar);
+        atomicAdd(&plm_probe_acc[1][2], pr_mm); atomicAdd(&plm_probe_acc[1][3], pr_t2 - pr_t0);
+        atomicAdd(&plm_probe_acc[1][4], pr_t2 - pr_t1); atomicAdd(&plm_probe_acc[1][5], 1ull);
+    }
+#endif
 }
 
 hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G, hipStream_t st) {
@@ -772,7 +911,7 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
     const dim3 grid(8 * ((ngroups + 7) / 8) * d.nrow_tiles), block(512);
 #define BWD_CASE(QQ, M, N)                                                                             \
     case QQ: {                                                                                         \
-        const size_t lds = (size_t)2 * (2 * N * 2 * 1024);                                             \
+        const size_t lds = (size_t)PLM_NBUF * (2 * N * 2 * 1024);                                      \
         static bool attr_done = false;                                                                 \
         if (!attr_done) {                                                                              \
             hipError_t e = hipFuncSetAttribute((const void *)k_bwd<QQ, M, N>,                          \
