@@ -22,24 +22,33 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
-// PLM_ABLATE bit mask for timing experiments (results invalid): 1 no barrier/vmcnt in k_fwd,
-// 2 no LDS-DMA in k_fwd, 4 no LDS reads in k_fwd (reuse the first fragments), 8 no one-hot expansion
+// PLM_PIPE selects how the streamed B tiles of k_fwd / k_bwd are synchronised.
+//   1 (default): three LDS buffers, ONE barrier per K step placed in the middle of the step.  Passing the
+//      barrier of step t proves that tile t+1 has landed and that everybody is done with tile t-1, so the
+//      copy of tile t+2 starts there, and the wave runs from step t straight into step t+1: the first B
+//      fragments of t+1 are read from LDS while the last MFMAs of t are still issuing.  No pipeline drain
+//      at step boundaries.
+//   0: double buffer, barrier at the top of every step (every wave restarts its LDS reads behind it).
+#ifndef PLM_PIPE
+#define PLM_PIPE 0
+#endif
+// PLM_ABLATE bit mask for timing experiments with PLM_PIPE=0 (RESULTS INVALID): 1 no per-step vmcnt wait +
+// barrier, 2 no LDS-DMA in the K loop, 4 no LDS reads in the K loop (first fragments reused), 8 no one-hot
+// expansion (raw bytes as the A operand), 16 no epilogue arithmetic in k_fwd
 #ifndef PLM_ABLATE
 #define PLM_ABLATE 0
 #endif
-#ifndef PLM_SETPRIO
-#define PLM_SETPRIO 0      // 1: raise wave priority around the MFMA groups (A/B experiment)
+// PLM_DMA_STAGGER_FWD / _BWD (sixteenths of a K step): waves 0-3 issue their LDS-DMA pieces at the start of
+// the step, waves 4-7 (the SIMD partners of 0-3) this far into it.  Issuing a piece blocks a wave for
+// ~100-200 cycles; when both waves of a SIMD do that at the same time the MFMA pipe idles, but pieces issued
+// late land late.  Measured on MI355X (ms, stagger 0/4/8/12): k_fwd 5.42/5.27/5.59/5.69, k_bwd 5.19/5.46/5.50/5.46.
+#ifndef PLM_DMA_STAGGER_FWD
+#define PLM_DMA_STAGGER_FWD 4
 #endif
-// PLM_NBUF: LDS ring depth of the streamed tiles.  2 (default): double buffer, every piece of the next tile
-// issued right after the barrier.  3 (experiment, measured on MI355X: no gain -- k_fwd 5.30 vs 5.28 ms, k_bwd
-// 5.10 vs 5.18 ms -- and kept out of the product build): the tile of step t+2 is copied while step t computes,
-// its pieces spread over the step (PLM_DMA_SPREAD) and allowed to land during step t+1 (counted vmcnt waits).
-#ifndef PLM_NBUF
-#define PLM_NBUF 2
+#ifndef PLM_DMA_STAGGER_BWD
+#define PLM_DMA_STAGGER_BWD 0
 #endif
-#ifndef PLM_DMA_SPREAD
-#define PLM_DMA_SPREAD (PLM_NBUF == 3)
-#endif
+#define PLM_NBUF (PLM_PIPE ? 3 : 2)
 typedef unsigned long long u64;
 // PLM_ASYNC_A: the alignment bytes of the next K step are fetched by a load the compiler does not track.
 // hipcc cannot count the LDS-DMA pieces issued under branches after an ordinary load, so it waits
@@ -50,27 +59,23 @@ typedef unsigned long long u64;
 #ifndef PLM_ASYNC_A
 #define PLM_ASYNC_A 1
 #endif
-__device__ __forceinline__ void load_b64_inplace(u64 &v, const void *p) {
+// address = wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: one VGPR instead of a 64-bit pointer
+__device__ __forceinline__ void load_b64_inplace(u64 &v, const void *base, u32 off) {
 #if PLM_ASYNC_A
-    asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
 #else
-    v = *(const u64 *)p;
+    v = *(const u64 *)((const char *)base + off);
 #endif
 }
 __device__ __forceinline__ void vm_landed(u64 &v) { asm volatile("" : "+v"(v)); }
+// hipcc does NOT drain the LDS-DMA queue at a barrier (only lgkmcnt): every wave waits for its own
+// global_load_lds pieces explicitly before the barrier that publishes a tile (without it a late piece
+// is read before it lands -- seen as run-to-run noise at N = 50k)
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// wait until at most `keep` (<= 3 used) of this wave's newest VMEM operations are outstanding
-__device__ __forceinline__ void vm_wait_keep(int keep) {
-    if (keep >= 3) vm_wait<3>();
-    else if (keep == 2) vm_wait<2>();
-    else if (keep == 1) vm_wait<1>();
-    else vm_wait<0>();
-}
-#ifndef PLM_STAGE_GLDS
-#define PLM_STAGE_GLDS 1   // 1: global_load_lds (LDS-DMA) staging; 0: register staging (debug A/B)
-#endif
-// PLM_PROBE=1 (debug build only): per-wave cycle totals of the K-loop phases of k_fwd / k_bwd, summed into
-// plm_probe_acc[kernel][phase]: 0 vmcnt wait, 1 barrier, 2 MFMA section, 3 whole kernel, 4 epilogue, 5 waves
+// bare s_barrier: unlike __syncthreads() it does not wait for this wave's LDS reads in flight
+__device__ __forceinline__ void barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
+// PLM_PROBE=1 (debug build only): per-wave cycle totals summed into plm_probe_acc[kernel][phase]:
+// 0 wait (vmcnt + barrier), 3 whole kernel, 4 epilogue, 5 waves
 #ifndef PLM_PROBE
 #define PLM_PROBE 0
 #endif
@@ -126,49 +131,40 @@ template <int N> __device__ __forceinline__ void lds_wait(half8 &a, half8 &b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
-// ---- LDS-DMA pieces spread over a K step ------------------------------------------------------
-// A tile is copied global -> LDS in 1 KB pieces (one global_load_lds per wave-instruction).  Issuing
-// a wave's 4-6 pieces back to back right after the barrier keeps every wave of the workgroup out
-// of the MFMA pipe at the same time; instead piece PI is issued between the MFMA groups of an
-// early fragment of the step (first ~60 % so it has landed before the next barrier).
+// ---- LDS-DMA staging of the next tile -----------------------------------------------------------
+// A tile is copied global -> LDS in 1 KB pieces (one global_load_lds per wave-instruction); wave w copies
+// pieces w, w+8, ...  (the wave number is passed through readfirstlane so the piece tests are scalar
+// branches).  Measured alternatives on MI355X, all slower: spreading a wave's pieces over the K step
+// (k_bwd +35 %: late pieces stall the vmcnt(0) before the next barrier), leaving the copy to 4 of the 8
+// waves (k_fwd 5.3 -> 6.2 ms, k_bwd 5.8 -> 9.7 ms), register staging instead of LDS-DMA.
 struct DmaPlan {
     const char *src;   // global address of piece 0 (wave-uniform: lives in SGPRs)
     char *dst;         // LDS base of the target buffer (wave-uniform)
-    int first;         // this wave's first piece (wave-uniform); pieces first + PLM_DMA_WAVES*PI
+    int first;         // this wave's first piece (wave-uniform)
     int limit;         // number of pieces to copy (0 = nothing to stage)
     u32 lane_off;      // lane * 16: the only per-lane part of the address
+    bool late;         // this wave issues in the second slot of the step (PLM_DMA_STAGGER_*)
 };
-// Waves w and w+4 of a 512-thread workgroup share a SIMD.  PLM_DMA_WAVES = 8: every wave stages its
-// share of the tile.  PLM_DMA_WAVES = 4 (one loader wave per SIMD, the partner computing meanwhile)
-// was measured on MI355X and is much slower (k_fwd 5.3 -> 6.2 ms, k_bwd 5.8 -> 9.7 ms): the serial
-// issue of 7-11 LDS-DMA pieces by one wave outlasts the step.
-#ifndef PLM_DMA_WAVES
-#define PLM_DMA_WAVES 8
-#endif
-#if PLM_DMA_WAVES == 8
-#define PLM_IS_LOADER(wave) true
-#else
-#define PLM_IS_LOADER(wave) ((wave) < PLM_DMA_WAVES)
-#endif
-template <int PI> __device__ __forceinline__ void dma_issue(const DmaPlan &P) {
-    const int p = P.first + PLM_DMA_WAVES * PI;
-    if (p < P.limit) {
-#if PLM_STAGE_GLDS
-        __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024 + P.lane_off), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
-#else
-        *(float4 *)(P.dst + p * 1024 + P.lane_off) = *(const float4 *)(P.src + p * 1024 + P.lane_off);
-#endif
+template <int NP> __device__ __forceinline__ void dma_issue_all(const DmaPlan &P) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int p = P.first + 8 * k;
+        if (p < P.limit)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024 + P.lane_off), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
     }
 }
-// issue every piece whose slot is fragment index A; NP pieces per wave, NF fragments per step
-template <int NP, int NF, int A, int PI = 0> __device__ __forceinline__ void dma_slot(const DmaPlan &P) {
-    if constexpr (PI < NP) {
-        // double buffer: spreading the pieces over the step made k_bwd 35 % slower on MI355X (late pieces
-        // stall the vmcnt(0) before the next barrier), so all pieces go out with the first fragment.
-        // Three-deep ring: the pieces have a whole further step to land, so they are spread evenly.
-        constexpr int slot = PLM_DMA_SPREAD ? (PI * NF) / NP : 0;
-        if constexpr (A == slot) dma_issue<PI>(P);
-        dma_slot<NP, NF, A, PI + 1>(P);
+// the two issue slots of a step with NF fragments: S0 for the early waves, S1 for the late ones
+template <int NF, int A, int NP, int STG> __device__ __forceinline__ void dma_at(const DmaPlan &P) {
+    if constexpr ((PLM_ABLATE & 2) != 0) return;
+    constexpr int MID = (NF - 2) / 2;                       // PLM_PIPE: fragment behind whose first MFMAs the barrier sits
+    constexpr int S0 = PLM_PIPE ? MID : 0;
+    constexpr int D = (NF * STG) / 16;
+    constexpr int S1 = (S0 + D < NF) ? S0 + D : NF - 1;
+    if constexpr (S0 == S1) {
+        if constexpr (A == S0) dma_issue_all<NP>(P);
+    } else {
+        if constexpr (A == S0) { if (!P.late) dma_issue_all<NP>(P); }
+        if constexpr (A == S1) { if (P.late) dma_issue_all<NP>(P); }
     }
 }
 
@@ -503,51 +499,56 @@ struct FwdArgs {
 };
 
 // one K step of the forward GEMM for one wave: Q states x (hi, lo) planes x 2 row fragments.
-// The B fragments of state A+2 are issued before state A computes (6 reads in flight at most).
+// The B fragments of state A+2 are issued before state A computes.  The fragment registers form a ring of
+// R slots, R | Q, so that with PLM_PIPE the ring runs on across step boundaries: the reads for states 0, 1
+// of the NEXT step (LDS address lbn) are issued behind states Q-2, Q-1 of this one.
+template <int Q> struct FwdRing {
+    static constexpr int R = (Q % 3 == 0) ? 3 : (Q % 4 == 0) ? 4 : Q;
+};
 template <int Q, int A>
-__device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb,
-                                          half8 (&bh)[3], half8 (&bl)[3], const DmaPlan &dma) {
-#if !(PLM_ABLATE & 4)
-    if constexpr (A + 2 < Q) {
-        bh[(A + 2) % 3] = lds_read_b128<(A + 2) * 1024>(lb);
-        bl[(A + 2) % 3] = lds_read_b128<(Q + A + 2) * 1024>(lb);
+__device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb, u32 lbn,
+                                          half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
+                                          const DmaPlan &dma) {
+    constexpr int R = FwdRing<Q>::R, MID = (Q - 2) / 2, NP = (2 * Q + 7) / 8;
+    if constexpr ((PLM_ABLATE & 4) != 0) {
+        if constexpr (A == 0) { lds_wait<0>(bh[0], bl[0]); lds_wait<0>(bh[1], bl[1]); }
+        if constexpr (A + 2 < Q) { bh[(A + 2) % R] = bh[A % R]; bl[(A + 2) % R] = bl[A % R]; }
+    } else if constexpr (A + 2 < Q) {
+        bh[(A + 2) % R] = lds_read_b128<(A + 2) * 1024>(lb);
+        bl[(A + 2) % R] = lds_read_b128<(Q + A + 2) * 1024>(lb);
+    } else if constexpr (PLM_PIPE) {
+        bh[(A + 2) % R] = lds_read_b128<(A + 2 - Q) * 1024>(lbn);
+        bl[(A + 2) % R] = lds_read_b128<(A + 2) * 1024>(lbn);
     }
-    constexpr int newer = (A + 2 < Q) ? 4 : (A + 1 < Q) ? 2 : 0;
-    lds_wait<newer>(bh[A % 3], bl[A % 3]);
-#if PLM_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#else
-    if constexpr (A == 0) lds_wait<0>(bh[0], bl[0]);
-    if constexpr (A == 0) lds_wait<0>(bh[1], bl[1]);
-    if constexpr (A == 0) { bh[2] = bh[0]; bl[2] = bl[1]; }
-#endif
-    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh[A % 3], acc[0][A], 0, 0, 0);
-    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[A % 3], acc[1][A], 0, 0, 0);
-    dma_slot<(2 * Q + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, Q, A>(dma);
-    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[A % 3], acc[0][A], 0, 0, 0);
-    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[A % 3], acc[1][A], 0, 0, 0);
-#if PLM_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    constexpr int newer = PLM_PIPE ? 4 : (A + 2 < Q) ? 4 : (A + 1 < Q) ? 2 : 0;
+    if constexpr ((PLM_ABLATE & 4) == 0) lds_wait<newer>(bh[A % R], bl[A % R]);
+    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh[A % R], acc[0][A], 0, 0, 0);
+    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[A % R], acc[1][A], 0, 0, 0);
+    if constexpr (PLM_PIPE && A == MID) {
+        vm_wait<0>();       // my pieces of tile t+1 (issued one step ago) have landed ...
+        barrier_raw();      // ... and so have everybody's; nobody reads tile t-1 any more
+    }
+    dma_at<Q, A, NP, PLM_DMA_STAGGER_FWD>(dma);  // PLM_PIPE: tile t+2 -> the buffer of tile t-1; else tile t+1 -> the other buffer
+    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[A % R], acc[0][A], 0, 0, 0);
+    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[A % R], acc[1][A], 0, 0, 0);
 }
 template <int Q, int... A>
-__device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb,
+__device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb, u32 lbn,
+                                          half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
                                           const DmaPlan &dma, std::integer_sequence<int, A...>) {
-    half8 bh[3], bl[3];
-    bh[0] = lds_read_b128<0>(lb);
-    bl[0] = lds_read_b128<Q * 1024>(lb);
-    if constexpr (Q > 1) {
+    if constexpr (!PLM_PIPE) {
+        bh[0] = lds_read_b128<0>(lb);
+        bl[0] = lds_read_b128<Q * 1024>(lb);
         bh[1] = lds_read_b128<1024>(lb);
         bl[1] = lds_read_b128<(Q + 1) * 1024>(lb);
     }
-    (fwd_state<Q, A>(acc, a0, a1, lb, bh, bl, dma), ...);
+    (fwd_state<Q, A>(acc, a0, a1, lb, lbn, bh, bl, dma), ...);
 }
 
 template <int Q>
 __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (guide 5/4a)
-    constexpr int TILE = 2 * Q * 1024;
+    constexpr int TILE = 2 * Q * 1024, NBUF = PLM_NBUF, NP = (2 * Q + 7) / 8, R = FwdRing<Q>::R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to be wave-uniform
     const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
@@ -555,8 +556,8 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     const int r = lane & 15, g = lane >> 4;
     const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
     const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE;
-    const int8_t *arow0 = A.msa_rm + (size_t)(s_wave + r) * d.Lp32 + 8 * g;
-    const int8_t *arow1 = arow0 + (size_t)16 * d.Lp32;
+    // A operand: byte offsets of the two sequences' rows in msa_rm (< 2^31: Np * Lp32 bytes)
+    const u32 arow0 = (u32)(s_wave + r) * (u32)d.Lp32 + 8 * g, arow1 = arow0 + 16 * (u32)d.Lp32;
 
     f32x4 acc[2][Q];
 #pragma unroll
@@ -564,72 +565,61 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
         acc[0][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    auto stage = [&](int ks, int buf) {
-        const char *src = bt + (size_t)ks * TILE + lane * 16;
-        char *dst = smem + buf * TILE;
-        for (int p = wave; p < 2 * Q; p += 8) {
-#if PLM_STAGE_GLDS
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src + p * 1024), LDS_PTR(dst + p * 1024), 16, 0, 0);
-#else
-            *(float4 *)(dst + p * 1024 + lane * 16) = *(const float4 *)(src + p * 1024);
-#endif
-        }
-    };
     // gap mode: the K steps of state 0 are skipped altogether (gapped neighbours contribute nothing)
     const int gap = d.gap_mode, Qe = Q - gap, nsteps = d.nu * Qe;
-    constexpr int NBUF = PLM_NBUF, AHEAD = NBUF - 1;   // the tile of step t + AHEAD is copied during step t
-    constexpr int KEEP = (2 * Q) / 8;                   // pieces every wave issues per step, at least
 #if PLM_PROBE
-    unsigned long long pr_vm = 0, pr_bar = 0, pr_mm = 0;
+    unsigned long long pr_wait = 0;
     const unsigned long long pr_t0 = PROBE_NOW();
 #endif
-    stage(gap, 0);
-    int un = 0, bn = gap;              // (u, b) of step t + AHEAD, advanced once per step
-    for (int k = 0; k < AHEAD; k++) {
+    // prologue: tiles of the first NBUF-1 steps; (un, bn) = (u, b) of the step whose tile is copied next
+    int un = 0, bn = gap;
+    for (int k = 0; k < NBUF - 1; k++) {
+        if (k < nsteps) {
+            const DmaPlan first{bt + (size_t)(un * Q + bn) * TILE, smem + k * TILE, wave_s, 2 * Q, (u32)lane * 16, false};
+            dma_issue_all<NP>(first);
+        }
         if (++bn == Q) { bn = gap; ++un; }
-        if (k + 1 < AHEAD && k + 1 < nsteps) stage(un * Q + bn, k + 1);
     }
-    u64 na0 = *(const u64 *)arow0, na1 = *(const u64 *)arow1;   // bytes of the NEXT u (loop carried, in place)
+    u64 na0 = *(const u64 *)(A.msa_rm + arow0), na1 = *(const u64 *)(A.msa_rm + arow1);   // bytes of the NEXT u
+    half8 bh[R], bl[R];
+    if constexpr (PLM_PIPE) {
+        vm_wait<0>();
+        __syncthreads();
+        const u32 l0 = lds_addr(smem + lane * 16);
+        bh[0] = lds_read_b128<0>(l0);
+        bl[0] = lds_read_b128<Q * 1024>(l0);
+        bh[1] = lds_read_b128<1024>(l0);
+        bl[1] = lds_read_b128<(Q + 1) * 1024>(l0);
+    }
     int t = 0, cur = 0;
     for (int u = 0; u < d.nu; ++u) {
-        // hand over the 32 sites of this u (landed: a vmcnt(0) and a barrier lie between the load and here),
+        // hand over the 32 sites of this u (landed: a vmcnt(0) lies between the load and here),
         // then start fetching the next 32
         vm_landed(na0);
         vm_landed(na1);
         const u64 xa0 = na0, xa1 = na1;
         if (u + 1 < d.nu) {
-            load_b64_inplace(na0, arow0 + 32 * (u + 1));
-            load_b64_inplace(na1, arow1 + 32 * (u + 1));
+            load_b64_inplace(na0, A.msa_rm, arow0 + 32 * (u + 1));
+            load_b64_inplace(na1, A.msa_rm, arow1 + 32 * (u + 1));
         }
         for (int b = gap; b < Q; ++b, ++t) {
-            // hipcc does NOT drain the LDS-DMA queue at this barrier (only lgkmcnt): without the
-            // explicit wait a late global_load_lds piece is read before it lands (seen as
-            // run-to-run noise at N=50k); every wave drains its own pieces of THIS step's tile, then
-            // the barrier.  Ring of 3: the >= KEEP pieces issued during the previous step (tile t+1)
-            // are newer than every piece of tile t and may stay in flight.
+            if constexpr (!PLM_PIPE) {
 #if PLM_PROBE
-            const unsigned long long pa = PROBE_NOW();
+                const unsigned long long pa = PROBE_NOW();
 #endif
-#if !(PLM_ABLATE & 1)
-            if (NBUF == 3 && t > 0 && t + 1 < nsteps) vm_wait<(KEEP < 1) ? 0 : KEEP>();
-            else vm_wait<0>();
-#endif
+                if constexpr ((PLM_ABLATE & 1) == 0) {
+                    vm_wait<0>();
+                    __syncthreads();
+                }
 #if PLM_PROBE
-            const unsigned long long pb = PROBE_NOW();
+                pr_wait += PROBE_NOW() - pa;
 #endif
-#if !(PLM_ABLATE & 1)
-            __syncthreads();
-#endif
-#if PLM_PROBE
-            const unsigned long long pc = PROBE_NOW();
-            pr_vm += pb - pa;
-            pr_bar += pc - pb;
-#endif
-            const int nb = (cur + AHEAD >= NBUF) ? cur + AHEAD - NBUF : cur + AHEAD;
-            const DmaPlan dma{bt + (size_t)(un * Q + bn) * TILE, smem + nb * TILE, wave_s,
-                              ((PLM_ABLATE & 2) == 0 && t + AHEAD < nsteps && PLM_IS_LOADER(wave_s)) ? 2 * Q : 0,
-                              (u32)lane * 16};
-            const char *lb = smem + cur * TILE + lane * 16;
+            }
+            const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
+            const int tgt = PLM_PIPE ? ((nxt + 1 == NBUF) ? 0 : nxt + 1) : nxt;   // buffer of step t + NBUF - 1
+            const DmaPlan dma{bt + (size_t)(un * Q + bn) * TILE, smem + tgt * TILE, wave_s,
+                              (t + NBUF - 1 < nsteps) ? 2 * Q : 0, (u32)lane * 16, wave_s >= 4};
+            const u32 lb = lds_addr(smem + cur * TILE + lane * 16), lbn = lds_addr(smem + nxt * TILE + lane * 16);
             const u32 bb = (u32)b * 0x01010101u;
 #if !(PLM_ABLATE & 8)
             const half8 a0 = onehot8((u32)xa0, (u32)(xa0 >> 32), bb);
@@ -639,20 +629,28 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             ((u32 *)&a0)[0] = (u32)xa0; ((u32 *)&a0)[1] = (u32)(xa0 >> 32); ((u32 *)&a0)[2] = bb; ((u32 *)&a0)[3] = (u32)xa1;
             ((u32 *)&a1)[0] = (u32)xa1; ((u32 *)&a1)[1] = (u32)(xa1 >> 32); ((u32 *)&a1)[2] = bb; ((u32 *)&a1)[3] = (u32)xa0;
 #endif
-            // software pipeline: the B fragments of state a+PF are in flight while state a computes
+            // software pipeline: the B fragments of state a+2 are in flight while state a computes
             // (without it hipcc waits lgkmcnt(0) before every group of 4 MFMAs: LDS latency x21)
-            fwd_kstep<Q>(acc, a0, a1, lds_addr(lb), dma, std::make_integer_sequence<int, Q>{});
-#if PLM_PROBE
-            pr_mm += PROBE_NOW() - pc;
-#endif
-            cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+            fwd_kstep<Q>(acc, a0, a1, lb, lbn, bh, bl, dma, std::make_integer_sequence<int, Q>{});
+            cur = nxt;
             if (++bn == Q) { bn = gap; ++un; }
         }
+    }
+    if constexpr (PLM_PIPE) {   // the last step read two fragments past the end: let them land before the
+#pragma unroll                  // registers are reused
+        for (int k = 0; k < R; k++) lds_wait<0>(bh[k], bl[k]);
     }
 #if PLM_PROBE
     const unsigned long long pr_t1 = PROBE_NOW();
 #endif
 
+#if PLM_ABLATE & 16
+    float fxl = 0.f;   // timing experiment: consume the accumulators, skip the real epilogue
+#pragma unroll
+    for (int a = 0; a < Q; a++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) fxl += acc[0][a][k] + acc[1][a][k];
+#else
     // ---- epilogue: softmax over states, residuals, -log P -------------------------------
     const float sc = ldexpf(1.f, -(*A.jexp));
     const int i = b16 * 16 + r;
@@ -711,14 +709,14 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             *(half4 *)(rt + (size_t)a * 1024 + 512 + slot) = lo;
         }
     }
+#endif
     __syncthreads();   // every wave is done with the B tiles: reuse the LDS for the reduction
     const double tot = block_reduce_sum((double)fxl, (double *)smem);
     if (tid == 0) A.fx_part[blockIdx.x] = tot;
 #if PLM_PROBE
     if (lane == 0) {
         const unsigned long long pr_t2 = PROBE_NOW();
-        atomicAdd(&plm_probe_acc[0][0], pr_vm); atomicAdd(&plm_probe_acc[0][1], pr_bar);
-        atomicAdd(&plm_probe_acc[0][2], pr_mm); atomicAdd(&plm_probe_acc[0][3], pr_t2 - pr_t0);
+        atomicAdd(&plm_probe_acc[0][0], pr_wait); atomicAdd(&plm_probe_acc[0][3], pr_t2 - pr_t0);
         atomicAdd(&plm_probe_acc[0][4], pr_t2 - pr_t1); atomicAdd(&plm_probe_acc[0][5], 1ull);
     }
 #endif
@@ -762,34 +760,45 @@ hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const floa
 //   residual panel on one XCD (block b runs on XCD b % 8).
 // =========================================================================================
 // one K step (32 sequences) of the backward GEMM for one wave: the B fragments of column C+1 are
-// in flight while the 2*FM MFMAs of column C run
-template <int FM, int FN, int C>
-__device__ __forceinline__ void bwd_col(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb, half8 (&bh)[2],
-                                        half8 (&bl)[2], const DmaPlan &dma) {
-    if constexpr (C + 1 < FN) {
-        bh[(C + 1) & 1] = lds_read_b128<(C + 1) * 2048>(lb);
-        bl[(C + 1) & 1] = lds_read_b128<(C + 1) * 2048 + 1024>(lb);
+// in flight while the 2*FM MFMAs of column C run.  Two fragment slots; with PLM_PIPE the read for column 0
+// of the NEXT step (LDS address lbn) is issued behind the last column, so when FN is odd the slot
+// parity PAR alternates from step to step (two instantiations of the step).
+template <int FM, int FN, int C, int PAR>
+__device__ __forceinline__ void bwd_col(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb, u32 lbn,
+                                        half8 (&bh)[2], half8 (&bl)[2], const DmaPlan &dma) {
+    constexpr int MID = (FN - 2) / 2, NP = (4 * FN + 7) / 8;
+    constexpr int me = (C + PAR) & 1, nx = (C + 1 + PAR) & 1;
+    if constexpr ((PLM_ABLATE & 4) != 0) {
+        if constexpr (C == 0) lds_wait<0>(bh[me], bl[me]);
+        bh[nx] = bh[me];
+        bl[nx] = bl[me];
+    } else if constexpr (C + 1 < FN) {
+        bh[nx] = lds_read_b128<(C + 1) * 2048>(lb);
+        bl[nx] = lds_read_b128<(C + 1) * 2048 + 1024>(lb);
+    } else if constexpr (PLM_PIPE) {
+        bh[nx] = lds_read_b128<0>(lbn);
+        bl[nx] = lds_read_b128<1024>(lbn);
     }
-    lds_wait<(C + 1 < FN) ? 2 : 0>(bh[C & 1], bl[C & 1]);
-#if PLM_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
+    if constexpr ((PLM_ABLATE & 4) == 0) lds_wait<(PLM_PIPE || C + 1 < FN) ? 2 : 0>(bh[me], bl[me]);
 #pragma unroll
-    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh[C & 1], acc[f][C], 0, 0, 0);
-    dma_slot<(4 * FN + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, FN, C>(dma);
+    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh[me], acc[f][C], 0, 0, 0);
+    if constexpr (PLM_PIPE && C == MID) {   // see fwd_state
+        vm_wait<0>();
+        barrier_raw();
+    }
+    dma_at<FN, C, NP, PLM_DMA_STAGGER_BWD>(dma);
 #pragma unroll
-    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl[C & 1], acc[f][C], 0, 0, 0);
-#if PLM_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl[me], acc[f][C], 0, 0, 0);
 }
-template <int FM, int FN, int... C>
-__device__ __forceinline__ void bwd_kstep(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb,
-                                          const DmaPlan &dma, std::integer_sequence<int, C...>) {
-    half8 bh[2], bl[2];
-    bh[0] = lds_read_b128<0>(lb);
-    bl[0] = lds_read_b128<1024>(lb);
-    (bwd_col<FM, FN, C>(acc, af, lb, bh, bl, dma), ...);
+template <int FM, int FN, int PAR, int... C>
+__device__ __forceinline__ void bwd_kstep(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb, u32 lbn,
+                                          half8 (&bh)[2], half8 (&bl)[2], const DmaPlan &dma,
+                                          std::integer_sequence<int, C...>) {
+    if constexpr (!PLM_PIPE) {
+        bh[PAR] = lds_read_b128<0>(lb);
+        bl[PAR] = lds_read_b128<1024>(lb);
+    }
+    (bwd_col<FM, FN, C, PAR>(acc, af, lb, lbn, bh, bl, dma), ...);
 }
 
 template <int Q, int FM, int FN>
@@ -797,6 +806,7 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
                                             const char *__restrict__ Rt, float *__restrict__ G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 2 * FN * 2 * 1024;  // 2*FN col fragments x 2 planes
+    constexpr int NBUF = PLM_NBUF, NP = (4 * FN + 7) / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to be wave-uniform
     const int wm = wave >> 1, wn = wave & 1;
@@ -814,7 +824,8 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
     const int j16 = row_ok ? mf0 / Q : 0, b0 = row_ok ? mf0 % Q : 0;
     const int nfl0 = col_tile * 2 * FN;
     const int r = lane & 15, g = lane >> 4;
-    const int8_t *acol = msa_cm + (size_t)(j16 * 16 + r) * d.Np + 8 * g;
+    // A operand: byte offset of this lane's site row in msa_cm (< 2^31: (nb16 + 1) * 16 * Np bytes)
+    const u32 acol = (u32)(j16 * 16 + r) * (u32)d.Np + 8 * g;
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -822,67 +833,88 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
 #pragma unroll
         for (int c = 0; c < FN; c++) acc[f][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int ss, int buf) {
-        char *dst = smem + buf * TILE;
-        for (int p = wave; p < 4 * FN; p += 8) {
-            const int c = p >> 1;   // col fragment within tile, plane = p & 1 (contiguous in Rt)
-            if (nfl0 + c < d.nnfl) {
-                const char *src = Rt + ((size_t)ss * d.nnfl + nfl0) * 2048 + (size_t)p * 1024 + lane * 16;
-#if PLM_STAGE_GLDS
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + p * 1024), 16, 0, 0);
-#else
-                *(float4 *)(dst + p * 1024 + lane * 16) = *(const float4 *)src;
-#endif
-            }
-        }
-    };
 #if PLM_PROBE
-    unsigned long long pr_vm = 0, pr_bar = 0, pr_mm = 0;
+    unsigned long long pr_wait = 0;
     const unsigned long long pr_t0 = PROBE_NOW();
 #endif
-    constexpr int NBUF = PLM_NBUF, AHEAD = NBUF - 1;   // the tile of step ss + AHEAD is copied during step ss
+    // tile of step ss: 2*FN column fragments x 2 planes, contiguous in Rt; fragments past nnfl are not copied
     const int np_valid = min(4 * FN, 2 * (d.nnfl - nfl0));
-    const int mine = (np_valid > wave_s) ? (np_valid - wave_s + 7) / 8 : 0;   // pieces this wave copies per step
-    for (int k = 0; k < AHEAD; k++)
-        if (k0 + k < k1) stage(k0 + k, k);
-    u64 nx = (k0 < k1) ? *(const u64 *)(acol + (size_t)32 * k0) : 0ull;   // bytes of the next step (in place)
-    int cur = 0;
-    for (int ss = k0; ss < k1; ++ss) {
-        // own LDS-DMA pieces of THIS step's tile landed (see k_fwd); with the ring of 3 the pieces issued
-        // during the previous step (tile ss+1) are newer and may stay in flight
-#if PLM_PROBE
-        const unsigned long long pa = PROBE_NOW();
-#endif
-        if (NBUF == 3 && ss > k0 && ss + 1 < k1) vm_wait_keep(mine);
-        else vm_wait<0>();
-#if PLM_PROBE
-        const unsigned long long pb = PROBE_NOW();
-#endif
+    const char *rt0 = Rt + (size_t)nfl0 * 2048;
+    const size_t rt_step = (size_t)d.nnfl * 2048;
+    for (int k = 0; k < NBUF - 1; k++)
+        if (k0 + k < k1) {
+            const DmaPlan first{rt0 + (size_t)(k0 + k) * rt_step, smem + k * TILE, wave_s, np_valid, (u32)lane * 16, false};
+            dma_issue_all<NP>(first);
+        }
+    u64 nx = (k0 < k1) ? *(const u64 *)(msa_cm + acol + (size_t)32 * k0) : 0ull;   // bytes of the next step (in place)
+    half8 bh[2], bl[2];
+    const u32 lw = lds_addr(smem + (wn * FN) * 2048 + lane * 16);   // this wave's columns in buffer 0
+    // the same register serves as the per-lane part of the LDS-DMA source address: lw = lane * 16 + lw_base
+    const u32 lw_base = __builtin_amdgcn_readfirstlane(lw - (u32)lane * 16);
+    if constexpr (PLM_PIPE) {
+        vm_wait<0>();
         __syncthreads();
-#if PLM_PROBE
-        const unsigned long long pc = PROBE_NOW();
-        pr_vm += pb - pa;
-        pr_bar += pc - pb;
-#endif
-        vm_landed(nx);
-        const u64 xa = nx;
-        if (ss + 1 < k1) load_b64_inplace(nx, acol + (size_t)32 * (ss + 1));
-        const int nb = (cur + AHEAD >= NBUF) ? cur + AHEAD - NBUF : cur + AHEAD;
-        const DmaPlan dma{Rt + ((size_t)(ss + AHEAD) * d.nnfl + nfl0) * 2048, smem + nb * TILE, wave_s,
-                          (ss + AHEAD < k1 && PLM_IS_LOADER(wave_s)) ? np_valid : 0, (u32)lane * 16};
         if (row_ok) {
-            const char *lb = smem + cur * TILE + (wn * FN) * 2048 + lane * 16;
+            bh[0] = lds_read_b128<0>(lw);
+            bl[0] = lds_read_b128<1024>(lw);
+        }
+    }
+    int cur = 0, ss = k0;
+    // one K step; PAR = slot that holds column 0 of this step
+    auto step = [&](auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        if constexpr (!PLM_PIPE) {
+#if PLM_PROBE
+            const unsigned long long pa = PROBE_NOW();
+#endif
+            if constexpr ((PLM_ABLATE & 1) == 0) {
+                vm_wait<0>();
+                __syncthreads();
+            }
+#if PLM_PROBE
+            pr_wait += PROBE_NOW() - pa;
+#endif
+        }
+        const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
+        const int tgt = PLM_PIPE ? ((nxt + 1 == NBUF) ? 0 : nxt + 1) : nxt;   // buffer of step ss + NBUF - 1
+        const DmaPlan dma{rt0 + (size_t)(ss + NBUF - 1) * rt_step - lw_base, smem + tgt * TILE, wave_s,
+                          (ss + NBUF - 1 < k1) ? np_valid : 0, lw, wave_s >= 4};
+        if (row_ok) {
+            vm_landed(nx);
+            const u64 xa = nx;
+            if (ss + 1 < k1) load_b64_inplace(nx, msa_cm, acol + 32 * (u32)(ss + 1));
             half8 af[FM];
 #pragma unroll
-            for (int f = 0; f < FM; f++) af[f] = onehot8((u32)xa, (u32)(xa >> 32), (u32)(b0 + f) * 0x01010101u);
-            bwd_kstep<FM, FN>(acc, af, lds_addr(lb), dma, std::make_integer_sequence<int, FN>{});
-        } else {
-            dma_slot<(4 * FN + PLM_DMA_WAVES - 1) / PLM_DMA_WAVES, 1, 0>(dma);   // idle row waves still copy their share
-        }
-        cur = (cur + 1 == NBUF) ? 0 : cur + 1;
-#if PLM_PROBE
-        pr_mm += PROBE_NOW() - pc;
+            for (int f = 0; f < FM; f++) {
+#if !(PLM_ABLATE & 8)
+                af[f] = onehot8((u32)xa, (u32)(xa >> 32), (u32)(b0 + f) * 0x01010101u);
+#else
+                ((u32 *)&af[f])[0] = (u32)xa; ((u32 *)&af[f])[1] = (u32)(xa >> 32); ((u32 *)&af[f])[2] = b0 + f; ((u32 *)&af[f])[3] = (u32)xa;
 #endif
+            }
+            bwd_kstep<FM, FN, PAR>(acc, af, lw + cur * TILE, lw + nxt * TILE, bh, bl, dma,
+                                   std::make_integer_sequence<int, FN>{});
+        } else {            // idle row waves still take part in the barrier and copy their share
+            if constexpr (PLM_PIPE) {
+                vm_wait<0>();
+                barrier_raw();
+            }
+            dma_issue_all<NP>(dma);
+        }
+        cur = nxt;
+        ++ss;
+    };
+    while (ss < k1) {
+        step(std::integral_constant<int, 0>{});
+        if constexpr (PLM_PIPE && (FN & 1)) {
+            if (ss < k1) step(std::integral_constant<int, 1>{});
+        }
+    }
+    if constexpr (PLM_PIPE) {   // a fragment read past the last step may still be in flight
+        if (row_ok) {
+            lds_wait<0>(bh[0], bl[0]);
+            lds_wait<0>(bh[1], bl[1]);
+        }
     }
 #if PLM_PROBE
     const unsigned long long pr_t1 = PROBE_NOW();
@@ -899,8 +931,7 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
 #if PLM_PROBE
     if (lane == 0) {
         const unsigned long long pr_t2 = PROBE_NOW();
-        atomicAdd(&plm_probe_acc[1][0], pr_vm); atomicAdd(&plm_probe_acc[1][1], pr_bar);
-        atomicAdd(&plm_probe_acc[1][2], pr_mm); atomicAdd(&plm_probe_acc[1][3], pr_t2 - pr_t0);
+        atomicAdd(&plm_probe_acc[1][0], pr_wait); atomicAdd(&plm_probe_acc[1][3], pr_t2 - pr_t0);
         atomicAdd(&plm_probe_acc[1][4], pr_t2 - pr_t1); atomicAdd(&plm_probe_acc[1][5], 1ull);
     }
 #endif

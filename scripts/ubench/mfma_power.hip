@@ -26,7 +26,10 @@ template <> struct Tr<2> { typedef i32x4 C; typedef i32x4 AB; static constexpr i
 template <> struct Tr<3> { typedef i32x16 C; typedef i32x4 AB; static constexpr int NACC = 12; static constexpr double OPS = 2.0 * 32 * 32 * 32;
     static __device__ C mma(AB a, AB b, C c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); } };
 
-template <int MODE>
+// DEP = 0: every MFMA of an iteration has its own accumulator.  DEP = d > 0: the accumulators are visited
+// in groups of d, each group twice in a row (a0 a1 .. a0 a1 ..): the dependent MFMA follows d instructions
+// later, the pattern of the hi/lo planes in k_fwd (d = 2) and k_bwd (d = 7).
+template <int MODE, int DEP>
 __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ adata, const uint4 *__restrict__ bdata, int iters, Out *out) {
     typedef Tr<MODE> T;
     typename T::C acc[T::NACC];
@@ -39,8 +42,18 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ adata, const 
     for (int i = 0; i < 4; i++) { uint4 v = bdata[(tid * 4 + i) & 0xffff]; b[i] = *(typename T::AB *)&v; }
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int it = 0; it < iters; it++) {
+        if constexpr (DEP == 0) {
 #pragma unroll
-        for (int i = 0; i < T::NACC; i++) acc[i] = T::mma(a[i % 3], b[i & 3], acc[i]);
+            for (int i = 0; i < T::NACC; i++) acc[i] = T::mma(a[i % 3], b[i & 3], acc[i]);
+        } else {
+#pragma unroll
+            for (int g0 = 0; g0 + DEP <= T::NACC / 2; g0 += DEP) {
+#pragma unroll
+                for (int i = 0; i < DEP; i++) acc[g0 + i] = T::mma(a[i % 3], b[0], acc[g0 + i]);
+#pragma unroll
+                for (int i = 0; i < DEP; i++) acc[g0 + i] = T::mma(a[i % 3], b[1], acc[g0 + i]);
+            }
+        }
         // rotate the B registers so the operands change like streamed fragments do
         typename T::AB t = b[0]; b[0] = b[1]; b[1] = b[2]; b[2] = b[3]; b[3] = t;
     }
@@ -53,23 +66,24 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ adata, const 
     if (s == 12345.678f) out->sink = s;
 }
 
-template <int MODE> void run(const char *name, const uint4 *a, const uint4 *b, Out *dout, double ms_target, const char *what) {
+template <int MODE, int DEP = 0> void run(const char *name, const uint4 *a, const uint4 *b, Out *dout, double ms_target, const char *what) {
     typedef Tr<MODE> T;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     int iters = 2000;
     float ms = 0;
     for (int pass = 0; pass < 3; pass++) {
         hipEventRecord(e0);
-        for (int r = 0; r < (pass == 2 ? 5 : 1); r++) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, a, b, iters, dout);
+        for (int r = 0; r < (pass == 2 ? 5 : 1); r++) hipLaunchKernelGGL((k<MODE, DEP>), dim3(256), dim3(512), 0, 0, a, b, iters, dout);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         if (pass == 0) iters = (int)(iters * ms_target / ms);
     }
     ms /= 5;
     Out o; hipMemcpy(&o, dout, sizeof o, hipMemcpyDeviceToHost);
-    const double nm = 256.0 * 8 * (double)iters * T::NACC;
+    const double per_iter = DEP == 0 ? T::NACC : 2 * DEP * ((T::NACC / 2) / DEP);
+    const double nm = 256.0 * 8 * (double)iters * per_iter;
     printf("%-14s %-10s %7.3f ms  %8.1f Tops/s   %5.1f cyc/MFMA/SIMD  clock %.2f GHz (s_memtime/wall_clock)\n", name, what, ms,
-           nm * T::OPS / (ms * 1e-3) / 1e12, (double)o.cyc / ((double)iters * T::NACC * 2), (double)o.cyc / ((double)o.wall * 10.0) );
+           nm * T::OPS / (ms * 1e-3) / 1e12, (double)o.cyc / ((double)iters * per_iter * 2), (double)o.cyc / ((double)o.wall * 10.0) );
 }
 
 int main(int argc, char **argv) {
@@ -97,6 +111,15 @@ int main(int argc, char **argv) {
     const std::vector<uint4> *src[6] = {&az, &bf, &bi, &asp16, &asp8, &bz};
     for (int i = 0; i < 6; i++) { hipMalloc(&d[i], n * 16); hipMemcpy(d[i], src[i]->data(), n * 16, hipMemcpyHostToDevice); }
     hipMalloc(&dout, sizeof(Out));
+    if (argc > 2) {   // dependency-distance study on the one-hot case
+        run<0, 0>("f16 16x16x32", d[3], d[1], dout, ms, "indep");
+        run<0, 1>("f16 16x16x32", d[3], d[1], dout, ms, "dep d=1");
+        run<0, 2>("f16 16x16x32", d[3], d[1], dout, ms, "dep d=2");
+        run<0, 4>("f16 16x16x32", d[3], d[1], dout, ms, "dep d=4");
+        run<0, 7>("f16 16x16x32", d[3], d[1], dout, ms, "dep d=7");
+        run<0, 12>("f16 16x16x32", d[3], d[1], dout, ms, "dep d=12");
+        return 0;
+    }
     for (int rep = 0; rep < 2; rep++) {
         run<0>("f16 16x16x32", d[0], d[5], dout, ms, "zeros");
         run<0>("f16 16x16x32", d[3], d[1], dout, ms, "onehot*dense");
