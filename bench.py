@@ -85,12 +85,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    # PLM_DIST_BACKEND=gloo: collectives staged through host memory and ranks folded onto the visible GPUs --
+    # exercises this multi-rank flow on a single-GPU box (never used for a reported number)
+    backend = os.environ.get("PLM_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     q, L, N = HEADLINE["q"], args.n_sites, args.n_seqs
     msa, _ = synthetic_msa(N, L, seed=BASE_SEED + HEADLINE["seed_offset"])
@@ -106,12 +111,13 @@ def main():
     if world > 1:
         # sharded-state mode: parameters, gradient and L-BFGS state split by owning site block; per
         # evaluation two all-to-alls of neighbour blocks + scalar all-reduces over RCCL
-        from evcouplings_amd.dist import make_torch_collective
+        from evcouplings_amd.dist import make_torch_collective, make_host_staged_collective
         x0 = ctx1.get_x()
         ctx1.close()
         ctx = plm.PlmContext(msa, q=q, lambda_h=0.01, lambda_j=lam_j, device=local_rank, n_shards=world,
                              shard=rank, max_iter=args.warmup, epsilon=1e-12, sharded_state=True)
-        ctx.set_collective(make_torch_collective())
+        ctx.set_collective(make_torch_collective() if backend == "nccl" else
+                           make_host_staged_collective(device=local_rank))
         ctx.set_weights(w)
         ctx.set_x(x0)
     else:
@@ -141,7 +147,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda")
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert res["iters"] == args.steps, res
@@ -162,7 +168,8 @@ def main():
         "config": {"workload": "headline: synthetic MSA L=%d q=%d N=%d, theta=0.8, lambda_h=0.01, lambda_J=%.1f"
                                % (L, q, N, lam_j),
                    "n_eff": n_eff,
-                   "parallelism": "single GPU" if world == 1 else "sites + state sharded x%d (RCCL all-to-all)" % world,
+                   "parallelism": "single GPU" if world == 1 else "sites + state sharded x%d (%s)" % (
+                       world, "RCCL all-to-all" if backend == "nccl" else "gloo, host-staged: flow test only"),
                    "evals_per_iteration": res["n_evals"] / max(1, res["iters"])},
     }
 

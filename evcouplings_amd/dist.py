@@ -123,12 +123,52 @@ def make_torch_collective(group=None):
     return collective
 
 
-def fit_distributed(msa, q=21, group=None, sharded_state=True, **kwargs):
+def make_host_staged_collective(group=None, device=0):
+    """
+    The same three collectives staged through host memory, for a process group whose backend cannot touch
+    device buffers (gloo): ranks that share one GPU, or a host without RCCL peer access.  Slow path -- used to
+    exercise the multi-process flow of bench.py / fit_distributed on a single-GPU box.
+    """
+    import torch
+    from evcouplings_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipSetDevice.argtypes = [C.c_int]
+
+    def d2h(ptr, nbytes):
+        host = np.empty(max(1, nbytes), np.uint8)
+        if nbytes and hip.hipMemcpy(host.ctypes.data, C.c_void_p(ptr), nbytes, 2) != 0:
+            raise RuntimeError("hipMemcpy device->host failed")
+        return host[:nbytes]
+
+    def h2d(ptr, host):
+        if host.size and hip.hipMemcpy(C.c_void_p(ptr), host.ctypes.data, host.size, 1) != 0:
+            raise RuntimeError("hipMemcpy host->device failed")
+
+    def collective(op, send_ptr, recv_ptr, send_counts, recv_counts, n_shards, shard):
+        hip.hipSetDevice(device)
+        if op == _lib.COLL_ALLTOALL:
+            send = torch.from_numpy(d2h(send_ptr, sum(send_counts)))
+            recv = torch.empty(sum(recv_counts), dtype=torch.uint8)
+            collective_on_tensors(op, send, recv, send_counts, recv_counts, group=group)
+            h2d(recv_ptr, np.ascontiguousarray(recv.numpy()))
+        else:
+            buf = torch.from_numpy(d2h(send_ptr, send_counts[0]).copy())
+            collective_on_tensors(op, buf, None, send_counts, recv_counts, group=group)
+            h2d(send_ptr, buf.numpy())
+        return 0
+
+    return collective
+
+
+def fit_distributed(msa, q=21, group=None, sharded_state=True, transport="rccl", **kwargs):
     """
     plm.fit on every rank of an initialised process group, sites sharded across ranks.
     sharded_state=True (default): parameters, gradient and L-BFGS state are split by owning site block;
     per evaluation two all-to-alls of neighbour blocks + scalar all-reduces.  False: replicated state,
     one all-gather of the gradient slabs per evaluation.
+    transport "rccl": collectives on the library's device buffers (backend nccl); "host": staged through
+    host memory (backend gloo; sharded-state mode only).
     """
     import torch
     import torch.distributed as dist
@@ -138,8 +178,10 @@ def fit_distributed(msa, q=21, group=None, sharded_state=True, **kwargs):
     if world == 1:
         return plm.fit(msa, q=q, device=device, **kwargs)
     if sharded_state:
-        return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device,
-                       collective=make_torch_collective(group), **kwargs)
+        coll = make_torch_collective(group) if transport == "rccl" else make_host_staged_collective(group, device)
+        return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device, collective=coll, **kwargs)
+    if transport != "rccl":
+        raise ValueError("replicated-state mode needs the rccl transport")
     return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device, exchange=make_torch_exchange(group),
                    **kwargs)
 

@@ -463,3 +463,28 @@ def test_sharded_state_fit_matches_single_gpu(plm, n_shards):
     ref = plm.fit(msa, Q, max_iter=3000, epsilon=2e-6)
     outs = ThreadedShards(n_shards).fit(msa, q=Q, max_iter=3000, epsilon=2e-6)
     np.testing.assert_allclose(outs[0]["cn"], ref["cn"], atol=1e-5)
+
+
+def test_two_process_fit_over_gloo(plm, tmp_path):
+    """The multi-process flow of fit_distributed / bench.py --gpus N: two torch.distributed.run ranks share GPU 0,
+    collectives staged through host memory (gloo).  Must reproduce the in-process sharded fit exactly."""
+    import socket
+    import subprocess
+    import sys
+    from evcouplings_amd.dist import ThreadedShards
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "mp_fit.npz")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp_fit_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), worker, out]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    got = np.load(out)
+    msa, _ = synthetic_msa(600, 70, seed=11)
+    ref = ThreadedShards(2).fit(msa, q=Q, lambda_h=0.01, lambda_j=plm.default_lambda_j(70, Q), max_iter=25,
+                                epsilon=1e-9, want_fij=False)[0]
+    assert int(got["iters"]) == ref["iters"] == 25
+    np.testing.assert_array_equal(got["jij"], ref["jij"])     # same library code, same reduction order
+    np.testing.assert_array_equal(got["cn"], ref["cn"])
