@@ -1106,6 +1106,73 @@ int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_ou
     return PLM_OK;
 }
 
+// statistical energies / potentials of n sequences under a model: upload, canonical -> native, expand,
+// forward GEMM with the energy epilogue (no weights, no backward pass, no optimiser state)
+static int energies_impl(const int8_t *seqs, int32_t n, int32_t L, int32_t q, const float *x_canon, int device,
+                         void *stream, int potentials, void *out_host) {
+    if (!seqs || !x_canon || !out_host) return fail(PLM_EINVAL, "NULL argument");
+    PLM_TRY(check_device(device));
+    plm_problem_t p = basic_problem(seqs, n, L, q);
+    PlmDims d;
+    PLM_TRY(make_dims(p, &d));
+    if ((int64_t)(d.Np + 32) * d.Lp32 >= (int64_t)1 << 31) return fail(PLM_EINVAL, "too many sequences for one call");
+    for (size_t k = 0; k < (size_t)n * L; k++)
+        if (seqs[k] < 0 || seqs[k] >= q) return fail(PLM_EINVAL, "seqs[%zu] = %d outside 0..%d", k, (int)seqs[k], q - 1);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rm_rows = (size_t)d.Np + 32;
+    std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE);
+    for (int s = 0; s < d.N; s++) memcpy(&rm[(size_t)s * d.Lp32], seqs + (size_t)s * d.L, d.L);
+    const int nblk = d.b16_hi - d.b16_lo;
+    const size_t out_dev_floats = potentials ? (size_t)d.N * d.L * d.Q : (size_t)d.Np * nblk * 2;
+    int8_t *msa_rm = nullptr;
+    float *canon = nullptr, *x = nullptr, *outd = nullptr;
+    char *Bt = nullptr;
+    uint32_t *maxbits = nullptr;
+    int32_t *jexp = nullptr;
+    double *en = nullptr;
+    auto cleanup = [&](int code) {
+        void *all[] = {msa_rm, canon, x, outd, Bt, maxbits, jexp, en};
+        for (void *b : all)
+            if (b) (void)hipFree(b);
+        return code;
+    };
+    int rc;
+    if ((rc = dalloc(&msa_rm, rm.size())) || (rc = dalloc(&canon, (size_t)d.n_canon)) ||
+        (rc = dalloc(&x, (size_t)d.n_native)) || (rc = dalloc(&outd, out_dev_floats)) ||
+        (rc = dalloc(&Bt, plm_bt_bytes(d))) || (rc = dalloc(&maxbits, (size_t)1)) || (rc = dalloc(&jexp, (size_t)1)) ||
+        (rc = dalloc(&en, (size_t)d.N * 3)))
+        return cleanup(rc);
+    hipError_t e;
+#define ET(expr)                                                                                   \
+    if ((e = (expr)) != hipSuccess)                                                                \
+        return cleanup(fail(PLM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e)));
+    ET(hipMemcpyAsync(msa_rm, rm.data(), rm.size(), hipMemcpyHostToDevice, st));
+    ET(hipMemcpyAsync(canon, x_canon, sizeof(float) * d.n_canon, hipMemcpyHostToDevice, st));
+    ET(hipMemsetAsync(x, 0, sizeof(float) * d.n_native, st));
+    ET(plm_launch_canon_to_native(d, canon, x, st));
+    ET(plm_launch_maxabs(d, x, maxbits, jexp, st));
+    ET(plm_launch_expand(d, x, nullptr, jexp, Bt, st));
+    ET(plm_launch_forward_energy(d, msa_rm, Bt, x, jexp, potentials, outd, st));
+    if (potentials) {
+        ET(hipMemcpyAsync(out_host, outd, sizeof(float) * out_dev_floats, hipMemcpyDeviceToHost, st));
+    } else {
+        ET(plm_launch_energy_sum(d, outd, en, st));
+        ET(hipMemcpyAsync(out_host, en, sizeof(double) * (size_t)d.N * 3, hipMemcpyDeviceToHost, st));
+    }
+    ET(hipStreamSynchronize(st));
+#undef ET
+    return cleanup(PLM_OK);
+}
+
+int plm_hamiltonians(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_states, const float *x_canonical,
+                     int device, void *stream, double *energies_out) {
+    return energies_impl(seqs, n, n_sites, n_states, x_canonical, device, stream, 0, energies_out);
+}
+int plm_potentials(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_states, const float *x_canonical,
+                   int device, void *stream, float *potentials_out) {
+    return energies_impl(seqs, n, n_sites, n_states, x_canonical, device, stream, 1, potentials_out);
+}
+
 static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,
                     void *iter_user, plm_exchange_cb exchange, void *exchange_user, plm_collective_cb collective,
                     void *collective_user) {

@@ -83,6 +83,10 @@ hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhal
 hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
                               const float *x, const int32_t *jexp, void *Rt, double *fx_part,
                               hipStream_t st);
+// statistical energies of sequences under a model (k_fwd modes 1/2)
+hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
+                                     const int32_t *jexp, int potentials, float *out, hipStream_t st);
+hipError_t plm_launch_energy_sum(const PlmDims &d, const float *part, double *out, hipStream_t st);
 hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G,
                                hipStream_t st);
 hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab, hipStream_t st);

@@ -496,7 +496,15 @@ struct FwdArgs {
     _Float16 *Rt;
     double *fx_part;
     float rscale;
+    float *out;           // MODE 1: float2 [Np][blocks] energy partials; MODE 2: potentials [N][L][Q]
 };
+// k_fwd MODE: 0 = conditional softmax, residuals, -log P (the solver).  The same GEMM also yields the
+// statistical energies of sequences under a fitted model (reference twins
+// couplings/model.py:25-60 _hamiltonians and :63-109 _single_mutant_hamiltonians):
+// 1 = per (sequence, site block) the pair (sum_i HJ[s,i,x_si], sum_i h_i(x_si)) with
+//     HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj); 2 = the potentials HJ[s,i,a] themselves.
+enum { FWD_SOLVER = 0, FWD_ENERGY = 1, FWD_POTENTIALS = 2 };
+
 
 // one K step of the forward GEMM for one wave: Q states x (hi, lo) planes x 2 row fragments.
 // The B fragments of state A+2 are issued before state A computes.  The fragment registers form a ring of
@@ -545,7 +553,7 @@ __device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, c
     (fwd_state<Q, A>(acc, a0, a1, lb, lbn, bh, bl, dma), ...);
 }
 
-template <int Q>
+template <int Q, int MODE>
 __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (guide 5/4a)
     constexpr int TILE = 2 * Q * 1024, NBUF = PLM_NBUF, NP = (2 * Q + 7) / 8, R = FwdRing<Q>::R;
@@ -644,6 +652,53 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     const unsigned long long pr_t1 = PROBE_NOW();
 #endif
 
+    if constexpr (MODE != FWD_SOLVER) {
+        // ---- statistical energies / potentials of the given sequences (no softmax) ------------
+        const float sc = ldexpf(1.f, -(*A.jexp));
+        const int i = b16 * 16 + r;
+        const bool site_ok = i < d.L;
+        if constexpr (MODE == FWD_ENERGY) {
+            float hv[Q];
+#pragma unroll
+            for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
+            const int nblk = d.b16_hi - d.b16_lo;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int s = s_wave + 16 * m + 4 * g + reg;
+                    const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
+                    float ej = 0.f, eh = 0.f;
+#pragma unroll
+                    for (int a = 0; a < Q; a++) {
+                        ej = (a == xi) ? acc[m][a][reg] : ej;
+                        eh = (a == xi) ? hv[a] : eh;
+                    }
+                    ej *= sc;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {   // sum over the 16 sites of the block (lanes r)
+                        ej += __shfl_xor(ej, o, 64);
+                        eh += __shfl_xor(eh, o, 64);
+                    }
+                    if (r == 0) *(float2 *)(A.out + ((size_t)s * nblk + b16l) * 2) = make_float2(ej, eh);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int s = s_wave + 16 * m + 4 * g + reg;
+                    if (site_ok && s < d.N) {
+                        float *o = A.out + ((size_t)s * d.L + i) * Q;
+#pragma unroll
+                        for (int a = 0; a < Q; a++) o[a] = acc[m][a][reg] * sc;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #if PLM_ABLATE & 16
     float fxl = 0.f;   // timing experiment: consume the accumulators, skip the real epilogue
 #pragma unroll
@@ -722,23 +777,27 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
 #endif
 }
 
-hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
-                              const float *x, const int32_t *jexp, void *Rt, double *fx_part, hipStream_t st) {
+static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    FwdArgs A{msa_rm, w, (const char *)Bt, x, jexp, (_Float16 *)Rt, fx_part, ldexpf(1.f, PLM_R_EXP)};
     const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
     const size_t lds = (size_t)PLM_NBUF * 2 * d.Q * 1024;
-#define FWD_CASE(QQ)                                                                                   \
-    case QQ: {                                                                                         \
+#define FWD_LAUNCH(QQ, MM)                                                                             \
+    {                                                                                                  \
         static bool attr_done = false;                                                                 \
         if (!attr_done) {                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void *)k_fwd<QQ>,                                \
+            hipError_t e = hipFuncSetAttribute((const void *)k_fwd<QQ, MM>,                            \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             if (e != hipSuccess) return e;                                                             \
             attr_done = true;                                                                          \
         }                                                                                              \
-        hipLaunchKernelGGL(k_fwd<QQ>, grid, block, lds, st, d, A);                                     \
-    } break;
+        hipLaunchKernelGGL((k_fwd<QQ, MM>), grid, block, lds, st, d, A);                               \
+    }
+#define FWD_CASE(QQ)                                                                                   \
+    case QQ:                                                                                           \
+        if (mode == FWD_SOLVER) FWD_LAUNCH(QQ, FWD_SOLVER)                                             \
+        else if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                        \
+        else FWD_LAUNCH(QQ, FWD_POTENTIALS)                                                            \
+        break;
     switch (d.Q) {
         FWD_CASE(21)
         FWD_CASE(20)
@@ -748,6 +807,40 @@ hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const floa
         return hipErrorInvalidValue;
     }
 #undef FWD_CASE
+#undef FWD_LAUNCH
+    return hipGetLastError();
+}
+hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
+                              const float *x, const int32_t *jexp, void *Rt, double *fx_part, hipStream_t st) {
+    const FwdArgs A{msa_rm, w, (const char *)Bt, x, jexp, (_Float16 *)Rt, fx_part, ldexpf(1.f, PLM_R_EXP), nullptr};
+    return launch_forward_mode(d, A, FWD_SOLVER, st);
+}
+// statistical energies: mode 1 -> out = float2 [Np][blocks] partial sums, mode 2 -> out = potentials [N][L][Q]
+hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
+                                     const int32_t *jexp, int potentials, float *out, hipStream_t st) {
+    const FwdArgs A{msa_rm, nullptr, (const char *)Bt, x, jexp, nullptr, nullptr, 0.f, out};
+    return launch_forward_mode(d, A, potentials ? FWD_POTENTIALS : FWD_ENERGY, st);
+}
+// out[s] = (E, E_J, E_h) in f64 from the per-block partials: E_J = 1/2 sum_i HJ[s,i,x_si] (every pair is seen
+// from both of its sites), E_h = sum_i h_i(x_si)
+__global__ __launch_bounds__(256) void k_energy_sum(const float2 *__restrict__ part, int n, int nblk,
+                                                   double *__restrict__ out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    double ej = 0, eh = 0;
+    for (int b = 0; b < nblk; b++) {
+        const float2 v = part[(size_t)s * nblk + b];
+        ej += v.x;
+        eh += v.y;
+    }
+    ej *= 0.5;
+    out[(size_t)s * 3 + 0] = ej + eh;
+    out[(size_t)s * 3 + 1] = ej;
+    out[(size_t)s * 3 + 2] = eh;
+}
+hipError_t plm_launch_energy_sum(const PlmDims &d, const float *part, double *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_energy_sum, dim3((d.N + 255) / 256), dim3(256), 0, st, (const float2 *)part, d.N,
+                       d.b16_hi - d.b16_lo, out);
     return hipGetLastError();
 }
 

@@ -85,6 +85,53 @@ def scores(jij, L, q):
     return fn, cn
 
 
+def _canonical(hi, jij, L, q):
+    """h [L][q] followed by the i<j coupling blocks [q][q]: the canonical parameter vector."""
+    hi = np.ascontiguousarray(hi, dtype=np.float32).reshape(L * q)
+    jij = np.ascontiguousarray(jij, dtype=np.float32).reshape(L * (L - 1) // 2 * q * q)
+    return np.concatenate([hi, jij])
+
+
+def hamiltonians(seqs, q, hi, jij, device=0):
+    """
+    Statistical energies of sequences under a model: n x 3 float64 (H, H_J, H_h) with
+    H_J = sum_{i<j} J_ij(x_i, x_j), H_h = sum_i h_i(x_i) -- the return value of the reference's
+    `_hamiltonians(sequences, J_ij, h_i)` (couplings/model.py:25-60), computed by the forward one-hot GEMM.
+    seqs: n x L integer states; hi: L x q; jij: the i<j blocks [L(L-1)/2][q][q].
+    """
+    lib = _lib.load()
+    seqs = _msa(seqs)
+    n, L = seqs.shape
+    out = np.zeros((n, 3))
+    check(lib.plm_hamiltonians(_ptr(seqs), n, L, q, _ptr(_canonical(hi, jij, L, q)), device, None, _ptr(out)))
+    return out
+
+
+def potentials(seqs, q, hi, jij, device=0):
+    """HJ[s, i, a] = sum_{j != i} J_ij(a, x_sj): n x L x q float32 (coupling part of every conditional)."""
+    lib = _lib.load()
+    seqs = _msa(seqs)
+    n, L = seqs.shape
+    out = np.zeros((n, L, q), dtype=np.float32)
+    check(lib.plm_potentials(_ptr(seqs), n, L, q, _ptr(_canonical(hi, jij, L, q)), device, None, _ptr(out)))
+    return out
+
+
+def single_mutant_matrix(target, q, hi, jij, device=0):
+    """
+    Energy differences of every single substitution of `target`: L x q x 3 float64 (dH, dH_J, dH_h), the
+    return value of the reference's `_single_mutant_hamiltonians` (couplings/model.py:63-109).
+    """
+    target = np.ascontiguousarray(target, dtype=np.int8).reshape(1, -1)
+    L = target.shape[1]
+    hj = potentials(target, q, hi, jij, device=device)[0].astype(np.float64)
+    hi = np.asarray(hi, dtype=np.float64).reshape(L, q)
+    rows = np.arange(L)
+    dj = hj - hj[rows, target[0]][:, None]
+    dh = hi - hi[rows, target[0]][:, None]
+    return np.stack([dj + dh, dj, dh], axis=2)
+
+
 FLAG_IGNORE_GAPS = 2
 FLAG_SHARDED_STATE = 4
 

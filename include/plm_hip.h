@@ -151,6 +151,21 @@ int plm_eval(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_
 int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_out,
                float *cn_out);
 
+/* ---- statistical energies under a fitted model -------------------
+ * Replace the numba loops of evcouplings/couplings/model.py that the mutate stage and
+ * CouplingsModel.hamiltonians / .single_mut_mat call:
+ *   plm_hamiltonians  <->  _hamiltonians(sequences, J_ij, h_i)              model.py:25-60
+ *   plm_potentials    <->  the sums of _single_mutant_hamiltonians           model.py:63-109
+ * seqs: n x n_sites int8 states 0..q-1 (row-major); x_canonical: the model in the canonical
+ * layout (h [L][q], then J pair blocks i<j row-major [q][q] -- the plmc_v2 .model order).
+ * energies_out: n x 3 doubles (H, H_J, H_h) with H_J = sum_{i<j} J_ij(x_i,x_j), H_h = sum_i h_i(x_i).
+ * potentials_out: n x n_sites x q floats, HJ[s][i][a] = sum_{j != i} J_ij(a, x_sj); the single-mutant
+ * matrix of a sequence is dJ(i,a) = HJ[i][a] - HJ[i][x_i], dh(i,a) = h_i(a) - h_i(x_i).            */
+int plm_hamiltonians(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_states,
+                     const float *x_canonical, int device, void *stream, double *energies_out);
+int plm_potentials(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_states,
+                   const float *x_canonical, int device, void *stream, float *potentials_out);
+
 /* -- resident-context API (bench / multi-GPU host) ---------------------------------------- */
 /* Uploads the alignment once; everything below runs on data resident in HBM. */
 int plm_ctx_create(const plm_problem_t *problem, int device, void *stream, plm_ctx_t **out);

@@ -172,6 +172,32 @@ class Oracle:
             raise RuntimeError("oracle scores rc=%d" % rc)
         return fn, cn
 
+    def hamiltonians(self, seqs, q, x):
+        """n x 3 (H, H_J, H_h) of the sequences under the canonical parameter vector x (model.py:25-60)."""
+        seqs = self._msa(seqs)
+        n, L = seqs.shape
+        x = np.ascontiguousarray(x, dtype=self.real)
+        out = np.zeros((n, 3))
+        f = self._f("hamiltonians")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        rc = f(self._p(seqs), n, L, q, self._p(x), self._p(out))
+        if rc:
+            raise RuntimeError("oracle hamiltonians rc=%d" % rc)
+        return out
+
+    def single_mutants(self, target, q, x):
+        """L x q x 3 (dH, dH_J, dH_h) of every single substitution of `target` (model.py:63-109)."""
+        target = np.ascontiguousarray(target, dtype=np.int8)
+        L = target.size
+        x = np.ascontiguousarray(x, dtype=self.real)
+        out = np.zeros((L, q, 3))
+        f = self._f("single_mutants")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        rc = f(self._p(target), L, q, self._p(x), self._p(out))
+        if rc:
+            raise RuntimeError("oracle single_mutants rc=%d" % rc)
+        return out
+
     def fit(self, msa, q, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
             epsilon=1e-3, lbfgs_m=6, want_fij=True, callback=None, ignore_gaps=False):
         """ignore_gaps=True: plmc -g semantics of plm_oracle.c eval_gaps; all outputs have q-1 states."""

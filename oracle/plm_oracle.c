@@ -406,6 +406,58 @@ int PLMO_NAME(scores)(const real *jij, int L, int q, double *fn, double *cn) {
     return PLMO_OK;
 }
 
+/* Statistical energies of sequences under a model, following
+ * evcouplings/couplings/model.py:25-60 (_hamiltonians): for every sequence the sums
+ * H_h = sum_i h_i(x_i), H_J = sum_{i<j} J_ij(x_i, x_j), H = H_J + H_h, accumulated in double in
+ * the reference's loop order.  x = canonical vector (h [L][q], then i<j blocks [q][q]);
+ * out = n x 3 doubles (H, H_J, H_h) -- the reference's column order (FULL, COUPLINGS, FIELDS). */
+int PLMO_NAME(hamiltonians)(const int8_t *seqs, int n, int L, int q, const real *x, double *out) {
+    if (!seqs || !x || !out || L <= 1 || q <= 0) return PLMO_EINVAL;
+    const real *h = x, *jij = x + (size_t)L * q;
+    const size_t qq = (size_t)q * q;
+    for (int s = 0; s < n; s++) {
+        const int8_t *A = seqs + (size_t)s * L;
+        double hs = 0, js = 0;
+        for (int i = 0; i < L; i++) {
+            hs += h[(size_t)i * q + A[i]];
+            for (int j = i + 1; j < L; j++) js += jij[pair_index(i, j, L) * qq + (size_t)A[i] * q + A[j]];
+        }
+        out[(size_t)s * 3 + 0] = js + hs;
+        out[(size_t)s * 3 + 1] = js;
+        out[(size_t)s * 3 + 2] = hs;
+    }
+    return PLMO_OK;
+}
+
+/* All single-site substitutions of a target sequence, following
+ * evcouplings/couplings/model.py:63-109 (_single_mutant_hamiltonians):
+ * dh(i,a) = h_i(a) - h_i(t_i); dJ(i,a) = sum_{j != i} [J_ij(a, t_j) - J_ij(t_i, t_j)];
+ * out = L x q x 3 doubles (dJ + dh, dJ, dh). */
+int PLMO_NAME(single_mutants)(const int8_t *target, int L, int q, const real *x, double *out) {
+    if (!target || !x || !out || L <= 1 || q <= 0) return PLMO_EINVAL;
+    const real *h = x, *jij = x + (size_t)L * q;
+    const size_t qq = (size_t)q * q;
+    for (int i = 0; i < L; i++)
+        for (int a = 0; a < q; a++) {
+            const double dh = (double)h[(size_t)i * q + a] - (double)h[(size_t)i * q + target[i]];
+            double dj = 0;
+            for (int j = 0; j < L; j++) {
+                if (j == i) continue;
+                /* J_ij(a, b) for i > j is the transposed block of the stored pair (j, i) */
+                const real *blk = (i < j) ? jij + pair_index(i, j, L) * qq : jij + pair_index(j, i, L) * qq;
+                const double v_new = (i < j) ? blk[(size_t)a * q + target[j]] : blk[(size_t)target[j] * q + a];
+                const double v_old = (i < j) ? blk[(size_t)target[i] * q + target[j]]
+                                             : blk[(size_t)target[j] * q + target[i]];
+                dj += v_new - v_old;
+            }
+            double *o = out + ((size_t)i * q + a) * 3;
+            o[0] = dj + dh;
+            o[1] = dj;
+            o[2] = dh;
+        }
+    return PLMO_OK;
+}
+
 /* ------------------------------------------------------------------------- */
 /* L-BFGS with a More'-Thuente line search (the published  */
 /* algorithms: Nocedal 1980 two-loop recursion, More' & Thuente 1994).          */

@@ -9,6 +9,8 @@ What is pinned here, and by which reference code:
   * `.model` plmc_v2 reader   <- evcouplings/couplings/model.py:317-389 (CouplingsModel)
   * FN / CN (APC) scores      <- evcouplings/couplings/model.py:179-233, 744-827
   * raw EC file reader        <- evcouplings/couplings/pairs.py:34-65
+  * statistical energies      <- evcouplings/couplings/model.py:25-109 (_hamiltonians,
+                                 _single_mutant_hamiltonians) and the CouplingsModel methods on top
 
 numba is not installed, so the reference's @jit kernels run as plain Python under an
 identity `numba.jit` stub.  `num_cluster_members` rebinds L to a
@@ -210,6 +212,22 @@ def main():
     os.remove(ind_path)
     np.savez_compressed(os.path.join(HERE, "independent_model_a.npz"), h_ref=mi.h_i, lambda_h=0.01,
                         n_eff=np.float32(wa.sum()).astype(np.float64), fi32=ca["fi"].astype(np.float32))
+    # ---- (6) statistical energies: the reference's own loops on the tiny model of (2)
+    rng = np.random.default_rng(11)
+    seqs = rng.integers(0, q, size=(40, L)).astype(np.int64)
+    seqs[0] = [ALPHABET_PROTEIN.index(c) for c in target]
+    # h_i is a float32 array in the reference object; compiled by numba its sums are double (float64 +
+    # float32 -> float64), but under the identity-jit stub NumPy 2 keeps `0.0 + float32` in float32.  Passing
+    # the same values as float64 reproduces the compiled semantics (J_ij already is float64).
+    h64 = m.h_i.astype(np.float64)
+    H = model_mod._hamiltonians(seqs, m.J_ij, h64)
+    smm = model_mod._single_mutant_hamiltonians(seqs[0], m.J_ij, h64)
+    # the public methods built on them must give the same numbers (up to that float32 artefact)
+    np.testing.assert_allclose(m.hamiltonians(["".join(ALPHABET_PROTEIN[k] for k in row) for row in seqs]), H,
+                               rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(m.smm(), smm[:, :, 0], rtol=1e-6, atol=1e-6)
+    np.savez_compressed(os.path.join(HERE, "energies_L12.npz"), seqs=seqs.astype(np.int8), hamiltonians=H,
+                        single_mutants=smm)
     print("golden vectors written to", HERE)
 
 

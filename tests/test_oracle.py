@@ -241,3 +241,22 @@ def test_field_objective_scaling_matches_reference_independent_model(oracle64, g
     d = np.random.default_rng(0).normal(size=L * Q)
     xp = x.copy(); xp[:L * Q] += 1e-2 * d
     assert oracle64.eval(msa, w, Q, 0.01, 7.0, xp)[0] > fx
+
+
+# ---------------------------------------------------------------- statistical energies (row N2)
+def test_energies_match_reference_golden(oracle64, golden_dir):
+    """hamiltonians / single-mutant matrix == the reference's own loops (couplings/model.py:25-109)."""
+    z = np.load(os.path.join(golden_dir, "energies_L12.npz"))
+    g = np.load(os.path.join(golden_dir, "scores_L12.npz"))
+    x = np.concatenate([g["hi"].ravel(), g["jij"].ravel()]).astype(np.float64)
+    H = oracle64.hamiltonians(z["seqs"], 21, x)
+    np.testing.assert_allclose(H, z["hamiltonians"], rtol=0, atol=1e-12)
+    S = oracle64.single_mutants(z["seqs"][0], 21, x)
+    np.testing.assert_allclose(S, z["single_mutants"], rtol=0, atol=1e-12)
+    # internal consistency: a single substitution changes the energy by the matrix entry
+    seq = z["seqs"][0].copy()
+    base = oracle64.hamiltonians(seq[None], 21, x)[0]
+    for (i, a) in ((0, 3), (5, 20), (11, 0)):
+        mut = seq.copy()
+        mut[i] = a
+        np.testing.assert_allclose(oracle64.hamiltonians(mut[None], 21, x)[0] - base, S[i, a], atol=1e-12)
