@@ -118,3 +118,30 @@ def test_reference_standard_protocol_runs_on_our_backend(ref, gpu_fit, golden_di
     finally:
         hip_protocol.uninstall()
     assert calls == [] and out2["num_sites"] == 24
+
+
+def test_fast_model_reader_is_a_drop_in_for_the_reference_reader(ref, golden_dir):
+    """model_accel's vectorised plmc_v2 reader vs the reference's own (model.py:317-400): every attribute the
+    reference reader sets, same dtype, same values; derived scores unchanged."""
+    import evcouplings.couplings.model as ref_model
+    from evcouplings_amd import model_accel
+    for fname in ("tiny_L12.model", "hip_fit_L24.model"):
+        path = os.path.join(golden_dir, fname)
+        slow = ref["CouplingsModel"](path)
+        model_accel.install(ref_model, reader=True)
+        try:
+            fast = ref["CouplingsModel"](path)
+            with open(path, "rb") as fh:                      # file-object form (the recommended use, model.py:247-249)
+                fast2 = ref["CouplingsModel"](fh)
+        finally:
+            model_accel.uninstall(ref_model)
+        again = ref["CouplingsModel"](path)                   # uninstall restored the original reader
+        for name in ("L", "num_symbols", "N_valid", "N_invalid", "num_iter", "theta", "lambda_h", "lambda_J",
+                     "lambda_group", "N_eff", "alphabet", "weights", "_target_seq", "index_list", "f_i", "h_i",
+                     "f_ij", "J_ij", "target_seq_mapped"):
+            for other in (fast, fast2, again):
+                a, b = getattr(slow, name), getattr(other, name)
+                assert np.asarray(a).dtype == np.asarray(b).dtype and np.asarray(a).shape == np.asarray(b).shape, name
+                np.testing.assert_array_equal(a, b, err_msg=name)
+        np.testing.assert_array_equal(slow.cn_scores, fast.cn_scores)
+        assert slow.has_target_seq == fast.has_target_seq
