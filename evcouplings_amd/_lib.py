@@ -47,6 +47,13 @@ class PlmResult(C.Structure):
     ]
 
 
+class PlmMfResult(C.Structure):
+    _fields_ = [
+        ("weights", C.c_void_p), ("n_eff", C.c_float), ("fi", C.c_void_p), ("fij", C.c_void_p),
+        ("hi", C.c_void_p), ("jij_full", C.c_void_p), ("jij", C.c_void_p), ("di", C.c_void_p),
+    ]
+
+
 # every symbol include/plm_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
@@ -65,6 +72,8 @@ SYMBOLS = [
     ("plm_scores", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     ("plm_hamiltonians", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int, _P, _P]),
     ("plm_potentials", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int, _P, _P]),
+    ("plm_meanfield", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int, _P,
+                                C.POINTER(PlmMfResult)]),
     ("plm_ctx_create", C.c_int, [C.POINTER(PlmProblem), C.c_int, _P, C.POINTER(_P)]),
     ("plm_ctx_destroy", None, [_P]),
     ("plm_ctx_set_exchange", C.c_int, [_P, EXCHANGE_CB, _P]),

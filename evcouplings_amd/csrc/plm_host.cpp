@@ -29,6 +29,20 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+}  // namespace
+// message recorder for the other translation units of the library
+int plm_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return fail(code, "%s", buf);
+}
+int plm_meanfield_device(const float *fi, const float *fij, int L, int q, double pseudo_count, hipStream_t st,
+                         double *hi, double *jfull, float *jpairs, double *di);   // plm_meanfield.hip
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e__ = (expr);                                                                   \
@@ -1171,6 +1185,43 @@ int plm_hamiltonians(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_s
 int plm_potentials(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_states, const float *x_canonical,
                    int device, void *stream, float *potentials_out) {
     return energies_impl(seqs, n, n_sites, n_states, x_canonical, device, stream, 1, potentials_out);
+}
+
+int plm_meanfield(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t n_states, double theta_id,
+                  double pseudo_count, int device, void *stream, plm_mf_result_t *out) {
+    if (!msa || !out) return fail(PLM_EINVAL, "NULL argument");
+    if (!(pseudo_count > 0.0 && pseudo_count < 1.0)) return fail(PLM_EINVAL, "pseudo_count must be in (0, 1)");
+    plm_problem_t p = basic_problem(msa, n_seqs, n_sites, n_states);
+    p.theta_id = theta_id;
+    plm_ctx_t *c = nullptr;
+    PLM_TRY(plm_ctx_create(&p, device, stream, &c));
+    const PlmDims d = c->d;
+    const size_t lq = (size_t)d.L * d.Q, pq = (size_t)d.L * (d.L - 1) / 2 * d.Q * d.Q, llqq = lq * lq;
+    double *hi = nullptr, *jfull = nullptr, *di = nullptr;
+    float *jp = nullptr;
+    auto done = [&](int code) {
+        void *all[] = {hi, jfull, di, jp};
+        for (void *b : all)
+            if (b) (void)hipFree(b);
+        plm_ctx_destroy(c);
+        return code;
+    };
+    int rc = plm_ctx_reweight(c);
+    if (!rc) rc = plm_ctx_get_weights(c, out->weights, nullptr, &out->n_eff);
+    if (!rc) rc = plm_ctx_marginals(c, out->fi, out->fij);      // leaves [f_i | f_ij blocks] in c->canon
+    if (rc) return done(rc);
+    if ((out->hi && (rc = dalloc(&hi, lq))) || (out->jij_full && (rc = dalloc(&jfull, llqq))) ||
+        (out->di && (rc = dalloc(&di, (size_t)d.L * d.L))) || (out->jij && (rc = dalloc(&jp, pq))))
+        return done(rc);
+    rc = plm_meanfield_device(c->canon, c->canon + lq, d.L, d.Q, pseudo_count, c->st, hi, jfull, jp, di);
+    if (rc) return done(rc);
+    hipError_t e = hipSuccess;
+    if (hi && e == hipSuccess) e = hipMemcpy(out->hi, hi, sizeof(double) * lq, hipMemcpyDeviceToHost);
+    if (jfull && e == hipSuccess) e = hipMemcpy(out->jij_full, jfull, sizeof(double) * llqq, hipMemcpyDeviceToHost);
+    if (di && e == hipSuccess) e = hipMemcpy(out->di, di, sizeof(double) * (size_t)d.L * d.L, hipMemcpyDeviceToHost);
+    if (jp && e == hipSuccess) e = hipMemcpy(out->jij, jp, sizeof(float) * pq, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(fail(PLM_EDEVICE, "download of the mean-field result failed: %s", hipGetErrorString(e)));
+    return done(PLM_OK);
 }
 
 static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,

@@ -132,6 +132,38 @@ def single_mutant_matrix(target, q, hi, jij, device=0):
     return np.stack([dj + dh, dj, dh], axis=2)
 
 
+def mean_field(msa, q=21, theta_id=0.8, pseudo_count=0.5, device=0, want_fij=True, want_full=True, want_di=True):
+    """
+    Mean-field direct coupling analysis of an alignment: the arithmetic of the reference's
+    `MeanFieldDCA.fit` (couplings/mean_field.py:163-222) and `direct_information` (:842-893) on the GPU.
+    Returns weights, n_eff, raw fi [L,q] / fij [pairs,q,q], fields hi [L,q] (float64), couplings as the i<j blocks
+    jij [pairs,q,q] (float32) and, if want_full, the dense jij_full [L,L,q,q] (float64, diagonal blocks included,
+    last row/column of every block zero), and di [L,L] (float64).
+    """
+    lib = _lib.load()
+    msa = _msa(msa)
+    N, L = msa.shape
+    npair = L * (L - 1) // 2
+    out = {
+        "weights": np.zeros(N, np.float32), "fi": np.zeros((L, q), np.float32), "hi": np.zeros((L, q)),
+        "jij": np.zeros((npair, q, q), np.float32),
+    }
+    if want_fij:
+        out["fij"] = np.zeros((npair, q, q), np.float32)
+    if want_full:
+        out["jij_full"] = np.zeros((L, L, q, q))
+    if want_di:
+        out["di"] = np.zeros((L, L))
+    res = _lib.PlmMfResult()
+    for name in ("weights", "fi", "fij", "hi", "jij_full", "jij", "di"):
+        if name in out:
+            setattr(res, name, out[name].ctypes.data)
+    check(lib.plm_meanfield(_ptr(msa), N, L, q, float(theta_id), float(pseudo_count), device, None, C.byref(res)))
+    out["n_eff"] = float(res.n_eff)
+    out["theta_id"], out["pseudo_count"] = theta_id, pseudo_count
+    return out
+
+
 FLAG_IGNORE_GAPS = 2
 FLAG_SHARDED_STATE = 4
 

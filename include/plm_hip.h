@@ -166,6 +166,25 @@ int plm_hamiltonians(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_s
 int plm_potentials(const int8_t *seqs, int32_t n, int32_t n_sites, int32_t n_states,
                    const float *x_canonical, int device, void *stream, float *potentials_out);
 
+/* ---- mean-field direct coupling analysis ---------------------------
+ * Replaces the arithmetic of evcouplings/couplings/mean_field.py:163-222 (MeanFieldDCA.fit: weights,
+ * frequencies, pseudo-count regularisation :717-790, covariance matrix :897-940, J = -C^-1 :204-210 and
+ * :943-975, fields :977-1014) and :792-893 (direct_information).  All outputs are caller-allocated host
+ * buffers; any pointer may be NULL to skip that output.                                                */
+typedef struct {
+    float *weights;     /* n_seqs                    1 / cluster size                                    */
+    float n_eff;
+    float *fi;          /* n_sites * q               raw frequencies                                     */
+    float *fij;         /* pairs * q * q             raw pair frequencies, i<j blocks row-major           */
+    double *hi;         /* n_sites * q               fields                                              */
+    double *jij_full;   /* n_sites^2 * q^2           dense couplings [i][j][a][b], diagonal blocks included
+                                                     (what reshape_invC_to_4d returns)                   */
+    float *jij;         /* pairs * q * q             the i<j blocks in the .model file's precision        */
+    double *di;         /* n_sites^2                 direct information, symmetric, zero diagonal         */
+} plm_mf_result_t;
+int plm_meanfield(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t n_states, double theta_id,
+                  double pseudo_count, int device, void *stream, plm_mf_result_t *out);
+
 /* -- resident-context API (bench / multi-GPU host) ---------------------------------------- */
 /* Uploads the alignment once; everything below runs on data resident in HBM. */
 int plm_ctx_create(const plm_problem_t *problem, int device, void *stream, plm_ctx_t **out);

@@ -9,6 +9,8 @@ What is pinned here, and by which reference code:
   * `.model` plmc_v2 reader   <- evcouplings/couplings/model.py:317-389 (CouplingsModel)
   * FN / CN (APC) scores      <- evcouplings/couplings/model.py:179-233, 744-827
   * raw EC file reader        <- evcouplings/couplings/pairs.py:34-65
+  * mean-field DCA            <- evcouplings/couplings/mean_field.py:717-1014 (regularisation, covariance,
+                                 reshape, fields, direct_information) on frequencies of golden alignments
   * statistical energies      <- evcouplings/couplings/model.py:25-109 (_hamiltonians,
                                  _single_mutant_hamiltonians) and the CouplingsModel methods on top
 
@@ -228,6 +230,27 @@ def main():
     np.testing.assert_allclose(m.smm(), smm[:, :, 0], rtol=1e-6, atol=1e-6)
     np.savez_compressed(os.path.join(HERE, "energies_L12.npz"), seqs=seqs.astype(np.int8), hamiltonians=H,
                         single_mutants=smm)
+    # ---- (7) mean-field DCA: the reference's own functions (couplings/mean_field.py) on the
+    # frequencies of golden alignments "a" (L=20) and "d" (L=10, theta 0.3); the package imports need the stub
+    # modules of tests/refstubs.py
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refstubs
+    refstubs.install()
+    import evcouplings.couplings.mean_field as mf
+    for name, pc in (("a", 0.5), ("d", 0.2)):
+        fi_r = za[name + "_fi"].astype(np.float64)
+        fij_r = za[name + "_fij"].astype(np.float64)          # dense L x L x q x q from pair_frequencies
+        Lm = fi_r.shape[0]
+        rfi = mf.regularize_frequencies(fi_r, pseudo_count=pc)
+        rfij = mf.regularize_pair_frequencies(fij_r, pseudo_count=pc)
+        cov = mf.compute_covariance_matrix(rfi, rfij)
+        inv = -np.linalg.inv(cov)
+        J4 = mf.reshape_invC_to_4d(inv, Lm, q)
+        h_mf = mf.fields(J4, rfi)
+        di = mf.direct_information(J4, rfi)
+        iu3 = np.triu_indices(Lm, 1)
+        np.savez_compressed(os.path.join(HERE, "meanfield_%s.npz" % name), pseudo_count=pc, fi=fi_r,
+                            fij_pairs=fij_r[iu3], rfi=rfi, cov=cov, jij_full=J4, hi=h_mf, di=di)
     print("golden vectors written to", HERE)
 
 

@@ -541,3 +541,36 @@ def test_model_accel_patches_reference_module(plm, golden_dir):
     model_accel.uninstall(mod)
     with pytest.raises(AssertionError):
         mod._hamiltonians()
+
+
+# ---------------------------------------------------------------- mean-field DCA
+def test_meanfield_golden_reference(plm, golden_dir):
+    """plm_meanfield end to end (reweighting, frequencies, covariance, rocSOLVER inverse, fields, DI) against
+    the reference's own mean_field.py run on the same alignment (golden case "a": L=20, N=96)."""
+    zf = np.load(os.path.join(golden_dir, "reweight_freqs.npz"))
+    z = np.load(os.path.join(golden_dir, "meanfield_a.npz"))
+    out = plm.mean_field(zf["a_msa"], Q, theta_id=float(zf["a_theta"]), pseudo_count=float(z["pseudo_count"]))
+    L = z["fi"].shape[0]
+    np.testing.assert_allclose(out["fi"], z["fi"], atol=2e-7)
+    scale = np.abs(z["jij_full"]).max()
+    np.testing.assert_allclose(out["jij_full"], z["jij_full"], atol=2e-4 * scale)      # f32 frequencies in, f64 after
+    iu = np.triu_indices(L, 1)
+    np.testing.assert_allclose(out["jij"], z["jij_full"][iu], atol=2e-4 * scale)
+    np.testing.assert_allclose(out["hi"], z["hi"], atol=2e-4 * np.abs(z["hi"]).max())
+    np.testing.assert_allclose(out["di"], z["di"], atol=2e-4 * z["di"].max())
+    assert np.array_equal(out["di"], out["di"].T) and not out["di"].diagonal().any()
+
+
+def test_meanfield_matches_oracle_given_the_same_frequencies(plm):
+    """Everything after the frequencies is float64 on the GPU: with the GPU's own f_i / f_ij as the oracle's input
+    the couplings, fields and DI agree to rounding."""
+    from oracle import meanfield_ref
+    msa, _ = synthetic_msa(1500, 48, seed=31)
+    out = plm.mean_field(msa, Q, theta_id=0.8, pseudo_count=0.5)
+    ref = meanfield_ref.mean_field(out["fi"].astype(np.float64), out["fij"].astype(np.float64), 0.5)
+    scale = np.abs(ref["jij_full"]).max()
+    np.testing.assert_allclose(out["jij_full"], ref["jij_full"], atol=1e-9 * scale)
+    np.testing.assert_allclose(out["hi"], ref["hi"], atol=1e-9 * np.abs(ref["hi"]).max())
+    np.testing.assert_allclose(out["di"], ref["di"], atol=1e-9)
+    # the top-ranked pairs are the planted couplings of the generator, like the PLM fit finds them
+    assert out["n_eff"] > 100

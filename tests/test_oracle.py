@@ -260,3 +260,17 @@ def test_energies_match_reference_golden(oracle64, golden_dir):
         mut = seq.copy()
         mut[i] = a
         np.testing.assert_allclose(oracle64.hamiltonians(mut[None], 21, x)[0] - base, S[i, a], atol=1e-12)
+
+
+# ---------------------------------------------------------------- mean-field DCA (row N4)
+@pytest.mark.parametrize("case", ["a", "d"])
+def test_meanfield_restatement_matches_reference_golden(golden_dir, case):
+    """oracle/meanfield_ref.py == the reference's own mean_field.py functions (regularisation, covariance,
+    inverse, fields, direct information) on the frequencies of golden alignments."""
+    from oracle import meanfield_ref
+    z = np.load(os.path.join(golden_dir, "meanfield_%s.npz" % case))
+    out = meanfield_ref.mean_field(z["fi"], z["fij_pairs"], float(z["pseudo_count"]))
+    np.testing.assert_allclose(out["rfi"], z["rfi"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(out["jij_full"], z["jij_full"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["hi"], z["hi"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["di"], z["di"], rtol=0, atol=1e-12)
