@@ -41,6 +41,7 @@ int plm_fail(int code, const char *fmt, ...) {
 }
 int plm_meanfield_device(const float *fi, const float *fij, int L, int q, double pseudo_count, hipStream_t st,
                          double *hi, double *jfull, float *jpairs, double *di);   // plm_meanfield.hip
+int plm_direct_information_device(const double *jdense, const double *rfi, int L, int q, hipStream_t st, double *di);
 namespace {
 
 #define HIP_TRY(expr)                                                                              \
@@ -1222,6 +1223,29 @@ int plm_meanfield(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t n_
     if (jp && e == hipSuccess) e = hipMemcpy(out->jij, jp, sizeof(float) * pq, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return done(fail(PLM_EDEVICE, "download of the mean-field result failed: %s", hipGetErrorString(e)));
     return done(PLM_OK);
+}
+
+int plm_direct_information(const double *jij_full, const double *fi, int32_t n_sites, int32_t n_states, int device,
+                           void *stream, double *di_out) {
+    if (!jij_full || !fi || !di_out || n_sites < 2) return fail(PLM_EINVAL, "NULL argument or fewer than 2 sites");
+    PLM_TRY(check_device(device));
+    const size_t L = (size_t)n_sites, q = (size_t)n_states;
+    double *J = nullptr, *f = nullptr, *di = nullptr;
+    auto done = [&](int code) {
+        void *all[] = {J, f, di};
+        for (void *b : all)
+            if (b) (void)hipFree(b);
+        return code;
+    };
+    int rc;
+    if ((rc = dalloc(&J, L * L * q * q)) || (rc = dalloc(&f, L * q)) || (rc = dalloc(&di, L * L))) return done(rc);
+    hipError_t e = hipMemcpy(J, jij_full, sizeof(double) * L * L * q * q, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(f, fi, sizeof(double) * L * q, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return done(fail(PLM_EDEVICE, "upload failed: %s", hipGetErrorString(e)));
+    rc = plm_direct_information_device(J, f, n_sites, n_states, (hipStream_t)stream, di);
+    if (rc) return done(rc);
+    e = hipMemcpy(di_out, di, sizeof(double) * L * L, hipMemcpyDeviceToHost);
+    return done(e == hipSuccess ? PLM_OK : fail(PLM_EDEVICE, "download failed: %s", hipGetErrorString(e)));
 }
 
 static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,

@@ -97,8 +97,12 @@ __global__ __launch_bounds__(256) void k_mf_fields(const double *__restrict__ Ci
 //   ht_i <- normalise(f_i / (W ht_j)),  ht_j <- normalise(f_j / (W^T ht_i))   from the uniform start until the
 // largest change is <= 1e-4 (both updates use the OLD vectors, mean_field.py:792-840), then
 //   P = W .* (ht_i ht_j^T) / sum,   DI = sum_ab P log((P + tiny) / (f_i(a) f_j(b) + tiny))   (:842-893)
+// Source of the couplings: the inverse covariance matrix (Cinv, leading dimension n; frequencies regularised on the
+// fly from the raw f32 fi) or, when Jdense is given, a dense L x L x q x q array with ready regularised f64
+// frequencies rfi (the standalone plm_direct_information entry point).
 __global__ __launch_bounds__(64) void k_mf_di(const double *__restrict__ Cinv, int n, const float *__restrict__ fi, int L,
-                                             int q, double pc, double *__restrict__ di) {
+                                             int q, double pc, const double *__restrict__ Jdense,
+                                             const double *__restrict__ rfi, double *__restrict__ di) {
     __shared__ double W[32 * 33];
     __shared__ double hti[32], htj[32];
     const int lane = threadIdx.x;
@@ -110,11 +114,13 @@ __global__ __launch_bounds__(64) void k_mf_di(const double *__restrict__ Cinv, i
     for (int k = lane; k < q * q; k += 64) {
         const int a = k / q, b = k % q;
         double v = 0.0;
-        if (a < q - 1 && b < q - 1) v = -mf_inv(Cinv, n, i * (q - 1) + a, j * (q - 1) + b);
+        if (Jdense) v = Jdense[(((size_t)i * L + j) * q + a) * q + b];
+        else if (a < q - 1 && b < q - 1) v = -mf_inv(Cinv, n, i * (q - 1) + a, j * (q - 1) + b);
         W[a * 33 + b] = exp(v);
     }
     const bool act = lane < q;
-    const double fia = act ? mf_rfi(fi, q, i, lane, pc) : 0.0, fja = act ? mf_rfi(fi, q, j, lane, pc) : 0.0;
+    const double fia = !act ? 0.0 : rfi ? rfi[(size_t)i * q + lane] : mf_rfi(fi, q, i, lane, pc);
+    const double fja = !act ? 0.0 : rfi ? rfi[(size_t)j * q + lane] : mf_rfi(fi, q, j, lane, pc);
     if (act) hti[lane] = htj[lane] = 1.0 / (double)q;
     __syncthreads();
     auto wave_sum = [](double v) {
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(64) void k_mf_di(const double *__restrict__ Cinv, i
     if (act)
         for (int b = 0; b < q; b++) {
             const double pab = W[lane * 33 + b] * hti[lane] * htj[b] / psum;
-            const double fjb = mf_rfi(fi, q, j, b, pc);
+            const double fjb = rfi ? rfi[(size_t)j * q + b] : mf_rfi(fi, q, j, b, pc);
             acc += pab * log((pab + tiny) / (fia * fjb + tiny));
         }
     acc = wave_sum(acc);
@@ -337,9 +343,20 @@ int plm_meanfield_device(const float *fi, const float *fij, int L, int q, double
     if (di) {
         (void)hipMemsetAsync(di, 0, sizeof(double) * (size_t)L * L, st);
         hipLaunchKernelGGL(k_mf_di, dim3((unsigned)((int64_t)L * (L - 1) / 2)), dim3(64), 0, st, C, np, fi, L, q,
-                           pseudo_count, di);
+                           pseudo_count, (const double *)nullptr, (const double *)nullptr, di);
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return done(plm_fail(PLM_EDEVICE, "mean-field kernels failed"));
     return done(PLM_OK);
+}
+
+// direct information from given couplings and (regularised) frequencies -- device pointers
+int plm_direct_information_device(const double *jdense, const double *rfi, int L, int q, hipStream_t st, double *di) {
+    if (q < 2 || q > 32) return plm_fail(PLM_EUNSUPPORTED, "direct information supports 2..32 states");
+    (void)hipMemsetAsync(di, 0, sizeof(double) * (size_t)L * L, st);
+    hipLaunchKernelGGL(k_mf_di, dim3((unsigned)((int64_t)L * (L - 1) / 2)), dim3(64), 0, st, (const double *)nullptr, 0,
+                       (const float *)nullptr, L, q, 0.0, jdense, rfi, di);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return plm_fail(PLM_EDEVICE, "k_mf_di failed");
+    return PLM_OK;
 }

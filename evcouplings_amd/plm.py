@@ -164,6 +164,19 @@ def mean_field(msa, q=21, theta_id=0.8, pseudo_count=0.5, device=0, want_fij=Tru
     return out
 
 
+def direct_information(jij_full, fi, device=0):
+    """DI of every pair from dense couplings [L,L,q,q] and frequencies [L,q] (both float64): the reference's
+    `direct_information(J_ij, f_i)` (couplings/mean_field.py:842-893).  Returns [L,L] float64."""
+    lib = _lib.load()
+    jij_full = np.ascontiguousarray(jij_full, dtype=np.float64)
+    fi = np.ascontiguousarray(fi, dtype=np.float64)
+    L, q = fi.shape
+    assert jij_full.shape == (L, L, q, q)
+    di = np.zeros((L, L))
+    check(lib.plm_direct_information(_ptr(jij_full), _ptr(fi), L, q, device, None, _ptr(di)))
+    return di
+
+
 FLAG_IGNORE_GAPS = 2
 FLAG_SHARDED_STATE = 4
 

@@ -184,6 +184,11 @@ typedef struct {
 } plm_mf_result_t;
 int plm_meanfield(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t n_states, double theta_id,
                   double pseudo_count, int device, void *stream, plm_mf_result_t *out);
+/* Direct information of every pair from given couplings and frequencies: replaces
+ * evcouplings/couplings/mean_field.py:842-893 direct_information(J_ij, f_i).  jij_full: dense
+ * [L][L][q][q] doubles (only i<j blocks are read); fi: [L][q] doubles; di_out: [L][L] doubles.       */
+int plm_direct_information(const double *jij_full, const double *fi, int32_t n_sites, int32_t n_states,
+                           int device, void *stream, double *di_out);
 
 /* -- resident-context API (bench / multi-GPU host) ---------------------------------------- */
 /* Uploads the alignment once; everything below runs on data resident in HBM. */

@@ -17,6 +17,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    # the reference tree (imported by test_reference_pipeline.py only) uses numpy calls deprecated in NumPy 2
+    config.addinivalue_line("filterwarnings", "ignore:.*in1d.*:DeprecationWarning")
 
 
 @pytest.fixture(scope="session")

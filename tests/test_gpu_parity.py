@@ -574,3 +574,12 @@ def test_meanfield_matches_oracle_given_the_same_frequencies(plm):
     np.testing.assert_allclose(out["di"], ref["di"], atol=1e-9)
     # the top-ranked pairs are the planted couplings of the generator, like the PLM fit finds them
     assert out["n_eff"] > 100
+
+
+def test_direct_information_golden(plm, golden_dir):
+    """plm_direct_information vs the reference's direct_information on its own couplings (both golden cases)."""
+    for case in ("a", "d"):
+        z = np.load(os.path.join(golden_dir, "meanfield_%s.npz" % case))
+        di = plm.direct_information(z["jij_full"], z["rfi"])
+        np.testing.assert_allclose(di, z["di"], rtol=0, atol=1e-10)
+        assert np.array_equal(di, di.T) and not di.diagonal().any()

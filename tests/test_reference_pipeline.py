@@ -145,3 +145,66 @@ def test_fast_model_reader_is_a_drop_in_for_the_reference_reader(ref, golden_dir
                 np.testing.assert_array_equal(a, b, err_msg=name)
         np.testing.assert_array_equal(slow.cn_scores, fast.cn_scores)
         assert slow.has_target_seq == fast.has_target_seq
+
+
+def test_mean_field_drop_in_behind_the_reference_classes(ref, golden_dir, monkeypatch, tmp_path):
+    """evcouplings_amd.mean_field.install(): the reference's MeanFieldDCA / MeanFieldCouplingsModel run on top of
+    our fit and DI functions.  No GPU here, so plm.mean_field / plm.direct_information are replaced by the numpy
+    oracle fed with the reference's own weights and frequencies -- the glue (attributes, dense layouts, model
+    object, ECs table, model file) is what is under test; the GPU arithmetic is tested in test_gpu_parity.py."""
+    import evcouplings.couplings.mean_field as ref_mf
+    from evcouplings.align.alignment import Alignment
+    from evcouplings_amd import mean_field as our_mf, plm
+    from oracle import meanfield_ref
+
+    a2m = os.path.join(golden_dir, "hip_fit_L24.a2m")
+    with open(a2m) as f:
+        ali = Alignment.from_file(f, "fasta")
+
+    def fake_mean_field(msa, q, theta_id=0.8, pseudo_count=0.5, **kw):
+        from oracle.oracle import Oracle
+        o = Oracle("f64")
+        counts = o.reweight(msa, theta_id)
+        w = 1.0 / counts
+        fi, fij = o.marginals(msa, w, q)
+        out = meanfield_ref.mean_field(fi, fij, pseudo_count, want_di=False)
+        return dict(weights=w.astype(np.float32), n_eff=float(w.sum()), fi=fi.astype(np.float32),
+                    fij=fij.astype(np.float32), hi=out["hi"], jij=out["jij"].astype(np.float32),
+                    jij_full=out["jij_full"])
+
+    monkeypatch.setattr(plm, "mean_field", fake_mean_field)
+    monkeypatch.setattr(plm, "direct_information", lambda J, f: meanfield_ref.direct_information(np.asarray(J), np.asarray(f)))
+
+    # the reference's num_cluster_members calls range(L) with a float L (alignment.py:1216,1225): legal under numba,
+    # a TypeError in CPython (SURVEY.md App. D-9) -- stand in the oracle's counts, pinned equal to it by
+    # tests/golden/reweight_freqs.npz
+    import evcouplings.align.alignment as ref_ali
+    from oracle.oracle import Oracle
+    monkeypatch.setattr(ref_ali, "num_cluster_members",
+                        lambda matrix, thr: Oracle("f64").reweight(np.asarray(matrix).astype(np.int8), thr).astype(float))
+    slow = ref_mf.MeanFieldDCA(ali).fit(theta=0.8, pseudo_count=0.5)           # the reference's own fit
+    with open(a2m) as f:
+        ali2 = Alignment.from_file(f, "fasta")
+    our_mf.install(ref_mf)
+    try:
+        fast = ref_mf.MeanFieldDCA(ali2).fit(theta=0.8, pseudo_count=0.5)
+        ecs_fast = fast.ecs
+        out_model = str(tmp_path / "mf.model")
+        fast.to_file(out_model)
+    finally:
+        our_mf.uninstall(ref_mf)
+    assert type(fast) is type(slow)
+    np.testing.assert_allclose(fast.weights, slow.weights, rtol=1e-6)
+    np.testing.assert_allclose(fast.f_i, slow.f_i, atol=1e-6)
+    np.testing.assert_allclose(fast.f_ij, slow.f_ij, atol=1e-6)
+    np.testing.assert_allclose(fast.J_ij, slow.J_ij, atol=2e-4 * np.abs(slow.J_ij).max())   # f32 frequencies in between
+    np.testing.assert_allclose(fast.h_i, slow.h_i, atol=2e-4 * np.abs(slow.h_i).max())
+    ecs_slow = slow.ecs
+    assert list(ecs_fast.columns) == list(ecs_slow.columns) and "di" in ecs_fast.columns
+    a = ecs_fast.sort_values(["i", "j"])
+    b = ecs_slow.sort_values(["i", "j"])
+    np.testing.assert_allclose(a["di"].values, b["di"].values, atol=2e-4 * b["di"].max())
+    np.testing.assert_allclose(a["cn"].values, b["cn"].values, atol=2e-4 * np.abs(b["cn"]).max())
+    # the file written through the reference's to_file comes back as a mean-field model
+    back = ref["CouplingsModel"](out_model)
+    assert type(back).__name__ == "MeanFieldCouplingsModel" and back.L == fast.L
