@@ -583,3 +583,25 @@ def test_direct_information_golden(plm, golden_dir):
         di = plm.direct_information(z["jij_full"], z["rfi"])
         np.testing.assert_allclose(di, z["di"], rtol=0, atol=1e-10)
         assert np.array_equal(di, di.T) and not di.diagonal().any()
+
+
+def test_alignment_accel_drop_ins_match_reference_golden(plm, golden_dir):
+    """alignment_accel: num_cluster_members / frequencies / pair_frequencies with the reference's signatures, against
+    the outputs of the reference's own functions (tests/golden/reweight_freqs.npz)."""
+    import types
+    from evcouplings_amd import alignment_accel
+    mod = types.ModuleType("fake_alignment")
+    mod.num_cluster_members = mod.frequencies = mod.pair_frequencies = None
+    alignment_accel.install(mod)
+    for name, c in _golden_cases(golden_dir).items():
+        matrix = c["msa"].astype(np.int64)                       # the reference passes its mapped int matrix
+        counts = mod.num_cluster_members(matrix, float(c["theta"]))
+        assert counts.dtype == np.float64 and np.array_equal(counts, c["counts"].astype(np.float64)), name
+        w = 1.0 / counts
+        fi = mod.frequencies(matrix, w, Q)
+        fij = mod.pair_frequencies(matrix, w, Q, fi)
+        assert fi.dtype == np.float64 and fij.dtype == np.float64 and fij.shape == c["fij"].shape
+        np.testing.assert_allclose(fi, c["fi"], atol=2e-6)
+        np.testing.assert_allclose(fij, c["fij"], atol=2e-6)
+    alignment_accel.uninstall(mod)
+    assert mod.frequencies is None

@@ -208,3 +208,34 @@ def test_mean_field_drop_in_behind_the_reference_classes(ref, golden_dir, monkey
     # the file written through the reference's to_file comes back as a mean-field model
     back = ref["CouplingsModel"](out_model)
     assert type(back).__name__ == "MeanFieldCouplingsModel" and back.L == fast.L
+
+
+def test_alignment_accel_installs_into_the_reference_module(ref, golden_dir, monkeypatch):
+    """alignment_accel.install() on the real evcouplings.align.alignment: Alignment.set_weights / .frequencies /
+    .pair_frequencies run through our wrappers (plm.* replaced by the oracle here: no GPU in this container)."""
+    import evcouplings.align.alignment as ref_ali
+    from evcouplings_amd import alignment_accel, plm
+    from oracle.oracle import Oracle
+    o = Oracle("f64")
+    monkeypatch.setattr(plm, "reweight", lambda msa, thr: o.reweight(msa, thr))
+
+    def fake_marginals(msa, w, q, pairs=True):
+        fi, fij = o.marginals(msa, np.asarray(w, dtype=np.float64), q, pairs=pairs) if pairs else (o.marginals(msa, np.asarray(w, dtype=np.float64), q, pairs=False), None)
+        fi = fi[0] if isinstance(fi, tuple) else fi
+        return fi.astype(np.float32), (None if fij is None else fij.astype(np.float32))
+
+    monkeypatch.setattr(plm, "marginals", fake_marginals)
+    with open(os.path.join(golden_dir, "hip_fit_L24.a2m")) as f:
+        ali = ref_ali.Alignment.from_file(f, "fasta")
+    z = np.load(os.path.join(golden_dir, "hip_fit_L24.npz"))
+    alignment_accel.install(ref_ali)
+    try:
+        ali.set_weights(identity_threshold=0.8)
+        fi, fij = ali.frequencies, ali.pair_frequencies
+    finally:
+        alignment_accel.uninstall(ref_ali)
+    np.testing.assert_allclose(ali.weights, z["weights"], rtol=1e-6)          # the MI355X fit's weights
+    L = fi.shape[0]
+    np.testing.assert_allclose(fi, z["fi"], atol=2e-6)
+    np.testing.assert_allclose(fij[np.triu_indices(L, 1)], z["fij"], atol=2e-6)
+    assert fij.shape == (L, L, 21, 21) and np.allclose(fij[3, 3], np.diag(fi[3]))
