@@ -103,10 +103,23 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.nnfl = d.blk_per_shard * d.Q;
     d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
     d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
-    int ks = (1536 + d.nrow_tiles * d.ncol_tiles - 1) / (d.nrow_tiles * d.ncol_tiles);
-    ks = std::max(1, std::min(ks, 16));
-    ks = std::min(ks, std::max(1, d.nssteps / 8));
-    d.ksplit = ks;
+    {
+        // split-K factor of the backward GEMM: at least ~6 rounds of workgroups on the 256 CUs (1536 blocks;
+        // fewer balances badly -- measured on configs 2 and 4), and among those the factor with the cheapest
+        // tail: the launch runs in ceil(tiles * ks / 256) rounds of 1/ks of the K range each, and every extra
+        // partial slab costs k_assemble two more reads of it (config 5: ks 1 -> 2 takes k_bwd from 14.2 to 12.5 ms).
+        // Cost in units of one full-K round (a K step is ~1.4 us, HBM ~4 TB/s effective):
+        const int tiles = d.nrow_tiles * d.ncol_tiles, ks_max = std::max(1, std::min(16, d.nssteps / 8));
+        const int ks_min = std::min(ks_max, (1536 + tiles - 1) / tiles);
+        const double beta = (2.0 * (double)d.nmf * d.nnfl * 1024.0 / 4e12) / ((double)d.nssteps * 1.4e-6);
+        int best = ks_min;
+        double best_cost = 1e300;
+        for (int ks = ks_min; ks <= ks_max; ks++) {
+            const double cost = (double)((tiles * ks + 255) / 256) / ks + beta * ks;
+            if (cost < best_cost * 0.98) { best_cost = cost; best = ks; }
+        }
+        d.ksplit = best;
+    }
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
     d.n_native = d.nh_pad + d.nbp * d.Q * d.Q * 256;
