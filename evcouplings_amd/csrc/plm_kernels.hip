@@ -190,7 +190,7 @@ size_t plm_bt_bytes(const PlmDims &d) { return (size_t)d.blk_per_shard * d.nkste
 size_t plm_rt_bytes(const PlmDims &d) { return (size_t)d.nssteps * d.nnfl * 2 * 1024; }
 size_t plm_g_bytes(const PlmDims &d) { return (size_t)d.ksplit * d.nmf * d.nnfl * 1024; }
 size_t plm_slab_bytes(const PlmDims &d) { return (size_t)d.nmf * d.nnfl * 1024 + 256; }
-int plm_reg_parts(const PlmDims &d) { return (int)(d.np_own * d.Q) + 1; }
+int plm_reg_parts(const PlmDims &d) { return (int)(d.np_own * d.Q) + (int)((d.nh_pad_l + 255) / 256); }
 
 // =========================================================================================
 // K1  sequence reweighting (row a4; twin: align/alignment.py:1193-1233)
@@ -392,7 +392,13 @@ hipError_t plm_launch_onehot_rt(const PlmDims &d, const int8_t *msa_rm, const fl
 // =========================================================================================
 __global__ __launch_bounds__(256) void k_maxabs(const float *__restrict__ x, int64_t n, u32 *maxbits) {
     u32 m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    // x is 16-byte aligned and n a multiple of 4 in every caller (block-padded parameter vectors)
+    const uint4 *x4 = (const uint4 *)x;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = x4[i];
+        m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    }
+    for (int64_t i = (n / 4) * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
     for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down((int)m, o, 64));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
@@ -1150,7 +1156,8 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
     double reg = 0;
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
     const int site_end = min(d.L, d.own_hi * 16);      // local field part: sites [h_site0, site_end)
-    for (int64_t idx = threadIdx.x; idx < d.nh_pad_l; idx += 256) {
+    {   // one element per thread, one workgroup per 256 elements (nh_pad_l is a multiple of 256)
+        const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
         float out = 0.f;
         if (idx < (int64_t)(site_end - d.h_site0) * d.Q) {
             const int i = d.h_site0 + (int)(idx / d.Q), a = (int)(idx % d.Q);
@@ -1171,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
     }
     if (mode == 0) {
         const double t = block_reduce_sum(reg, red);
-        if (threadIdx.x == 0) reg_part[d.np_own * d.Q] = (double)lambda_h * t;
+        if (threadIdx.x == 0) reg_part[d.np_own * d.Q + blockIdx.x] = (double)lambda_h * t;
     }
 }
 hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *ghalo, const float *x,
@@ -1183,7 +1190,7 @@ hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, c
     if (d.np_own > 0)
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride,
                            ghalo, x, g, lambda_j, reg_part, mode, scale);
-    hipLaunchKernelGGL(k_assemble_h, dim3(1), dim3(256), 0, st, d, G, ks_count, slab_stride, x, g, lambda_h,
+    hipLaunchKernelGGL(k_assemble_h, dim3((unsigned)(d.nh_pad_l / 256)), dim3(256), 0, st, d, G, ks_count, slab_stride, x, g, lambda_h,
                        reg_part, mode, scale);
     return hipGetLastError();
 }
