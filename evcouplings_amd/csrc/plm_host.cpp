@@ -796,6 +796,16 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             std::swap(c->x, c->xp);
             std::swap(c->g, c->gp);
             const double finit = fx, nllinit = nll, dgtest = ftol * dginit;
+            // the new pair goes into slot `end`; queries and basis of the Gram pass (rows for s, y, g)
+            float *s_new = S + (size_t)end * n, *y_new = Y + (size_t)end * n;
+            const int nst = std::min(m, stored + 1);
+            PlmVecList Qv, B;
+            Qv.n = 3;
+            Qv.v[0] = s_new; Qv.v[1] = y_new; Qv.v[2] = c->g;       // c->g: the buffer the trial gradients land in
+            B.n = 0;
+            for (int i = 0; i < nst; i++) B.v[B.n++] = S + (size_t)i * n;
+            for (int i = 0; i < nst; i++) B.v[B.n++] = Y + (size_t)i * n;
+            B.v[B.n++] = c->g;
             int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
             double width = stpmax - stpmin, prev_width = 2.0 * width;
             double stx = 0, fxx = finit, dgx = dginit, sty = 0, fy = finit, dgy = dginit, stp = step, stmin, stmax;
@@ -812,8 +822,16 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 {
                     const float *a[1] = {c->g}, *b[1] = {c->dir};
                     PLM_TRY(dots(c, 1, a, b, n, SL_DG));
-                    PLM_TRY(ctx_allreduce_scalars(c, SL_FX, 3));
-                    PLM_TRY(fetch_scalars(c, SL_FX, 3));
+                    // Speculate that this trial point is accepted (it is, 97 % of the time): form its (s, y) pair
+                    // in slot `end` -- the slot the next pair goes to anyway; a rejected trial is simply
+                    // overwritten by the next one -- and run the Gram pass now, so that ONE host
+                    // synchronisation (and, sharded, one all-reduce) per trial brings back f, the directional
+                    // derivative and everything the next direction needs.
+                    HIP_TRY(plm_launch_sy(s_new, y_new, c->x, c->xp, c->g, c->gp, n, c->st));
+                    HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, c->st));
+                    PLM_TRY(norm_dots());
+                    PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
+                    PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
                 }
                 double dg = c->h_scal[SL_DG];
                 fx = c->h_scal[SL_FX];
@@ -874,21 +892,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             }
             restarts = 0;
             step = stp;
-            // new pair into slot `end`, then ONE pass: rows of the Gram matrix for s, y, g + norms
-            float *s = S + (size_t)end * n, *y = Y + (size_t)end * n;
-            HIP_TRY(plm_launch_sy(s, y, c->x, c->xp, c->g, c->gp, n, c->st));
-            const int nst = std::min(m, stored + 1);
-            PlmVecList Qv, B;
-            Qv.n = 3;
-            Qv.v[0] = s; Qv.v[1] = y; Qv.v[2] = c->g;
-            B.n = 0;
-            for (int i = 0; i < nst; i++) B.v[B.n++] = S + (size_t)i * n;
-            for (int i = 0; i < nst; i++) B.v[B.n++] = Y + (size_t)i * n;
-            B.v[B.n++] = c->g;
-            HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, c->st));
-            PLM_TRY(norm_dots());
-            PLM_TRY(ctx_allreduce_scalars(c, SL_XX, SL_MD + 3 * B.n - SL_XX));
-            PLM_TRY(fetch_scalars(c, SL_XX, SL_MD + 3 * B.n - SL_XX));
+            // the pair of the accepted point already sits in slot `end` and its Gram rows in h_scal (see above)
             const double *md = c->h_scal + SL_MD;
             const int nbv = B.n, e = end;
             for (int j = 0; j < nst; j++) {

@@ -605,3 +605,41 @@ def test_alignment_accel_drop_ins_match_reference_golden(plm, golden_dir):
         np.testing.assert_allclose(fij, c["fij"], atol=2e-6)
     alignment_accel.uninstall(mod)
     assert mod.frequencies is None
+
+
+@pytest.mark.parametrize("q,L,N", [(20, 70, 300), (5, 45, 260), (4, 33, 100)])
+def test_hamiltonians_other_alphabets(plm, oracle64, q, L, N):
+    """energies / single-mutant matrix for the other instantiated alphabets (q = 20: gap-free protein models)."""
+    rng = np.random.default_rng(q)
+    seqs = rng.integers(0, q, size=(N, L)).astype(np.int8)
+    hi = rng.normal(size=(L, q)).astype(np.float32)
+    jij = (0.1 * rng.normal(size=(L * (L - 1) // 2, q, q))).astype(np.float32)
+    x = np.concatenate([hi.ravel(), jij.ravel()]).astype(np.float64)
+    Ho = oracle64.hamiltonians(seqs, q, x)
+    np.testing.assert_allclose(plm.hamiltonians(seqs, q, hi, jij), Ho, rtol=2e-5, atol=2e-5 * np.abs(Ho).max())
+    So = oracle64.single_mutants(seqs[1], q, x)
+    np.testing.assert_allclose(plm.single_mutant_matrix(seqs[1], q, hi, jij), So, rtol=2e-5,
+                               atol=2e-5 * np.abs(So).max())
+
+
+def test_meanfield_dna_alphabet(plm):
+    """mean-field DCA with q = 5 (nucleotides + gap) against the numpy oracle fed with the GPU's frequencies."""
+    from oracle import meanfield_ref
+    rng = np.random.default_rng(2)
+    msa = rng.integers(0, 5, size=(400, 37)).astype(np.int8)
+    msa[:, 5] = msa[:, 20]                                   # one strongly coupled pair
+    out = plm.mean_field(msa, 5, theta_id=0.9, pseudo_count=0.3)
+    ref = meanfield_ref.mean_field(out["fi"].astype(np.float64), out["fij"].astype(np.float64), 0.3)
+    np.testing.assert_allclose(out["jij_full"], ref["jij_full"], atol=1e-9 * np.abs(ref["jij_full"]).max())
+    np.testing.assert_allclose(out["di"], ref["di"], atol=1e-9)
+    i, j = np.unravel_index(np.argmax(out["di"]), out["di"].shape)
+    assert {int(i), int(j)} == {5, 20}
+
+
+def test_meanfield_rejects_bad_input(plm):
+    from evcouplings_amd._lib import PlmError
+    msa = np.zeros((10, 8), np.int8)
+    with pytest.raises(PlmError):
+        plm.mean_field(msa, 21, pseudo_count=0.0)            # pseudo-count outside (0, 1)
+    with pytest.raises(PlmError):
+        plm.mean_field(msa, 7)                               # alphabet size not instantiated
