@@ -179,6 +179,12 @@ __device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
     return t;  // valid in thread 0
 }
 
+#define PLM_MAX_DEVICES 64
+static int plm_current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (dev >= 0 && dev < PLM_MAX_DEVICES) ? dev : 0;
+}
 bool plm_q_supported(int q) { return q == 21 || q == 20 || q == 5 || q == 4; }
 void plm_pick_tile(int q, int *fm, int *fn) {
     if (q == 21) { *fm = 7; *fn = 7; }
@@ -789,7 +795,8 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
     const size_t lds = (size_t)PLM_NBUF * 2 * d.Q * 1024;
 #define FWD_LAUNCH(QQ, MM)                                                                             \
     {                                                                                                  \
-        static bool attr_done = false;                                                                 \
+        static bool attr_done_dev[PLM_MAX_DEVICES] = {false};   /* the attribute is per device */     \
+        bool &attr_done = attr_done_dev[plm_current_device()];                                         \
         if (!attr_done) {                                                                              \
             hipError_t e = hipFuncSetAttribute((const void *)k_fwd<QQ, MM>,                            \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
@@ -1042,7 +1049,8 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
 #define BWD_CASE(QQ, M, N)                                                                             \
     case QQ: {                                                                                         \
         const size_t lds = (size_t)PLM_NBUF * (2 * N * 2 * 1024);                                      \
-        static bool attr_done = false;                                                                 \
+        static bool attr_done_dev[PLM_MAX_DEVICES] = {false};   /* the attribute is per device */     \
+        bool &attr_done = attr_done_dev[plm_current_device()];                                         \
         if (!attr_done) {                                                                              \
             hipError_t e = hipFuncSetAttribute((const void *)k_bwd<QQ, M, N>,                          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
