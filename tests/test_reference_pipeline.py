@@ -239,3 +239,81 @@ def test_alignment_accel_installs_into_the_reference_module(ref, golden_dir, mon
     np.testing.assert_allclose(fi, z["fi"], atol=2e-6)
     np.testing.assert_allclose(fij[np.triu_indices(L, 1)], z["fij"], atol=2e-6)
     assert fij.shape == (L, L, 21, 21) and np.allclose(fij[3, 3], np.diag(fi[3]))
+
+
+def _oracle_backed_plm(monkeypatch):
+    """No GPU in this container: stand the numpy / C oracle in for the library calls the drop-ins make."""
+    from evcouplings_amd import plm
+    from oracle import meanfield_ref
+    from oracle.oracle import Oracle
+    o = Oracle("f64")
+
+    def fake_mean_field(msa, q, theta_id=0.8, pseudo_count=0.5, **kw):
+        counts = o.reweight(msa, theta_id)
+        w = 1.0 / counts
+        fi, fij = o.marginals(msa, w, q)
+        out = meanfield_ref.mean_field(fi, fij, pseudo_count, want_di=False)
+        return dict(weights=w.astype(np.float32), n_eff=float(w.sum()), fi=fi.astype(np.float32),
+                    fij=fij.astype(np.float32), hi=out["hi"], jij=out["jij"].astype(np.float32),
+                    jij_full=out["jij_full"])
+
+    monkeypatch.setattr(plm, "mean_field", fake_mean_field)
+    monkeypatch.setattr(plm, "direct_information",
+                        lambda J, f: meanfield_ref.direct_information(np.asarray(J), np.asarray(f)))
+
+
+def test_reference_mean_field_protocol_runs_on_our_drop_in(ref, golden_dir, monkeypatch, tmp_path):
+    """the reference's second inference protocol (couplings/protocol.py:597 mean_field) end to end with
+    evcouplings_amd.mean_field installed: model file, raw EC file with MI / DI / CN columns, score table."""
+    import evcouplings.couplings.mean_field as ref_mf
+    from evcouplings_amd import mean_field as our_mf
+    _oracle_backed_plm(monkeypatch)
+    cp = ref["cp"]
+    prefix = str(tmp_path / "mf" / "job")
+    kwargs = dict(prefix=prefix, alignment_file=os.path.join(golden_dir, "hip_fit_L24.a2m"), segments=None,
+                  focus_mode=True, focus_sequence="SYN/10-33", theta=0.8, pseudo_count=0.5, alphabet=None,
+                  min_sequence_distance=6, ec_score_type="cn", scoring_model="skewnormal", frequencies_file=None)
+    our_mf.install(ref_mf)
+    try:
+        outcfg = cp.run(protocol="mean_field", **kwargs)
+    finally:
+        our_mf.uninstall(ref_mf)
+    assert outcfg["num_sites"] == 24 and outcfg["num_valid_sequences"] == 500 and outcfg["region_start"] == 10
+    for key in ("raw_ec_file", "model_file", "ec_file"):
+        assert os.path.getsize(outcfg[key]) > 0, key
+    import pandas as pd
+    raw = pd.read_csv(outcfg["raw_ec_file"], sep=" ", names=["i", "A_i", "j", "A_j", "mi_raw", "mi_apc", "di", "cn"])
+    assert len(raw) == 276 and np.isfinite(raw[["mi_raw", "mi_apc", "di", "cn"]].values).all()
+    back = ref["CouplingsModel"](outcfg["model_file"])
+    assert type(back).__name__ == "MeanFieldCouplingsModel" and back.L == 24
+
+
+def test_reference_complex_protocol_runs_on_our_backend(ref, gpu_fit, golden_dir, tmp_path):
+    """the second caller of infer_plmc (couplings/protocol.py:521 complex): two segments of 12 sites each on the
+    MI355X fixture -- segment mapping of the ECs, intra/inter scoring, inter-EC table."""
+    fit, calls, z = gpu_fit
+    from evcouplings_amd import protocol as hip_protocol
+    cp = ref["cp"]
+    prefix = str(tmp_path / "complex" / "job")
+    # list form of mapping.Segment: segment_id, segment_type, sequence_id, region_start, region_end, positions
+    segments = [["A_1", "aa", "SYNA", 10, 21, list(range(10, 22))], ["B_1", "aa", "SYNB", 122, 133, list(range(122, 134))]]
+    kwargs = dict(
+        prefix=prefix, alignment_file=os.path.join(golden_dir, "hip_fit_L24.a2m"), focus_mode=True,
+        focus_sequence="SYN/10-33", segments=segments, theta=0.8, alphabet=None, ignore_gaps=False, iterations=100,
+        lambda_h=0.01, lambda_J=0.01, lambda_J_times_Lq=True, lambda_group=None, scale_clusters=None, cpu=None,
+        plmc="plmc", reuse_ecs=False, min_sequence_distance=6, frequencies_file=None, scoring_model="skewnormal",
+        use_all_ecs_for_scoring=False, save_model=True)
+    hip_protocol.install()
+    try:
+        outcfg = cp.run(protocol="complex", **kwargs)
+    finally:
+        hip_protocol.uninstall()
+    (shape, kw), = calls
+    assert shape == (500, 24) and kw["lambda_j"] == pytest.approx(0.01 * 20 * 23)
+    import pandas as pd
+    ecs = pd.read_csv(outcfg["ec_file"])
+    inter = pd.read_csv(outcfg["inter_ec_file"])
+    assert len(ecs) == 276 and len(inter) == 144 and set(inter["segment_i"]) == {"A_1"} and set(inter["segment_j"]) == {"B_1"}
+    # sites 13..24 of the model were renumbered into the second segment's coordinates
+    assert inter["j"].min() == 122 and inter["j"].max() == 133 and inter["i"].max() == 21
+    assert "probability" in ecs.columns
