@@ -173,6 +173,11 @@ struct plm_ctx {
     int hist_m = 0;
     double *h_scal = nullptr;  // pinned host scalars
     bool have_weights = false;
+    // (x, g) and these values belong together: set when an optimisation ends, cleared by everything that
+    // changes x, the weights or the scratch use of g -- lets a follow-up plm_ctx_optimize (a resumed fit)
+    // start from the known point instead of re-evaluating it
+    bool eval_valid = false;
+    double last_fx = 0, last_nll = 0;
     double n_eff = 0;
     int n_evals = 0;
     std::vector<float> h_fi;   // L*q, kept for the start point
@@ -389,6 +394,7 @@ int set_start_point(plm_ctx *c) {
         mean /= (d.Q - a0);
         for (int a = a0; a < d.Q; a++) h[(size_t)(i - d.h_site0) * d.Q + a] = (float)(v[a] - mean);
     }
+    c->eval_valid = false;
     HIP_TRY(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_local, c->st));
     HIP_TRY(hipMemcpyAsync(c->x, h.data(), sizeof(float) * d.nh_pad_l, hipMemcpyHostToDevice, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
@@ -557,6 +563,7 @@ int plm_ctx_set_weights(plm_ctx_t *c, const float *weights_host) {
     HIP_TRY(hipStreamSynchronize(c->st));
     c->n_eff = neff;
     c->have_weights = true;
+    c->eval_valid = false;
     return PLM_OK;
 }
 
@@ -596,6 +603,7 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set: call plm_ctx_reweight / plm_ctx_set_weights");
     if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "marginals run unsharded (create a 1-shard context)");
+    c->eval_valid = false;   // g is used as scratch below
     HIP_TRY(hipSetDevice(c->device));
     const PlmDims &d = c->d;
     // weighted one-hot Gram matrix through the backward GEMM: G = X^T diag(w) X
@@ -642,6 +650,7 @@ int plm_ctx_set_x(plm_ctx_t *c, const float *x_canonical_host) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     HIP_TRY(hipSetDevice(c->device));
     if (!x_canonical_host) return set_start_point(c);
+    c->eval_valid = false;
     const PlmDims &d = c->d;
     HIP_TRY(hipMemcpyAsync(c->canon, x_canonical_host, sizeof(float) * d.n_canon, hipMemcpyHostToDevice, c->st));
     HIP_TRY(plm_launch_canon_to_native(d, c->canon, c->x, c->st));
@@ -678,10 +687,14 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
     HIP_TRY(hipSetDevice(c->device));
     PLM_TRY(ctx_eval_enqueue(c));
     if (c->d.sharded) PLM_TRY(ctx_allreduce_scalars(c, 0, 2));   // every shard must call eval together
+    c->eval_valid = false;
     if (fx_out || nll_out) {
         PLM_TRY(fetch_scalars(c, 0, 2));
         if (fx_out) *fx_out = c->h_scal[0];
         if (nll_out) *nll_out = c->h_scal[1];
+        c->eval_valid = true;
+        c->last_fx = c->h_scal[0];
+        c->last_nll = c->h_scal[1];
     }
     return PLM_OK;
 }
@@ -772,18 +785,21 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         return PLM_OK;
     };
 
-    PLM_TRY(ctx_eval_enqueue(c));
+    // objective and gradient at the start point -- unless this context still holds them (a resumed fit)
+    const bool resume = c->eval_valid;
+    if (!resume) PLM_TRY(ctx_eval_enqueue(c));
     {
         const float *a[1] = {c->g};
         PLM_TRY(dots(c, 1, a, a, n, SL_DG));
         PLM_TRY(norm_dots());
-        PLM_TRY(ctx_allreduce_scalars(c, 0, 8));
+        PLM_TRY(ctx_allreduce_scalars(c, resume ? SL_DG : 0, resume ? 8 - SL_DG : 8));
         PLM_TRY(fetch_scalars(c, 0, 8));
         gg = c->h_scal[SL_DG];
         xx = c->h_scal[SL_XX];
         hh = c->h_scal[SL_HH];
     }
-    double fx = c->h_scal[SL_FX], nll = c->h_scal[SL_NLL];
+    double fx = resume ? c->last_fx : c->h_scal[SL_FX], nll = resume ? c->last_nll : c->h_scal[SL_NLL];
+    c->eval_valid = false;
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
     if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) > eps) {
@@ -923,6 +939,9 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         }
     }
     HIP_TRY(hipStreamSynchronize(c->st));
+    c->eval_valid = true;   // every exit path above leaves the last accepted point in (x, g)
+    c->last_fx = fx;
+    c->last_nll = nll;
     if (res) {
         res->iters_done = k;
         res->n_evals = c->n_evals;
@@ -987,6 +1006,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
     if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "kernel timing runs on 1-shard contexts");
     HIP_TRY(hipSetDevice(c->device));
+    c->eval_valid = false;
     const PlmDims &d = c->d;
     hipEvent_t ev[6];
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));

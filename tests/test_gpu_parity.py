@@ -643,3 +643,29 @@ def test_meanfield_rejects_bad_input(plm):
         plm.mean_field(msa, 21, pseudo_count=0.0)            # pseudo-count outside (0, 1)
     with pytest.raises(PlmError):
         plm.mean_field(msa, 7)                               # alphabet size not instantiated
+
+
+def test_resumed_optimisation_skips_the_known_start_point(plm):
+    """A second optimize() on the same context starts from the point and gradient the first one left behind.
+    Forcing the re-evaluation (set_x of the same vector) costs exactly one more evaluation and changes nothing."""
+    msa, _ = synthetic_msa(400, 40, seed=5)
+
+    def ctx():
+        c = plm.PlmContext(msa, q=Q, max_iter=15, epsilon=1e-12)
+        c.reweight(); c.marginals(pairs=False); c.set_x(None)
+        return c
+
+    a = ctx()
+    a1 = a.optimize()
+    a._set_max_iter(25)
+    a2 = a.optimize()                                 # resumed
+    b = ctx()
+    b1 = b.optimize()
+    b.set_x(b.get_x())                                # same point, but the context no longer trusts (x, g)
+    b._set_max_iter(25)
+    b2 = b.optimize()                                 # evaluates the start point first
+    assert a1["iters"] == b1["iters"] == 15 and a2["iters"] == b2["iters"] == 25
+    assert a1["fx"] == b1["fx"]
+    assert b2["n_evals"] == a2["n_evals"] + 1
+    assert a2["fx"] == b2["fx"] and a2["fx"] < a1["fx"]
+    np.testing.assert_array_equal(a.get_x(), b.get_x())
