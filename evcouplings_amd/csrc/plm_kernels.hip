@@ -42,6 +42,14 @@ typedef unsigned int u32;
 // the step, waves 4-7 (the SIMD partners of 0-3) this far into it.  Issuing a piece blocks a wave for
 // ~100-200 cycles; when both waves of a SIMD do that at the same time the MFMA pipe idles, but pieces issued
 // late land late.  Measured on MI355X (ms, stagger 0/4/8/12): k_fwd 5.42/5.27/5.59/5.69, k_bwd 5.19/5.46/5.50/5.46.
+// PLM_FWD_SPLIT=1: the solver's forward pass runs k_fwd_split (states of a site block split over the two waves
+// of a SIMD, B fragments reused by 4 row fragments: half the LDS fragment reads, no register spills) instead of
+// k_fwd.  Parity-green and measured on MI355X: the same time (5.27 vs 5.14-5.42 ms) from 8 % MORE shader cycles --
+// the chip runs these kernels at its power limit (clock ~15 % below the first version's), so the LDS energy
+// saved is spent again on twice the one-hot expansions.  Kept as an alternative, not the default.
+#ifndef PLM_FWD_SPLIT
+#define PLM_FWD_SPLIT 0
+#endif
 #ifndef PLM_DMA_STAGGER_FWD
 #define PLM_DMA_STAGGER_FWD 4
 #endif
@@ -789,6 +797,195 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
 #endif
 }
 
+// =========================================================================================
+// K_fwd_split: the solver's forward kernel with the states of a site block split over the two waves of a
+// SIMD (PLM_FWD_SPLIT).  Workgroup = 256 sequences x one 16-site block as in k_fwd, but wave w owns the 64
+// sequences of group w & 3 and the states of half w >> 2 (ceil(Q/2) states for half 0, floor(Q/2) for half 1;
+// waves w and w+4 share a SIMD, so every SIMD still sees all Q states).  Every B fragment read from LDS now
+// feeds 4 row fragments instead of 2: half the LDS fragment traffic of k_fwd for the same MFMA work.  The
+// softmax over states needs the partner wave's maximum and sum: two small exchanges through LDS.
+// =========================================================================================
+// B fragment number F = 2 * state + plane of a K step: one ds_read_b128, 4 MFMAs (one per row fragment).  A ring
+// of three single fragments (12 VGPRs): fragment F+2 is requested before fragment F computes.
+template <int N> __device__ __forceinline__ void lds_wait1(half8 &a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+// One code path for both halves: NS0 = ceil(Q/2) states are stepped through; for odd Q the half with one state
+// less still reads the two fragments of the surplus state (they lie just behind its own; the launcher adds 1 KB of
+// LDS for the very last one) but skips their MFMAs -- a wave-uniform branch around 4 instructions.
+template <int Q, int F>
+__device__ __forceinline__ void fwds_frag(f32x4 (&acc)[4][(Q + 1) / 2], const half8 (&af)[4], u32 lb, half8 (&bq)[3],
+                                          const DmaPlan &dma, bool last_state_live) {
+    constexpr int NS0 = (Q + 1) / 2, NP = (2 * Q + 7) / 8, TOT = 2 * NS0, A = F / 2;
+    constexpr int F2 = F + 2;
+    if constexpr (F2 < TOT) bq[F2 % 3] = lds_read_b128<((F2 & 1) ? Q + F2 / 2 : F2 / 2) * 1024>(lb);
+    lds_wait1<(TOT - 1 - F < 2) ? (TOT - 1 - F) : 2>(bq[F % 3]);
+    if (A < NS0 - 1 || (Q % 2 == 0) || last_state_live) {
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+            acc[m][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bq[F % 3], acc[m][A], 0, 0, 0);
+    }
+    if constexpr ((F & 1) == 0) dma_at<NS0, A, NP, PLM_DMA_STAGGER_FWD>(dma);
+}
+template <int Q, int... F>
+__device__ __forceinline__ void fwds_kstep(f32x4 (&acc)[4][(Q + 1) / 2], const half8 (&af)[4], u32 lb,
+                                           const DmaPlan &dma, bool last_state_live,
+                                           std::integer_sequence<int, F...>) {
+    half8 bq[3];
+    bq[0] = lds_read_b128<0>(lb);
+    bq[1] = lds_read_b128<Q * 1024>(lb);
+    (fwds_frag<Q, F>(acc, af, lb, bq, dma, last_state_live), ...);
+}
+
+template <int Q>
+__global__ __launch_bounds__(512) void k_fwd_split(PlmDims d, FwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 2 * Q * 1024, NP = (2 * Q + 7) / 8, NS0 = (Q + 1) / 2, NS1 = Q / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int sg = wave_s & 3, sh = wave_s >> 2;          // sequence group, state half
+    const int a_lo = sh ? NS0 : 0, ns = sh ? NS1 : NS0;   // own states [a_lo, a_lo + ns)
+    const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
+    const int b16 = d.b16_lo + b16l;
+    const int r = lane & 15, g = lane >> 4;
+    const int s_wave = stile * PLM_SEQ_TILE + sg * 64;
+    const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE;
+    u32 arow[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) arow[m] = (u32)(s_wave + 16 * m + r) * (u32)d.Lp32 + 8 * g;
+
+    f32x4 acc[4][NS0];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int a = 0; a < NS0; a++) acc[m][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int gap = d.gap_mode, nsteps = d.nu * (Q - gap);
+    {
+        const DmaPlan first{bt + (size_t)gap * TILE, smem, wave_s, 2 * Q, (u32)lane * 16, false};
+        dma_issue_all<NP>(first);
+    }
+    // alignment bytes of the 4 row fragments for the current 32 sites; the next 32 are fetched IN PLACE during
+    // the last K step of this u (after its one-hot fragments are built) and land under that step's MFMAs
+    u64 xa[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) xa[m] = *(const u64 *)(A.msa_rm + arow[m]);
+    int t = 0;
+    for (int u = 0; u < d.nu; ++u) {
+        for (int b = gap; b < Q; ++b, ++t) {
+            const int ks_next = (b + 1 < Q) ? u * Q + b + 1 : (u + 1) * Q + gap;
+            vm_wait<0>();
+            __syncthreads();
+            const DmaPlan dma{bt + (size_t)ks_next * TILE, smem + ((t + 1) & 1) * TILE, wave_s,
+                              (t + 1 < nsteps) ? 2 * Q : 0, (u32)lane * 16, wave_s >= 4};
+            const u32 lb = lds_addr(smem + (t & 1) * TILE + a_lo * 1024 + lane * 16);
+            const u32 bb = (u32)b * 0x01010101u;
+            half8 af[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                vm_landed(xa[m]);
+                af[m] = onehot8((u32)xa[m], (u32)(xa[m] >> 32), bb);
+            }
+            if (b == Q - 1 && u + 1 < d.nu) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) load_b64_inplace(xa[m], A.msa_rm, arow[m] + 32 * (u + 1));
+            }
+            fwds_kstep<Q>(acc, af, lb, dma, ns == NS0, std::make_integer_sequence<int, 2 * NS0>{});
+        }
+    }
+
+    // ---- epilogue: softmax over all Q states = own states + the partner wave's (max, sum) ----------
+    // Three phases separated by barriers; nothing but the accumulators stays in registers across them (the
+    // per-(sequence, site) scalars go through LDS or are reloaded: 256 VGPRs hold 176 accumulator registers).
+    __syncthreads();                                  // the B tiles are dead: LDS becomes the exchange area
+    float *ex = (float *)smem;                         // [half][sg][k = 4 m + reg][lane]: max, then sum
+    float *exh = ex + 2 * 4 * 16 * 64;                 // [wave][k][lane]: H of the observed state - max
+    const int my = ((sh * 4 + sg) * 16) * 64 + lane, other = (((1 - sh) * 4 + sg) * 16) * 64 + lane;
+    const float sc = ldexpf(1.f, -(*A.jexp));
+    const int i = b16 * 16 + r;
+    const bool site_ok = i < d.L;
+    {
+        float hv[NS0];
+#pragma unroll
+        for (int a = 0; a < NS0; a++) hv[a] = (site_ok && a < ns) ? A.h[(size_t)(i - d.h_site0) * Q + a_lo + a] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int m = k >> 2, reg = k & 3;
+            float v = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < NS0; a++) {
+                const bool dead = a >= ns || (gap && a_lo + a == 0);
+                const float H = dead ? -INFINITY : fmaf(acc[m][a][reg], sc, hv[a]);
+                acc[m][a][reg] = H;
+                v = fmaxf(v, H);
+            }
+            ex[my + k * 64] = v;
+        }
+    }
+    __syncthreads();
+    float mx[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) mx[k] = fmaxf(ex[my + k * 64], ex[other + k * 64]);
+    __syncthreads();                                  // everybody has read the maxima: the area now takes the sums
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int m = k >> 2, reg = k & 3;
+        const int s = s_wave + 16 * m + 4 * g + reg;
+        const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
+        float Z = 0.f, h = 0.f;
+#pragma unroll
+        for (int a = 0; a < NS0; a++) {
+            const float H = acc[m][a][reg] - mx[k];   // -inf for states this wave does not own
+            h = (a_lo + a == xi && a < ns) ? H : h;
+            const float ev = __expf(H);
+            acc[m][a][reg] = ev;
+            Z += ev;
+        }
+        ex[my + k * 64] = Z;
+        exh[(wave_s * 16 + k) * 64 + lane] = h;
+    }
+    __syncthreads();
+    float fxl = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int m = k >> 2, reg = k & 3;
+        const int s = s_wave + 16 * m + 4 * g + reg;
+        const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
+        const bool skip = gap && xi == 0;            // gapped site: no conditional for (s, i)
+        const float ws = skip ? 0.f : A.w[s];
+        const float Z = ex[my + k * 64] + ex[other + k * 64];
+        const float invZ = 1.f / Z;
+        const bool mine = xi >= a_lo && xi < a_lo + ns && !skip;
+        // -w log P(x_si | rest) is added by the wave that owns the observed state
+        if (site_ok && mine) fxl -= ws * (exh[(wave_s * 16 + k) * 64 + lane] - __logf(Z));
+        const float wr = site_ok ? ws * A.rscale : 0.f;
+#pragma unroll
+        for (int a = 0; a < NS0; a++)
+            acc[m][a][reg] = wr * (acc[m][a][reg] * invZ - ((a_lo + a == xi) ? 1.f : 0.f));
+    }
+    // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes), own states only ---------
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int sstep = (s_wave >> 5) + (m >> 1);
+        _Float16 *rt = A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q + a_lo) * 1024;
+        const int slot = ((2 * (m & 1) + (g >> 1)) * 16 + r) * 8 + (g & 1) * 4;
+#pragma unroll
+        for (int a = 0; a < NS0; a++) {
+            if (a < ns) {
+                const f32x4 v = acc[m][a];
+                half4 hi, lo;
+                hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[2]; hi[2] = (_Float16)v[1]; hi[3] = (_Float16)v[3];
+                lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[2] - (float)hi[1]);
+                lo[2] = (_Float16)(v[1] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
+                *(half4 *)(rt + (size_t)a * 1024 + slot) = hi;
+                *(half4 *)(rt + (size_t)a * 1024 + 512 + slot) = lo;
+            }
+        }
+    }
+    __syncthreads();
+    const double tot = block_reduce_sum((double)fxl, (double *)smem);
+    if (tid == 0) A.fx_part[blockIdx.x] = tot;
+}
+
 static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
@@ -807,7 +1004,18 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
     }
 #define FWD_CASE(QQ)                                                                                   \
     case QQ:                                                                                           \
-        if (mode == FWD_SOLVER) FWD_LAUNCH(QQ, FWD_SOLVER)                                             \
+        if (mode == FWD_SOLVER && PLM_FWD_SPLIT && !PLM_PIPE) {                                        \
+            const size_t lds_s = (lds > 65536 ? lds : 65536) + 1024;   /* tiles (+1 KB overread), 64 KB exchange */ \
+            static bool attr_done_dev[PLM_MAX_DEVICES] = {false};                                      \
+            bool &attr_done = attr_done_dev[plm_current_device()];                                     \
+            if (!attr_done) {                                                                          \
+                hipError_t e = hipFuncSetAttribute((const void *)k_fwd_split<QQ>,                      \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); \
+                if (e != hipSuccess) return e;                                                         \
+                attr_done = true;                                                                      \
+            }                                                                                          \
+            hipLaunchKernelGGL((k_fwd_split<QQ>), grid, block, lds_s, st, d, A);                       \
+        } else if (mode == FWD_SOLVER) FWD_LAUNCH(QQ, FWD_SOLVER)                                      \
         else if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                        \
         else FWD_LAUNCH(QQ, FWD_POTENTIALS)                                                            \
         break;
