@@ -4,10 +4,15 @@
 // process that evcouplings/couplings/tools.py:266 launches:
 //   k_reweight   N x N Hamming identity counts on the packed int8 alignment (VALU, integer)
 //   k_expand     parameters -> forward B operand (f16 hi/lo MFMA fragments)
-//   k_fwd        one-hot(MSA) x J on MFMA + per-site softmax + residuals + -log P (fused)
+//   k_fwd        one-hot(MSA) x J on MFMA + per-site softmax + residuals + -log P (fused); two more
+//                epilogues turn the same GEMM into statistical energies / potentials of sequences under a
+//                fitted model (row N2); k_fwd_split is a measured alternative tiling (PLM_FWD_SPLIT)
 //   k_bwd        one-hot(MSA)^T x residuals on MFMA -> asymmetric gradient slab
 //   k_assemble   slab + slab^T + L2 term -> gradient, regulariser partial sums
-// plus small streaming kernels for L-BFGS (dots / linear combinations) and scoring.
+// plus small streaming kernels for L-BFGS (dots / linear combinations) and scoring.  Mean-field DCA
+// (covariance inverse, fields, direct information) lives in plm_meanfield.hip.
+// Compile-time experiment switches (all off / neutral in the product build; DESIGN.md 4.3 has the measurements):
+// PLM_PIPE, PLM_FWD_SPLIT, PLM_DMA_STAGGER_*, PLM_ASYNC_A, PLM_ABLATE, PLM_PROBE.
 //
 // The alignment is int8 in HBM; one-hot MFMA A fragments are expanded from 8 packed bytes
 // in registers (never materialised in memory); the dense operand (couplings / residuals)
