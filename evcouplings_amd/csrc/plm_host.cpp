@@ -1330,7 +1330,15 @@ static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int devi
         if (!rc && result->hi) memcpy(result->hi, x.data(), sizeof(float) * L * q);
         if (!rc && result->jij) memcpy(result->jij, x.data() + (size_t)L * q, sizeof(float) * npq);
     }
-    if (!rc && result->fn && result->cn) rc = plm_ctx_scores(c, result->fn, result->cn);
+    if (!rc && (result->fn || result->cn)) {   // either score matrix may be asked for on its own
+        std::vector<float> spare;
+        float *fn = result->fn, *cn = result->cn;
+        if (!fn || !cn) {
+            spare.resize((size_t)c->d.L * c->d.L);
+            (fn ? cn : fn) = spare.data();
+        }
+        rc = plm_ctx_scores(c, fn, cn);
+    }
     if (!rc) {
         if (result->weights) memcpy(result->weights, w.data(), sizeof(float) * N);
         if (result->fi) memcpy(result->fi, fi.data(), sizeof(float) * L * q);

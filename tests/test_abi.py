@@ -49,3 +49,28 @@ def test_no_cpu_fallback_without_a_gpu():
         plm.reweight(np.zeros((4, 8), np.int8), 0.8)
     with pytest.raises(_lib.PlmError):
         plm.fit(np.zeros((4, 8), np.int8), q=21, max_iter=1)
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.join(root, "evcouplings_amd")
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "c_host.c"), "-L" + libdir, "-lplm_hip", "-Wl,-rpath," + libdir, "-o", exe]
+    run = subprocess.run(cmd, capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    return exe
+
+
+def test_plain_c_host_compiles_and_links_against_the_header(tmp_path):
+    """include/plm_hip.h is valid C11 and the library satisfies a C host's link (examples/c_host.c)."""
+    assert os.path.exists(_build_c_host(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_host_fits_and_finds_the_planted_pair(tmp_path):
+    import subprocess
+    run = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "top long-range pair 7 29" in run.stdout and "iter 10" in run.stderr
