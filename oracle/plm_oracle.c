@@ -11,6 +11,10 @@
  *     - sequence reweighting      <- evcouplings/align/alignment.py:1193-1233
  *     - single / pair frequencies <- evcouplings/align/alignment.py:1079-1153
  *     - zero-sum gauge, FN, APC   <- evcouplings/couplings/model.py:179-233, 744-827
+ *     - statistical energies, single-mutant matrix (rows N2)
+ *                                 <- evcouplings/couplings/model.py:25-109 (tests/golden/energies_L12.npz, exact)
+ *     (mean-field DCA, row N4, is restated in oracle/meanfield_ref.py and pinned by
+ *      tests/golden/meanfield_{a,d}.npz <- evcouplings/couplings/mean_field.py:717-1014)
  *   PARITY UNPINNED (no reference code, test or golden vector exists for it; the
  *   arithmetic lives in the un-vendored, un-versioned third-party `plmc` program,
  *   reached only through evcouplings/couplings/tools.py:202-266):
