@@ -9,6 +9,10 @@ attribute ``ct.run_plmc``, so the ``standard`` (:363) and ``complex`` (:480) pro
 unchanged on top of the GPU inference.  ``uninstall()`` restores the subprocess path.
 
 The alternative that needs no Python hook at all is the CLI shim: ``tools: plmc: bin/plmc_hip``.
+
+``install_all()`` additionally installs the optional GPU drop-ins of the rows SURVEY.md section 8f lists:
+statistical energies behind ``CouplingsModel`` (``model_accel``), mean-field DCA (``mean_field``) and the
+alignment statistics behind ``Alignment`` (``alignment_accel``).
 """
 from evcouplings_amd import tools
 
@@ -42,3 +46,20 @@ def infer_plmc(**kwargs):
         return cp.infer_plmc(**kwargs)
     finally:
         uninstall()
+
+
+def install_all():
+    """run_plmc + the N2 / N3 / N4 drop-ins (model energies, alignment statistics, mean-field DCA)."""
+    from evcouplings_amd import alignment_accel, mean_field, model_accel
+    install()
+    model_accel.install()
+    mean_field.install()
+    alignment_accel.install()
+
+
+def uninstall_all():
+    from evcouplings_amd import alignment_accel, mean_field, model_accel
+    alignment_accel.uninstall()
+    mean_field.uninstall()
+    model_accel.uninstall()
+    uninstall()

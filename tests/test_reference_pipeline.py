@@ -317,3 +317,37 @@ def test_reference_complex_protocol_runs_on_our_backend(ref, gpu_fit, golden_dir
     # sites 13..24 of the model were renumbered into the second segment's coordinates
     assert inter["j"].min() == 122 and inter["j"].max() == 133 and inter["i"].max() == 21
     assert "probability" in ecs.columns
+
+
+def test_model_accel_behind_the_reference_couplings_model(ref, golden_dir, monkeypatch):
+    """install_all(): the reference's CouplingsModel methods (hamiltonians, smm, dmm, delta_hamiltonian) run on our
+    wrappers and give the numbers of the reference's own loops (plm.* stands on the C oracle here: no GPU)."""
+    import evcouplings.couplings.model as ref_model
+    from evcouplings_amd import plm, protocol as hip_protocol
+    from oracle.oracle import Oracle
+    o = Oracle("f64")
+
+    def canon(hi, jij):
+        return np.concatenate([np.asarray(hi, np.float64).ravel(), np.asarray(jij, np.float64).ravel()])
+
+    monkeypatch.setattr(plm, "hamiltonians", lambda seqs, q, hi, jij, device=0: o.hamiltonians(seqs, q, canon(hi, jij)))
+    monkeypatch.setattr(plm, "single_mutant_matrix",
+                        lambda t, q, hi, jij, device=0: o.single_mutants(np.asarray(t).ravel(), q, canon(hi, jij)))
+    path = os.path.join(golden_dir, "hip_fit_L24.model")
+    slow = ref["CouplingsModel"](path)
+    seqs = ["".join(slow.target_seq)] + ["".join(np.roll(slow.target_seq, k)) for k in (1, 5)]
+    H_slow, smm_slow, dmm_slow = slow.hamiltonians(seqs), slow.smm(), slow.dmm()
+    hip_protocol.install_all()
+    try:
+        assert ref_model._hamiltonians.__module__ == "evcouplings_amd.model_accel"
+        fast = ref["CouplingsModel"](path)
+        H_fast, smm_fast, dmm_fast = fast.hamiltonians(seqs), fast.smm(), fast.dmm()
+        muts = [(12, slow.target_seq[2], "W"), (20, slow.target_seq[10], "K")]     # positions in index_list numbering
+        d_fast = fast.delta_hamiltonian(muts)
+    finally:
+        hip_protocol.uninstall_all()
+    assert ref_model._hamiltonians.__module__ != "evcouplings_amd.model_accel"
+    np.testing.assert_allclose(H_fast, H_slow, rtol=1e-6, atol=1e-6)       # float32 parameters either way
+    np.testing.assert_allclose(smm_fast, smm_slow, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dmm_fast, dmm_slow, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(d_fast, slow.delta_hamiltonian(muts), rtol=1e-6, atol=1e-6)
