@@ -351,3 +351,39 @@ def test_model_accel_behind_the_reference_couplings_model(ref, golden_dir, monke
     np.testing.assert_allclose(smm_fast, smm_slow, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(dmm_fast, dmm_slow, rtol=1e-6, atol=1e-5)
     np.testing.assert_allclose(d_fast, slow.delta_hamiltonian(muts), rtol=1e-6, atol=1e-6)
+
+
+def test_mutate_stage_calculations_on_the_energy_drop_ins(ref, golden_dir, monkeypatch):
+    """the arithmetic of the reference's mutate stage (evcouplings/mutate/calculations.py: single_mutant_matrix,
+    predict_mutation_table) with model_accel installed gives the table the unpatched reference computes."""
+    import pandas as pd
+    import evcouplings.mutate.calculations as mc
+    from evcouplings_amd import model_accel, plm
+    from oracle.oracle import Oracle
+    o = Oracle("f64")
+
+    def canon(hi, jij):
+        return np.concatenate([np.asarray(hi, np.float64).ravel(), np.asarray(jij, np.float64).ravel()])
+
+    monkeypatch.setattr(plm, "hamiltonians", lambda seqs, q, hi, jij, device=0: o.hamiltonians(seqs, q, canon(hi, jij)))
+    monkeypatch.setattr(plm, "single_mutant_matrix",
+                        lambda t, q, hi, jij, device=0: o.single_mutants(np.asarray(t).ravel(), q, canon(hi, jij)))
+    path = os.path.join(golden_dir, "hip_fit_L24.model")
+    slow = ref["CouplingsModel"](path)
+    t = slow.target_seq
+    data = pd.DataFrame({"mutant": ["%s12W" % t[2], "%s20K,%s31D" % (t[10], t[21]), "wild"]})
+    want_singles = mc.single_mutant_matrix(slow, output_column="prediction_epistatic")
+    want_table = mc.predict_mutation_table(slow, data, "prediction_epistatic")
+    model_accel.install()
+    try:
+        fast = ref["CouplingsModel"](path)
+        got_singles = mc.single_mutant_matrix(fast, output_column="prediction_epistatic")
+        got_table = mc.predict_mutation_table(fast, data, "prediction_epistatic")
+    finally:
+        model_accel.uninstall()
+    assert list(got_singles.columns) == list(want_singles.columns) and len(got_singles) == len(want_singles) == 24 * 19
+    np.testing.assert_allclose(got_singles["prediction_epistatic"].values, want_singles["prediction_epistatic"].values,
+                               rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got_table["prediction_epistatic"].values.astype(float),
+                               want_table["prediction_epistatic"].values.astype(float), rtol=1e-6, atol=1e-6,
+                               equal_nan=True)
