@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("PLM_HIP_LIB") or os.path.join(_HERE, "libplm_hip.so")
 
 PLM_OK = 0
 STATUS_CONVERGED, STATUS_MAXITER, STATUS_LINESEARCH = 0, 1, 2
-K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_FIELDS, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
 
 ITER_CB = C.CFUNCTYPE(None, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                       C.c_double, C.c_double, C.c_void_p)

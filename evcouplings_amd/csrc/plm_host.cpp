@@ -119,6 +119,8 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
             if (cost < best_cost * 0.98) { best_cost = cost; best = ks; }
         }
         d.ksplit = best;
+        // measurement knob (tests/probes/noise_probe.py): force the split-K factor of the backward GEMM
+        if (const char *e = getenv("PLM_KSPLIT")) d.ksplit = std::max(1, std::min(ks_max, atoi(e)));
     }
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
@@ -170,6 +172,12 @@ struct plm_ctx {
     int32_t *jexp = nullptr;
     float *x = nullptr, *g = nullptr, *xp = nullptr, *gp = nullptr, *dir = nullptr, *hist = nullptr;
     float *canon = nullptr;    // canonical-layout staging (n_canon floats, + L*L for fn)
+    float *dinv = nullptr;     // H0 diagonal of the preconditioned L-BFGS (n_local floats), built by plm_ctx_optimize
+    // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
+    float *hj = nullptr, *hpart = nullptr;
+    double *hg2 = nullptr, *hinv = nullptr;
+    int vp_newton_total = 0;   // Newton steps on the fields taken by the current optimisation
+    int vp_hess_age = -1;      // field-solver passes since the cached inverse Hessians were refreshed (-1: none yet)
     int hist_m = 0;
     double *h_scal = nullptr;  // pinned host scalars
     bool have_weights = false;
@@ -177,7 +185,8 @@ struct plm_ctx {
     // changes x, the weights or the scratch use of g -- lets a follow-up plm_ctx_optimize (a resumed fit)
     // start from the known point instead of re-evaluating it
     bool eval_valid = false;
-    double last_fx = 0, last_nll = 0;
+    double last_fx = 0, last_nll = 0, last_gh2 = 0;
+    bool eval_vp = false;      // ... and g is the gradient of the reduced (variable-projection) objective
     double n_eff = 0;
     int n_evals = 0;
     std::vector<float> h_fi;   // L*q, kept for the start point
@@ -280,6 +289,98 @@ int ctx_eval_enqueue(plm_ctx *c) {
     return PLM_OK;
 }
 
+// ---- variable projection ------------------------------------------------------------
+// The fields enter the objective only through per-site, strictly convex subproblems (for fixed couplings), so
+// the fit runs L-BFGS on  F(J) = min_h f(h, J):  an evaluation computes the coupling part HJ of every conditional
+// with the forward GEMM, solves the fields by Newton (k_hpass / k_hsolve, HJ streamed from HBM once per step),
+// and returns dF/dJ = df/dJ at (h*(J), J) (envelope theorem).  x's field part is overwritten with h*(J); the
+// field part of g is zero.  scal[SL_GH2 = 5] = squared gradient norm of the field subproblems at the returned point.
+bool vp_enabled(const plm_ctx *c) {
+    return !(c->prob.flags & PLM_FLAG_JOINT_LBFGS) && (c->d.nshards == 1 || c->d.sharded);
+}
+int vp_alloc(plm_ctx *c) {
+    if (c->hj) return PLM_OK;
+    const size_t nsites = (size_t)std::max(1, (c->d.b16_hi - c->d.b16_lo) * 16);
+    PLM_TRY(dalloc((char **)&c->hj, plm_hj_bytes(c->d)));
+    PLM_TRY(dalloc((char **)&c->hpart, plm_hpart_bytes(c->d)));
+    PLM_TRY(dalloc(&c->hg2, nsites));
+    PLM_TRY(dalloc(&c->hinv, nsites * c->d.Q * c->d.Q));
+    c->vp_hess_age = -1;
+    return PLM_OK;
+}
+// stage 1: forward GEMM (couplings of x) -> HJ
+int vp_stage1(plm_ctx *c) {
+    const PlmDims &d = c->d;
+    if (d.sharded) {
+        HIP_TRY(plm_launch_pack_x(d, c->x, c->xsend, c->st));
+        PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
+        HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
+                                   d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, c->st));
+        HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
+    } else {
+        HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
+        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
+    }
+    HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
+    return PLM_OK;
+}
+// stage 2: `newton` Newton steps on the fields from their current values, then the residual pass at the result
+// (Rt, -log P partials) with the gradient norm of the field subproblems -> scal[5].  refresh: the first step
+// recomputes the per-site Hessians (a pass with 12x the arithmetic), otherwise the cached inverses are reused.
+int vp_stage2(plm_ctx *c, int newton, bool refresh) {
+    const PlmDims &d = c->d;
+    for (int it = 0; it < newton; it++) {
+        const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
+        HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 0, full ? 2 : 1, nullptr, nullptr, c->hpart, c->st));
+        HIP_TRY(plm_launch_hsolve(d, c->hpart, full, c->x, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, c->st));
+        c->vp_hess_age = full ? 0 : c->vp_hess_age + 1;
+    }
+    c->vp_newton_total += newton;
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 1, 1, c->Rt, c->fx_part, c->hpart, c->st));
+    HIP_TRY(plm_launch_hsolve(d, c->hpart, 0, c->x, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, c->st));
+    return PLM_OK;
+}
+// stage 3: backward GEMM, gradient of the reduced objective, objective value
+int vp_stage3(plm_ctx *c) {
+    const PlmDims &d = c->d;
+    if (d.nblk_own > 0 || !d.sharded) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    if (d.sharded) {
+        HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
+        PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
+    }
+    // mode 2: gradient of the reduced objective (field part zero), regulariser sums as usual
+    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, d.sharded ? c->ghalo : nullptr, c->x, c->g, c->prob.lambda_h,
+                                c->prob.lambda_j, c->reg_part, 2, 0.f, c->st));
+    HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d), c->scal,
+                                 c->st));
+    return PLM_OK;
+}
+// the whole evaluation: the field solver iterates until the subproblem gradient is below tol2 (or stalls at its
+// f32 summation floor); the check costs one extra host synchronisation per evaluation (sharded: one scalar all-reduce)
+int ctx_allreduce_scalars(plm_ctx *c, int first, int count);
+int fetch_scalars(plm_ctx *c, int first, int count);
+int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
+    PLM_TRY(vp_stage1(c));
+    double prev = INFINITY;
+    int newton = *newton_io, used = 0;
+    for (int round = 0;; round++) {
+        PLM_TRY(vp_stage2(c, newton, round > 0 ? c->vp_hess_age > 0 : c->vp_hess_age >= 24));
+        used += newton;
+        PLM_TRY(ctx_allreduce_scalars(c, 5, 1));
+        PLM_TRY(fetch_scalars(c, 5, 1));
+        const double gh2 = c->h_scal[5];
+        *gh2_out = gh2;
+        // done: converged, or not finite (the line search deals with that), or no longer improving (summation floor)
+        if (!(gh2 > tol2) || round >= 8 || (round > 0 && gh2 > 0.25 * prev)) break;
+        prev = gh2;
+        newton = 2;
+    }
+    // next evaluation: as many steps as this one needed, one fewer if the first round overshot the tolerance by far
+    *newton_io = std::max(1, std::min(4, used - ((used > 1 && *gh2_out < 1e-3 * tol2) ? 1 : 0)));
+    PLM_TRY(vp_stage3(c));
+    c->n_evals++;
+    return PLM_OK;
+}
 int fetch_scalars(plm_ctx *c, int first, int count) {
     HIP_TRY(hipMemcpyAsync(c->h_scal + first, c->scal + first, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
@@ -434,7 +535,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     hipSetDevice(c->device);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend};
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->hg2, c->hinv};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);
@@ -513,6 +614,7 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     CT(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(d), c->st));
     CT(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_local, c->st));
     CT(hipMemsetAsync(c->g, 0, sizeof(float) * d.n_local, c->st));
+    CT(hipMemsetAsync(c->scal, 0, sizeof(double) * 256, c->st));   // slots nobody writes still travel in all-reduces
     if (c->gather) CT(hipMemsetAsync(c->gather, 0, plm_slab_bytes(d) * d.nshards, c->st));
     CT(hipStreamSynchronize(c->st));
 #undef CT
@@ -693,6 +795,7 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
         if (fx_out) *fx_out = c->h_scal[0];
         if (nll_out) *nll_out = c->h_scal[1];
         c->eval_valid = true;
+        c->eval_vp = false;
         c->last_fx = c->h_scal[0];
         c->last_nll = c->h_scal[1];
     }
@@ -723,15 +826,41 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     const double epsf = 1e-6;
     PLM_TRY(ctx_alloc_lbfgs(c, m));
     float *S = c->hist, *Y = c->hist + (size_t)m * n;
-    // Gram matrix pieces, indexed by history slot
-    std::vector<double> SS(m * m, 0.0), SY(m * m, 0.0), YY(m * m, 0.0), Sg(m, 0.0), Yg(m, 0.0);
-    double gg = 0, xx = 0, hh = 0;
+    // H0 = gamma * D^-1 with D the Hessian diagonal of the independent-site model at the start point (closed form
+    // from the single-site frequencies).  The recursion only ever needs s.y, s.g and the D^-1-weighted products of
+    // {y_j, g}.  Opt-in (PLM_FLAG_PRECOND): measured to need MORE iterations than the scalar H0 at L = 300.
+    const bool precond = (c->prob.flags & PLM_FLAG_PRECOND) && !c->h_fi.empty();
+    if (precond) {
+        if (!c->dinv) PLM_TRY(dalloc(&c->dinv, (size_t)n));
+        const size_t lq = (size_t)d.L * d.Q;
+        std::vector<float> fv(2 * lq, 0.f);
+        const int a0 = d.gap_mode;
+        for (int i = 0; i < d.L; i++) {
+            double tot = 0;
+            for (int a = a0; a < d.Q; a++) tot += (double)c->h_fi[i * d.Q + a] + 1.0 / c->n_eff;
+            for (int a = a0; a < d.Q; a++) {
+                const double pa = ((double)c->h_fi[i * d.Q + a] + 1.0 / c->n_eff) / tot;   // the start point's P_i(a)
+                fv[i * d.Q + a] = c->h_fi[i * d.Q + a];
+                fv[lq + i * d.Q + a] = (float)(pa * (1.0 - pa));
+            }
+        }
+        // staged through the gradient buffer's tail?  no: a small dedicated upload into canon (free during optimize)
+        HIP_TRY(hipMemcpyAsync(c->canon, fv.data(), sizeof(float) * fv.size(), hipMemcpyHostToDevice, c->st));
+        HIP_TRY(plm_launch_precond(d, c->canon, (float)c->n_eff, (float)c->prob.lambda_h, (float)c->prob.lambda_j,
+                                   c->dinv, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));   // fv leaves scope
+    }
+    const float *dinv = precond ? c->dinv : nullptr;
+    // Gram matrix pieces, indexed by history slot: SY[i][j] = s_i.y_j, YDY[i][j] = y_i.D^-1 y_j, Sg = s_i.g,
+    // YDg = y_i.D^-1 g, gDg = g.D^-1 g, gg = g.g (stop rule)
+    std::vector<double> SY(m * m, 0.0), YDY(m * m, 0.0), Sg(m, 0.0), YDg(m, 0.0);
+    double gg = 0, gDg = 0, xx = 0, hh = 0;
     std::vector<double> alpha(m), cs(m), cy(m);
     const double t0 = now_s();
     c->n_evals = 0;
     // device scalar slots; in sharded-state mode each fetch is preceded by a sum over the shards of
     // exactly the slots that were just written ([FX..DG] after an evaluation, [XX..MD+..] after the pass)
-    enum { SL_FX = 0, SL_NLL = 1, SL_DG = 2, SL_XX = 3, SL_HH = 4, SL_MD = 8 };
+    enum { SL_FX = 0, SL_NLL = 1, SL_DG = 2, SL_XX = 3, SL_HH = 4, SL_GH2 = 5, SL_MD = 8 };
 
     auto norm_dots = [&]() -> int {   // x.x (all) and x.x (fields only)
         const float *a[1] = {c->x};
@@ -740,34 +869,36 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         return PLM_OK;
     };
     auto direction = [&](int stored, int end, double *dginit) -> int {
-        // coefficients of p = sum cs[j] s_j + sum cy[j] y_j + cg g, two-loop in coefficient space
+        // p = sum cs[j] s_j + D^-1 (sum cy[j] y_j + cg g): two-loop recursion in coefficient space
         std::fill(cs.begin(), cs.end(), 0.0);
         std::fill(cy.begin(), cy.end(), 0.0);
         double cg = -1.0;
-        auto s_dot_p = [&](int i) {
+        // first loop: q = cg g + sum cy y lives in the plain space, only s_i.q is needed (cs is still zero)
+        auto s_dot_q = [&](int i) {
             double v = cg * Sg[i];
-            for (int j = 0; j < stored; j++) v += cs[j] * SS[i * m + j] + cy[j] * SY[i * m + j];
+            for (int j = 0; j < stored; j++) v += cy[j] * SY[i * m + j];
             return v;
         };
-        auto y_dot_p = [&](int i) {
-            double v = cg * Yg[i];
-            for (int j = 0; j < stored; j++) v += cs[j] * SY[j * m + i] + cy[j] * YY[i * m + j];
+        // second loop: r = sum cs s + D^-1 (cg g + sum cy y)
+        auto y_dot_r = [&](int i) {
+            double v = cg * YDg[i];
+            for (int j = 0; j < stored; j++) v += cs[j] * SY[j * m + i] + cy[j] * YDY[i * m + j];
             return v;
         };
         int j = end;
         for (int i = 0; i < stored; i++) {
             j = (j + m - 1) % m;
-            alpha[j] = s_dot_p(j) / SY[j * m + j];
+            alpha[j] = s_dot_q(j) / SY[j * m + j];
             cy[j] -= alpha[j];
         }
         if (stored > 0) {
             const int newest = (end + m - 1) % m;
-            const double gamma = SY[newest * m + newest] / YY[newest * m + newest];
+            const double gamma = SY[newest * m + newest] / YDY[newest * m + newest];
             cg *= gamma;
-            for (int i = 0; i < stored; i++) { cs[i] *= gamma; cy[i] *= gamma; }
+            for (int i = 0; i < stored; i++) cy[i] *= gamma;
         }
         for (int i = 0; i < stored; i++) {
-            const double beta = y_dot_p(j) / SY[j * m + j];
+            const double beta = y_dot_r(j) / SY[j * m + j];
             cs[j] += alpha[j] - beta;
             j = (j + 1) % m;
         }
@@ -775,35 +906,58 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         PlmCoefList C;
         B.n = 0;
         for (int i = 0; i < stored; i++) { B.v[B.n] = S + (size_t)i * n; C.c[B.n++] = (float)cs[i]; }
+        const int first_weighted = B.n;
         for (int i = 0; i < stored; i++) { B.v[B.n] = Y + (size_t)i * n; C.c[B.n++] = (float)cy[i]; }
         B.v[B.n] = c->g;
         C.c[B.n++] = (float)cg;
-        HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, c->st));
-        double dg = cg * gg;
-        for (int i = 0; i < stored; i++) dg += cs[i] * Sg[i] + cy[i] * Yg[i];
+        HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, dinv, first_weighted, c->st));
+        double dg = cg * gDg;
+        for (int i = 0; i < stored; i++) dg += cs[i] * Sg[i] + cy[i] * YDg[i];
         *dginit = dg;
         return PLM_OK;
     };
 
+    // variable projection: the fields are solved exactly for every trial couplings (vp_stage2); L-BFGS then only
+    // sees the couplings (field part of g is zero, field part of s = the change of the optimal fields)
+    const bool vp = vp_enabled(c);
+    if (vp) PLM_TRY(vp_alloc(c));
+    c->vp_newton_total = 0;
+    int vp_newton = 2;                       // Newton steps per evaluation (warm start: the L-BFGS extrapolation)
+    double gh2 = 0;                          // |grad_h|^2 left by the field solver at the current point
+    // field-solver tolerance: a fraction of what the stop rule allows the whole gradient
+    auto vp_tol2 = [&](double xnorm2) { const double t = 0.03 * eps * std::max(1.0, std::sqrt(xnorm2)); return t * t; };
     // objective and gradient at the start point -- unless this context still holds them (a resumed fit)
-    const bool resume = c->eval_valid;
-    if (!resume) PLM_TRY(ctx_eval_enqueue(c));
+    const bool resume = c->eval_valid && c->eval_vp == vp;
     {
-        const float *a[1] = {c->g};
-        PLM_TRY(dots(c, 1, a, a, n, SL_DG));
+        if (!resume) {
+            if (!vp) PLM_TRY(ctx_eval_enqueue(c));
+            else {
+                int first = 4;   // J = 0 typically: the start fields are near the independent-site optimum
+                PLM_TRY(ctx_eval_vp(c, &first, vp_tol2((double)d.L), &gh2));
+            }
+        }
+        PlmVecList Qg, Bg;
+        Qg.n = 1; Qg.v[0] = c->g;
+        Bg.n = 2; Bg.v[0] = c->g; Bg.v[1] = c->g;
+        HIP_TRY(plm_launch_multidot(Qg, Bg, n, c->dot_scratch, c->scal + SL_MD, dinv, 1u, 1ull, c->st));   // gDg, gg
         PLM_TRY(norm_dots());
-        PLM_TRY(ctx_allreduce_scalars(c, resume ? SL_DG : 0, resume ? 8 - SL_DG : 8));
-        PLM_TRY(fetch_scalars(c, 0, 8));
-        gg = c->h_scal[SL_DG];
+        PLM_TRY(ctx_allreduce_scalars(c, resume ? SL_DG : 0, (resume ? 8 - SL_DG : 8) + 2));
+        PLM_TRY(fetch_scalars(c, 0, 10));
+        gDg = c->h_scal[SL_MD];
+        gg = c->h_scal[SL_MD + 1];
         xx = c->h_scal[SL_XX];
         hh = c->h_scal[SL_HH];
     }
+    if (resume) gh2 = c->last_gh2;
     double fx = resume ? c->last_fx : c->h_scal[SL_FX], nll = resume ? c->last_nll : c->h_scal[SL_NLL];
     c->eval_valid = false;
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
-    if (std::sqrt(gg) / std::max(1.0, std::sqrt(xx)) > eps) {
-        double step = 1.0 / std::sqrt(gg);
+    if (std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx)) > eps) {
+        // first step: unit displacement along the plain gradient; the D^-1-scaled direction is Newton-like for the
+        // diagonal part of the Hessian, so it starts from min(1, that)
+        auto first_step = [&]() { return precond ? std::min(1.0, 1.0 / std::sqrt(gDg)) : 1.0 / std::sqrt(gg); };
+        double step = first_step();
         for (k = 1;; k++) {
             double dginit;
             PLM_TRY(direction(stored, end, &dginit));
@@ -820,12 +974,17 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             Qv.v[0] = s_new; Qv.v[1] = y_new; Qv.v[2] = c->g;       // c->g: the buffer the trial gradients land in
             B.n = 0;
             for (int i = 0; i < nst; i++) B.v[B.n++] = S + (size_t)i * n;
-            for (int i = 0; i < nst; i++) B.v[B.n++] = Y + (size_t)i * n;
+            unsigned long long wb = 0;                    // basis vectors that enter products in the H0 metric: Y, g
+            for (int i = 0; i < nst; i++) { wb |= 1ull << B.n; B.v[B.n++] = Y + (size_t)i * n; }
+            wb |= 1ull << B.n;
             B.v[B.n++] = c->g;
+            B.v[B.n++] = c->g;                            // once more, unweighted: g.g for the stop rule
+            const unsigned wq = 6u;                       // queries y_new and g
             int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
             double width = stpmax - stpmin, prev_width = 2.0 * width;
             double stx = 0, fxx = finit, dgx = dginit, sty = 0, fy = finit, dgy = dginit, stp = step, stmin, stmax;
             double trace[64][3];
+            double gh2_trial = 0;
             for (;;) {
                 if (brackt) { stmin = std::min(stx, sty); stmax = std::max(stx, sty); }
                 else { stmin = stx; stmax = stp + 4.0 * (stp - stx); }
@@ -834,7 +993,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     (brackt && stmax - stmin <= xtol * stmax))
                     stp = stx;
                 HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, (float)stp, c->dir, n, c->st));
-                PLM_TRY(ctx_eval_enqueue(c));
+                if (!vp) PLM_TRY(ctx_eval_enqueue(c));
+                else PLM_TRY(ctx_eval_vp(c, &vp_newton, vp_tol2(xx), &gh2_trial));
                 {
                     const float *a[1] = {c->g}, *b[1] = {c->dir};
                     PLM_TRY(dots(c, 1, a, b, n, SL_DG));
@@ -844,7 +1004,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     // synchronisation (and, sharded, one all-reduce) per trial brings back f, the directional
                     // derivative and everything the next direction needs.
                     HIP_TRY(plm_launch_sy(s_new, y_new, c->x, c->xp, c->g, c->gp, n, c->st));
-                    HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, c->st));
+                    HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, dinv, wq, wb, c->st));
                     PLM_TRY(norm_dots());
                     PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
                     PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
@@ -852,7 +1012,21 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 double dg = c->h_scal[SL_DG];
                 fx = c->h_scal[SL_FX];
                 nll = c->h_scal[SL_NLL];
-                if (!std::isfinite(fx)) { fx = INFINITY; dg = 0; }
+                if (!std::isfinite(fx) || !std::isfinite(dg)) {
+                    // the trial left the region where the objective is representable: the interpolation formulas
+                    // of mt_update are meaningless on it (NaN steps).  Make the trial the far end of the bracket
+                    // with a finite stand-in value and bisect towards the best point found so far.
+                    if (count < 64) { trace[count][0] = stp; trace[count][1] = INFINITY; trace[count][2] = 0; }
+                    if (++count >= max_ls) { lsrc = -5; break; }
+                    sty = stp;
+                    fy = fxx + std::fabs(fxx) + 1.0;
+                    dgy = std::fabs(dgx);
+                    brackt = 1;
+                    stp = stx + 0.5 * (stp - stx);
+                    width = std::fabs(sty - stx);
+                    prev_width = 2.0 * width;
+                    continue;
+                }
                 const double ftest1 = finit + stp * dgtest;
                 if (count < 64) { trace[count][0] = stp; trace[count][1] = fx - finit; trace[count][2] = dg; }
                 count++;
@@ -899,7 +1073,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     restarts++;
                     stored = 0;
                     end = 0;
-                    step = 1.0 / std::sqrt(gg);
+                    step = first_step();
                     continue;
                 }
                 status = PLM_STATUS_LINESEARCH;
@@ -912,17 +1086,18 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             const double *md = c->h_scal + SL_MD;
             const int nbv = B.n, e = end;
             for (int j = 0; j < nst; j++) {
-                SS[e * m + j] = SS[j * m + e] = md[0 * nbv + j];
                 SY[e * m + j] = md[0 * nbv + nst + j];            // s_e . y_j
                 SY[j * m + e] = md[1 * nbv + j];                  // s_j . y_e
-                YY[e * m + j] = YY[j * m + e] = md[1 * nbv + nst + j];
+                YDY[e * m + j] = YDY[j * m + e] = md[1 * nbv + nst + j];
                 Sg[j] = md[2 * nbv + j];
-                Yg[j] = md[2 * nbv + nst + j];
+                YDg[j] = md[2 * nbv + nst + j];
             }
-            gg = md[2 * nbv + 2 * nst];
+            gDg = md[2 * nbv + 2 * nst];
+            gg = md[2 * nbv + 2 * nst + 1];
             xx = c->h_scal[SL_XX];
             hh = c->h_scal[SL_HH];
-            const double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg);
+            gh2 = gh2_trial;
+            const double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg + gh2);
             if (cb)
                 cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
                    std::sqrt(std::max(0.0, xx - hh)), user);
@@ -940,8 +1115,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     }
     HIP_TRY(hipStreamSynchronize(c->st));
     c->eval_valid = true;   // every exit path above leaves the last accepted point in (x, g)
+    c->eval_vp = vp;
     c->last_fx = fx;
     c->last_nll = nll;
+    c->last_gh2 = gh2;
     if (res) {
         res->iters_done = k;
         res->n_evals = c->n_evals;
@@ -1008,31 +1185,45 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     HIP_TRY(hipSetDevice(c->device));
     c->eval_valid = false;
     const PlmDims &d = c->d;
-    hipEvent_t ev[6];
+    struct Events {   // destroyed on every exit path (HIP_TRY returns early)
+        hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Events() { for (auto &x : e) if (x) (void)hipEventDestroy(x); }
+    } evs;
+    hipEvent_t (&ev)[6] = evs.e;
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
     double acc[PLM_K_COUNT] = {0};
+    const bool vp = vp_enabled(c);
+    if (vp) PLM_TRY(vp_alloc(c));
     for (int r = 0; r < reps; r++) {
+        float ms;
         HIP_TRY(hipEventRecord(ev[0], c->st));
         HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
         HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
         HIP_TRY(hipEventRecord(ev[1], c->st));
-        HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
-        HIP_TRY(hipEventRecord(ev[2], c->st));
+        if (vp) {   // the fit's pipeline: forward GEMM -> HJ, 2 Newton steps on the fields, residual pass
+            HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
+            HIP_TRY(hipEventRecord(ev[2], c->st));
+            PLM_TRY(vp_stage2(c, 2, r == 0));   // 2 Newton steps (Hessians refreshed on the first repetition only)
+            HIP_TRY(hipEventRecord(ev[5], c->st));
+        } else {
+            HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
+            HIP_TRY(hipEventRecord(ev[2], c->st));
+            HIP_TRY(hipEventRecord(ev[5], c->st));
+        }
         HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
         HIP_TRY(hipEventRecord(ev[3], c->st));
         HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
-                                    c->reg_part, 0, 0.f, c->st));
+                                    c->reg_part, vp ? 2 : 0, 0.f, c->st));
         HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d),
                                      c->scal, c->st));
         HIP_TRY(hipEventRecord(ev[4], c->st));
         HIP_TRY(hipEventSynchronize(ev[4]));
-        float ms;
-        for (int k = 0; k < 4; k++) {
-            HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-            acc[k] += ms;
-        }
-        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[4]));
-        acc[PLM_K_TOTAL] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); acc[PLM_K_EXPAND] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); acc[PLM_K_FORWARD] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[5])); acc[PLM_K_FIELDS] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[5], ev[3])); acc[PLM_K_BACKWARD] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); acc[PLM_K_ASSEMBLE] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[4])); acc[PLM_K_TOTAL] += ms;
     }
     {
         const int thresh = (int)std::ceil((double)c->prob.theta_id * d.L - 1e-9);
@@ -1045,7 +1236,6 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         acc[PLM_K_REWEIGHT] = ms * reps;
     }
     for (int k = 0; k < PLM_K_COUNT; k++) out_ms[k] = (float)(acc[k] / reps);
-    for (auto &e : ev) hipEventDestroy(e);
     return PLM_OK;
 }
 

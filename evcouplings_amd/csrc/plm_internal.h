@@ -87,6 +87,21 @@ hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const floa
 hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
                                      const int32_t *jexp, int potentials, float *out, hipStream_t st);
 hipError_t plm_launch_energy_sum(const PlmDims &d, const float *part, double *out, hipStream_t st);
+// ---- variable-projection fit (fields eliminated by an inner Newton solve) ------------
+// forward GEMM only: HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj) in accumulator order (plm_hj_bytes)
+hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const int32_t *jexp,
+                                    float *hj, hipStream_t st);
+// one pass over HJ with the fields of x: per-workgroup per-site sums for the field solver (stats 1: gradient,
+// 2: gradient + Hessian; into hpart) and, with write_rt, the residual fragments (Rt) and -log P partials (fx_part)
+// of the solver's forward epilogue (gradient sums included)
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const float *x,
+                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, hipStream_t st);
+// Newton step per site on the field part of x from the sums of the last pass; full = that pass carried Hessian sums
+// (inverse cached in hinv [sites][Q][Q]); update = 0: only the squared gradient norm, summed into *g2_out
+hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, int full, float *x, double lambda_h, int update,
+                             double *hinv, double *g2_site, double *g2_out, hipStream_t st);
+size_t plm_hj_bytes(const PlmDims &d);
+size_t plm_hpart_bytes(const PlmDims &d);
 hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G,
                                hipStream_t st);
 hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab, hipStream_t st);
@@ -122,21 +137,27 @@ bool plm_q_supported(int q);
 void plm_pick_tile(int q, int *fm, int *fn);
 
 // ---- vector-free L-BFGS kernels (plm_kernels.hip) ----------------------------------------
-#define PLM_MAX_BASIS 41   // 2*m + 1 with m <= 20
+#define PLM_MAX_BASIS 42   // 2*m + 2 with m <= 20 (S, Y, g in the H0 metric, g)
 struct PlmVecList {
     const float *v[PLM_MAX_BASIS];
     int n;
 };
 // out[q * basis.n + k] = <queries.v[q], basis.v[k]>  (queries.n <= 4), f64 accumulation;
 // scratch holds queries.n * basis.n * PLM_DOT_BLOCKS doubles
+// dinv != nullptr: products of a query flagged in `wq` (bit q) with a basis vector flagged in `wb` (bit k) carry the
+// diagonal weight dinv[i] (the H0 metric of the preconditioned L-BFGS)
 hipError_t plm_launch_multidot(const PlmVecList &queries, const PlmVecList &basis, int64_t n, double *scratch,
-                               double *out, hipStream_t st);
+                               double *out, const float *dinv, unsigned wq, unsigned long long wb, hipStream_t st);
 // out = sum_k coef[k] * basis.v[k]   (coefficients passed by value, f32)
 struct PlmCoefList {
     float c[PLM_MAX_BASIS];
 };
+// dinv != nullptr: the basis vectors from index `first_weighted` on are summed separately and multiplied by dinv
 hipError_t plm_launch_multiaxpy(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n,
-                                hipStream_t st);
+                                const float *dinv, int first_weighted, hipStream_t st);
+// inverse Hessian diagonal of the independent-site model in the native layout; fv = [f | p(1-p)], 2*L*Q floats
+hipError_t plm_launch_precond(const PlmDims &d, const float *fv, float neff, float lambda_h, float lambda_j, float *dinv,
+                              hipStream_t st);
 // s = x - xp ; y = g - gp in one pass
 hipError_t plm_launch_sy(float *s, float *y, const float *x, const float *xp, const float *g, const float *gp,
                          int64_t n, hipStream_t st);

@@ -20,6 +20,7 @@
 // accumulated in f32 by v_mfma_f32_16x16x32_f16.  Written for wave64 / gfx950 only.
 #include "plm_internal.h"
 #include <math.h>
+#include <stdlib.h>
 #include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -104,6 +105,7 @@ extern "C" void plm_probe_read(unsigned long long *out, int reset) {
 }
 #endif
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+#define LDS_FPTR(p) ((__attribute__((address_space(3))) float *)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
 // half index e of an 8-wide MFMA k-chunk <-> byte PERM8[e] of the 8 packed alignment bytes
@@ -422,11 +424,19 @@ __global__ __launch_bounds__(256) void k_maxabs(const float *__restrict__ x, int
     for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down((int)m, o, 64));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
 }
-__global__ void k_scale_from_max(const u32 *maxbits, int32_t *jexp) {
+// PLM_JEXP_BIAS (environment, measurement knob): added to the scale exponent of the coupling operand.  A different
+// power-of-two pre-scale moves every hi/lo split point and every f32 rounding of the forward GEMM without
+// changing the mathematics: the difference of two evaluations that differ only in it measures the rounding
+// noise of the forward pass (tests/probes/noise_probe.py).  Negative values are safe; positive ones overflow f16.
+static int plm_jexp_bias() {
+    const char *e = getenv("PLM_JEXP_BIAS");
+    return e ? atoi(e) : 0;
+}
+__global__ void k_scale_from_max(const u32 *maxbits, int32_t *jexp, int bias) {
     const float mx = __uint_as_float(*maxbits);
     int e = 0;
     if (mx > 0.f && mx < INFINITY) frexpf(mx, &e);  // mx = m * 2^e, m in [0.5, 1)
-    int s = PLM_R_EXP - e;
+    int s = PLM_R_EXP - e + bias;
     s = max(-100, min(100, s));
     *jexp = (mx > 0.f) ? s : 0;
 }
@@ -436,7 +446,7 @@ hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_
     if (e != hipSuccess) return e;
     if (na > 0) hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, a, na, maxbits);
     if (nb > 0) hipLaunchKernelGGL(k_maxabs, dim3(256), dim3(256), 0, st, b, nb, maxbits);
-    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp);
+    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, plm_jexp_bias());
     return hipGetLastError();
 }
 hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int32_t *jexp, hipStream_t st) {
@@ -444,7 +454,7 @@ hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int
     if (e != hipSuccess) return e;
     const int64_t n = d.n_local - d.nh_pad_l;
     hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, x + d.nh_pad_l, n, maxbits);
-    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp);
+    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, plm_jexp_bias());
     return hipGetLastError();
 }
 
@@ -528,7 +538,9 @@ struct FwdArgs {
 // couplings/model.py:25-60 _hamiltonians and :63-109 _single_mutant_hamiltonians):
 // 1 = per (sequence, site block) the pair (sum_i HJ[s,i,x_si], sum_i h_i(x_si)) with
 //     HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj); 2 = the potentials HJ[s,i,a] themselves.
-enum { FWD_SOLVER = 0, FWD_ENERGY = 1, FWD_POTENTIALS = 2 };
+// 3 = the coupling part of every conditional, HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj), stored in accumulator order
+//     (float4 per lane and state) for the field solver of the variable-projection fit (k_hpass below).
+enum { FWD_SOLVER = 0, FWD_ENERGY = 1, FWD_POTENTIALS = 2, FWD_STORE = 3 };
 
 
 // one K step of the forward GEMM for one wave: Q states x (hi, lo) planes x 2 row fragments.
@@ -677,6 +689,18 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     const unsigned long long pr_t1 = PROBE_NOW();
 #endif
 
+    if constexpr (MODE == FWD_STORE) {
+        const float sc = ldexpf(1.f, -(*A.jexp));
+        float4 *hj = (float4 *)A.out + ((size_t)blockIdx.x * 8 + wave) * 2 * Q * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                const f32x4 v = acc[m][a];
+                hj[(size_t)(m * Q + a) * 64] = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+            }
+        return;
+    }
     if constexpr (MODE != FWD_SOLVER) {
         // ---- statistical energies / potentials of the given sequences (no softmax) ------------
         const float sc = ldexpf(1.f, -(*A.jexp));
@@ -1022,6 +1046,7 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
             hipLaunchKernelGGL((k_fwd_split<QQ>), grid, block, lds_s, st, d, A);                       \
         } else if (mode == FWD_SOLVER) FWD_LAUNCH(QQ, FWD_SOLVER)                                      \
         else if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                        \
+        else if (mode == FWD_STORE) FWD_LAUNCH(QQ, FWD_STORE)                                          \
         else FWD_LAUNCH(QQ, FWD_POTENTIALS)                                                            \
         break;
     switch (d.Q) {
@@ -1047,6 +1072,297 @@ hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, con
     const FwdArgs A{msa_rm, nullptr, (const char *)Bt, x, jexp, nullptr, nullptr, 0.f, out};
     return launch_forward_mode(d, A, potentials ? FWD_POTENTIALS : FWD_ENERGY, st);
 }
+// variable-projection fit: the forward GEMM alone; HJ (descaled) goes to HBM in accumulator order
+hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const int32_t *jexp,
+                                    float *hj, hipStream_t st) {
+    const FwdArgs A{msa_rm, nullptr, (const char *)Bt, nullptr, jexp, nullptr, nullptr, 0.f, hj};
+    return launch_forward_mode(d, A, FWD_STORE, st);
+}
+size_t plm_hj_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 8 * 2 * d.Q * 1024; }
+
+// =========================================================================================
+// Field solver of the variable-projection fit.  For fixed couplings the objective is a sum
+// of independent, strictly convex problems in the fields of one site:
+//     phi_i(h) = sum_s w_s [ lse_a(HJ[s,i,a] + h_a) - (HJ[s,i,x_si] + h_{x_si}) ] + lambda_h |h|^2
+// k_hpass streams HJ once (same tiling as k_fwd: 256 sequences x 16 sites per workgroup, the 8 (sequence, site)
+// pairs of a lane belong to ONE site, so the softmax is in-lane register work) and produces per workgroup and site
+//     g_a  = sum_s w_s (P_s(a) - [x_si = a])                      NS = Q values
+//     M_ab = sum_s w_s P_s(a) P_s(b), b >= a                      Q (Q+1) / 2 values
+// summed deterministically (lanes -> wave via shuffles, waves -> workgroup through LDS in fixed order, workgroups
+// -> site in f64 by k_hsolve), and with WRITE_RT also the residuals (backward-pass B fragments) and -log P partials
+// of the solver's forward epilogue.  k_hsolve takes one Newton step per site: H = diag(rowsum M) - M + 2 lambda_h I.
+// =========================================================================================
+#define PLM_HSTATS(Q) ((Q) + (Q) * ((Q) + 1) / 2)
+__global__ void k_sum_partials(const double *__restrict__ p, int n, double *out);
+struct HpassArgs {
+    const float4 *hj;
+    const int8_t *msa_rm;
+    const float *w;
+    const float *h;       // native vector (fields first)
+    _Float16 *Rt;
+    double *fx_part;
+    float *hpart;         // [workgroup][16 sites][PLM_HSTATS(Q)]
+    float rscale;
+};
+template <int Q, bool WRITE_RT, int STATS>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums
+__global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NV = (STATS == 2) ? PLM_HSTATS(Q) : Q;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
+    const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
+    const int b16 = d.b16_lo + b16l;
+    const int r = lane & 15, g = lane >> 4;
+    const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
+    const int gap = d.gap_mode;
+    const int i = b16 * 16 + r;
+    const bool site_ok = i < d.L;
+    float hv[Q];
+#pragma unroll
+    for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
+    float fxl = 0.f;
+    // statistics area [site][NV] of the workgroup: every lane adds its share with fire-and-forget LDS float adds
+    // (the 4 lanes of a site collide on one address; the LDS resolves that in lane order: deterministic)
+    float *ls = (float *)smem + (size_t)r * NV;
+    if (STATS) {
+        for (int k = tid; k < 16 * NV; k += 512) ((float *)smem)[k] = 0.f;
+        __syncthreads();
+    }
+    // wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset: no 64-bit per-lane addresses
+    const char *hj_u = (const char *)(A.hj + ((size_t)blockIdx.x * 8 + wave) * 2 * Q * 64);
+    const u32 lane16 = (u32)lane * 16;
+    // the wave's 32 sequences are handled in two halves of 16 (4 per lane): half the registers of the whole tile
+    int m_end = 2;
+    asm volatile("" : "+s"(m_end));   // opaque trip count: the loop must not be unrolled (register pressure)
+#pragma nounroll
+    for (int m = 0; m < m_end; m++) {
+        f32x4 acc[Q];
+#pragma unroll
+        for (int a = 0; a < Q; a++) {
+            const float4 v = *(const float4 *)(hj_u + (size_t)(m * Q + a) * 1024 + lane16);
+            acc[a] = (f32x4){v.x, v.y, v.z, v.w};
+        }
+        float wk[4];     // weight of the lane's 4 (sequence, site) pairs (0: padding, gapped site in gap mode)
+        int xk[4];       // observed state
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int s = s_wave + 16 * m + 4 * g + reg;
+            const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
+            const bool skip = gap && xi == 0;
+            const float ws = (skip || !site_ok) ? 0.f : A.w[s];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                const float H = (gap && a == 0) ? -INFINITY : acc[a][reg] + hv[a];
+                acc[a][reg] = H;
+                mx = fmaxf(mx, H);
+            }
+            float Z = 0.f, hx = 0.f;
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                const float H = acc[a][reg] - mx;
+                hx = (a == xi) ? H : hx;
+                const float ev = __expf(H);
+                acc[a][reg] = ev;
+                Z += ev;
+            }
+            const float invZ = 1.f / Z;
+            if (WRITE_RT && ws > 0.f) fxl -= ws * (hx - __logf(Z));
+#pragma unroll
+            for (int a = 0; a < Q; a++) acc[a][reg] *= invZ;     // P
+            wk[reg] = ws;
+            xk[reg] = xi;
+            asm volatile("" : "+v"(xk[reg]));   // no sharing of compare masks between the sections (SGPR spills)
+        }
+        if constexpr (STATS != 0) {
+            int idx = Q;
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                float t[4], ga = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    t[k] = wk[k] * acc[a][k];
+                    ga += t[k] - ((xk[k] == a) ? wk[k] : 0.f);
+                }
+                __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[a]), ga, 0, 0, false);
+                if constexpr (STATS == 2) {
+#pragma unroll
+                    for (int b = a; b < Q; b++) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[b][k], v);
+                        __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[idx]), v, 0, 0, false);
+                        ++idx;
+                    }
+                }
+            }
+        }
+        if constexpr (WRITE_RT) {
+            // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes), as in k_fwd ------------
+            const int sstep = s_wave >> 5;
+            char *rt_u = (char *)(A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q) * 1024);   // wave-uniform
+            const u32 slot2 = (u32)(((2 * m + (g >> 1)) * 16 + r) * 8 + (g & 1) * 4) * 2;        // bytes
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                wk[reg] *= A.rscale;
+                asm volatile("" : "+v"(xk[reg]));
+            }
+#pragma unroll
+            for (int a = 0; a < Q; a++) {
+                f32x4 v;
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++)
+                    v[reg] = wk[reg] * (acc[a][reg] - ((a == xk[reg]) ? 1.f : 0.f));
+                half4 hi, lo;
+                hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[2]; hi[2] = (_Float16)v[1]; hi[3] = (_Float16)v[3];
+                lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[2] - (float)hi[1]);
+                lo[2] = (_Float16)(v[1] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
+                *(half4 *)(rt_u + (size_t)a * 2048 + slot2) = hi;
+                *(half4 *)(rt_u + (size_t)a * 2048 + 1024 + slot2) = lo;
+                __builtin_amdgcn_sched_barrier(0);   // one state at a time (hipcc otherwise hoists all 84 compares)
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (STATS != 0) {
+        float *out = A.hpart + (size_t)blockIdx.x * 16 * NV;
+        for (int k = tid; k < 16 * NV; k += 512) out[k] = ((const float *)smem)[k];
+    }
+    if constexpr (WRITE_RT) {
+        __syncthreads();
+        const double tot = block_reduce_sum((double)fxl, (double *)smem);
+        if (tid == 0) A.fx_part[blockIdx.x] = tot;
+    }
+}
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const float *x,
+                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, hipStream_t st) {
+    if (d.b16_hi <= d.b16_lo) return hipSuccess;
+    const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
+    const HpassArgs A{(const float4 *)hj, msa_rm, w, x, (_Float16 *)Rt, fx_part, hpart, ldexpf(1.f, PLM_R_EXP)};
+#define HP_LAUNCH(QQ, WW, SS)                                                                          \
+    {                                                                                                  \
+        const size_t lds = std::max<size_t>(64, (size_t)16 * ((SS) == 2 ? PLM_HSTATS(QQ) : (QQ)) * sizeof(float)); \
+        hipLaunchKernelGGL((k_hpass<QQ, WW, SS>), grid, block, lds, st, d, A);                         \
+    }
+#define HP_CASE(QQ)                                                                                    \
+    case QQ:                                                                                           \
+        if (write_rt) HP_LAUNCH(QQ, true, 1)                                                           \
+        else if (stats == 2) HP_LAUNCH(QQ, false, 2)                                                   \
+        else HP_LAUNCH(QQ, false, 1)                                                                   \
+        break;
+    switch (d.Q) {
+        HP_CASE(21)
+        HP_CASE(20)
+        HP_CASE(5)
+        HP_CASE(4)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef HP_CASE
+#undef HP_LAUNCH
+    return hipGetLastError();
+}
+size_t plm_hpart_bytes(const PlmDims &d) {
+    return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 16 * PLM_HSTATS(d.Q) * sizeof(float);
+}
+
+// Newton step on the fields of one site (one wave per site).  The workgroup partials of the last pass are summed
+// in f64 (fixed order).  full = 1: the pass carried Hessian sums -- H = diag(rowsum M) - M + 2 lambda_h I is
+// inverted (Gauss-Jordan in LDS, f64) and the inverse cached in hinv; otherwise the cached inverse is reused
+// (simplified Newton: the Hessian moves slowly from one trial point to the next).  update = 0: only the squared
+// gradient norm of the subproblem is recorded (verification of the point the residuals were computed at).
+template <int Q>
+__global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restrict__ hpart, int full,
+                                              float *__restrict__ x, double lambda_h, int update,
+                                              double *__restrict__ hinv, double *__restrict__ g2_site) {
+    constexpr int NVF = PLM_HSTATS(Q);
+    __shared__ double st[NVF];
+    __shared__ double Hm[Q][2 * Q + 1];             // [H | I] -> [I | H^-1] (odd row stride: no bank conflicts)
+    __shared__ double gr[Q];
+    const int il = blockIdx.x, t = threadIdx.x;     // local site index
+    const int i = d.h_site0 + il;
+    if (i >= min(d.L, d.own_hi * 16)) {             // padding sites of the last block
+        if (t == 0) g2_site[il] = 0.0;
+        return;
+    }
+    const int b16l = il >> 4, r = il & 15;
+    const int NV = full ? NVF : Q;
+    for (int k = t; k < NV; k += 64) {
+        double v = 0;
+        for (int tt = 0; tt < d.nstiles; tt++) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NV + k];
+        st[k] = v;
+    }
+    __syncthreads();
+    const int a0 = d.gap_mode;                      // gap mode: state 0 is not a model state
+    if (t < Q) gr[t] = (t < a0) ? 0.0 : st[t] + 2.0 * lambda_h * (double)x[(size_t)il * Q + t];
+    double *inv = hinv + (size_t)il * Q * Q;
+    if (full) {
+        for (int k = t; k < Q * Q; k += 64) {
+            const int a = k / Q, b = k % Q, lo = min(a, b), hi = max(a, b);
+            // index of (lo, hi) in the row-major upper triangle that follows the Q gradient sums
+            Hm[a][b] = -st[Q + lo * Q - lo * (lo - 1) / 2 + (hi - lo)];
+            Hm[a][Q + b] = (a == b) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (t < Q) {
+            double rowsum = 0;
+            for (int b = 0; b < Q; b++) rowsum -= Hm[t][b];   // sum_b M_ab = sum_s w P_s(a)
+            Hm[t][2 * Q] = rowsum;
+        }
+        __syncthreads();
+        if (t < Q) Hm[t][t] += Hm[t][2 * Q] + 2.0 * lambda_h + 1e-12 * (1.0 + Hm[t][2 * Q]);
+        __syncthreads();
+        // Gauss-Jordan without pivoting (H is symmetric positive definite): lane -> one of the 2Q columns
+        for (int p = 0; p < Q; p++) {
+            const double piv = 1.0 / Hm[p][p];
+            __syncthreads();
+            if (t < 2 * Q) Hm[p][t] *= piv;
+            __syncthreads();
+            const double fcol = (t < Q) ? Hm[t][p] : 0.0;   // column p before it is eliminated (lane = row)
+            __syncthreads();
+            for (int a = 0; a < Q; a++) {
+                if (a == p) continue;
+                const double f = __shfl(fcol, a, 64);
+                if (t < 2 * Q) Hm[a][t] -= f * Hm[p][t];     // every lane stays in its own column
+            }
+            __syncthreads();
+        }
+        for (int k = t; k < Q * Q; k += 64) inv[k] = Hm[k / Q][Q + k % Q];
+        __syncthreads();
+    }
+    double g2 = 0;
+    if (t == 0) {
+        for (int a = 0; a < Q; a++) g2 += gr[a] * gr[a];
+        g2_site[il] = g2;
+    }
+    if (!update) return;
+    // dh = H^-1 grad, one lane per state; cap far-away steps (a full Newton step can overshoot)
+    double dh = 0;
+    if (t < Q) {
+        if (full) { for (int b = 0; b < Q; b++) dh += Hm[t][Q + b] * gr[b]; }
+        else { for (int b = 0; b < Q; b++) dh += inv[t * Q + b] * gr[b]; }
+        if (t < a0) dh = 0;
+    }
+    double mxs = fabs(dh);
+    for (int o = 32; o > 0; o >>= 1) mxs = fmax(mxs, __shfl_xor(mxs, o, 64));
+    const double cap = (mxs > 3.0) ? 3.0 / mxs : 1.0;
+    if (t < Q && !(mxs != mxs)) x[(size_t)il * Q + t] = (float)((double)x[(size_t)il * Q + t] - cap * dh);
+}
+hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, int full, float *x, double lambda_h, int update,
+                             double *hinv, double *g2_site, double *g2_out, hipStream_t st) {
+    const int nsites = (d.b16_hi - d.b16_lo) * 16;
+    if (nsites <= 0) return hipMemsetAsync(g2_out, 0, sizeof(double), st);
+    switch (d.Q) {
+    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
+    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
+    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
+    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
+    default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out);
+    return hipGetLastError();
+}
+
 // out[s] = (E, E_J, E_h) in f64 from the per-block partials: E_J = 1/2 sum_i HJ[s,i,x_si] (every pair is seen
 // from both of its sites), E_h = sum_i h_i(x_si)
 __global__ __launch_bounds__(256) void k_energy_sum(const float2 *__restrict__ part, int n, int nblk,
@@ -1385,10 +1701,12 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
             const size_t o = g_frag(d, ks_count, slab_stride, i >> 4, a, d.nb16 * d.Q) + (size_t)(i & 15) * 4;
             float v = 0.f;
             for (int k = 0; k < ks_count; k++) v += G[o + k * kstride];
-            if (mode == 0) {
+            if (mode != 1) {
                 const float xv = x[idx];
                 if (!(d.gap_mode && a == 0)) {
-                    out = fmaf(scale, v, 2.f * lambda_h * xv);
+                    // mode 2: reduced objective of the variable-projection fit -- the fields are at their optimum
+                    // for the current couplings, their gradient entries are zero by construction
+                    out = (mode == 2) ? 0.f : fmaf(scale, v, 2.f * lambda_h * xv);
                     reg += (double)xv * (double)xv;
                 }
             } else {
@@ -1397,7 +1715,7 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
         }
         gout[idx] = out;
     }
-    if (mode == 0) {
+    if (mode != 1) {
         const double t = block_reduce_sum(reg, red);
         if (threadIdx.x == 0) reg_part[d.np_own * d.Q + blockIdx.x] = (double)lambda_h * t;
     }
@@ -1410,7 +1728,7 @@ hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, c
     const float scale = ldexpf(1.f, -PLM_R_EXP) * (mode == 1 ? inv_neff : 1.f);
     if (d.np_own > 0)
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride,
-                           ghalo, x, g, lambda_j, reg_part, mode, scale);
+                           ghalo, x, g, lambda_j, reg_part, mode == 2 ? 0 : mode, scale);
     hipLaunchKernelGGL(k_assemble_h, dim3((unsigned)(d.nh_pad_l / 256)), dim3(256), 0, st, d, G, ks_count, slab_stride, x, g, lambda_h,
                        reg_part, mode, scale);
     return hipGetLastError();
@@ -1632,6 +1950,54 @@ hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, hi
 }
 
 // =========================================================================================
+// Diagonal of the Hessian at the start point (independent-site model), inverted: the H0 of the preconditioned
+// L-BFGS (plm_host.cpp).  With p_i = the site's start distribution and v = p (1 - p):
+//   d2f/dh_i(a)^2      = N_eff v_i(a) + 2 lambda_h
+//   d2f/dJ_ij(a,b)^2   = N_eff ( f_j(b) v_i(a) + f_i(a) v_j(b) ) + 2 lambda_J
+// fv = [f | v] as two L*Q arrays.  Structurally-zero entries (padding, i >= j inside a diagonal block, state 0 in
+// gap mode) get 0, so a direction never leaves the parameter subspace.
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_precond_j(PlmDims d, const float *__restrict__ fv, float neff, float lambda_j,
+                                                  float *__restrict__ dinv) {
+    const int a = blockIdx.y;
+    int I = d.own_lo;
+    int64_t rem = blockIdx.x;
+    while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
+    const int J = I + (int)rem;
+    const int ii = threadIdx.x >> 4, jj = threadIdx.x & 15;
+    const int i = I * 16 + ii, j = J * 16 + jj;
+    const bool valid = i < d.L && j < d.L && i < j;
+    const float *f = fv, *v = fv + (size_t)d.L * d.Q;
+    const float fia = valid ? f[(size_t)i * d.Q + a] : 0.f, via = valid ? v[(size_t)i * d.Q + a] : 0.f;
+    const size_t dst = d.nh_pad_l + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
+    for (int b = 0; b < d.Q; b++) {
+        float out = 0.f;
+        if (valid && !(d.gap_mode && (a == 0 || b == 0)))
+            out = 1.f / (neff * (f[(size_t)j * d.Q + b] * via + fia * v[(size_t)j * d.Q + b]) + 2.f * lambda_j);
+        dinv[dst + (size_t)b * 256] = out;
+    }
+}
+__global__ __launch_bounds__(256) void k_precond_h(PlmDims d, const float *__restrict__ fv, float neff, float lambda_h,
+                                                  float *__restrict__ dinv) {
+    const int site_end = min(d.L, d.own_hi * 16);
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= d.nh_pad_l) return;
+    float out = 0.f;
+    if (idx < (int64_t)(site_end - d.h_site0) * d.Q) {
+        const int i = d.h_site0 + (int)(idx / d.Q), a = (int)(idx % d.Q);
+        if (!(d.gap_mode && a == 0)) out = 1.f / (neff * fv[(size_t)d.L * d.Q + (size_t)i * d.Q + a] + 2.f * lambda_h);
+    }
+    dinv[idx] = out;
+}
+hipError_t plm_launch_precond(const PlmDims &d, const float *fv, float neff, float lambda_h, float lambda_j, float *dinv,
+                              hipStream_t st) {
+    if (d.np_own > 0)
+        hipLaunchKernelGGL(k_precond_j, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, fv, neff, lambda_j, dinv);
+    hipLaunchKernelGGL(k_precond_h, dim3((unsigned)(d.nh_pad_l / 256)), dim3(256), 0, st, d, fv, neff, lambda_h, dinv);
+    return hipGetLastError();
+}
+
+// =========================================================================================
 // sharded-state exchange staging.  A "block" is the Q*Q*256 floats of one 16x16-site block pair.
 //   x halo : owner of J' (lower shard) -> owner of I (higher shard), pairs (J', I); receiver layout
 //            xhalo[J' * nblk_own + (I - own_lo)]
@@ -1684,30 +2050,43 @@ hipError_t plm_launch_pack_g(const PlmDims &d, const float *G, float *sendbuf, h
 // pass over the history (queries x basis), the direction from one fused linear combination
 // =========================================================================================
 #define MD_CHUNK 8
+// Optional diagonal metric (preconditioned L-BFGS, H0 = gamma * diag(dinv)): the product <q, b> carries the weight
+// dinv[i] when BOTH the query (bit q of wq) and the basis vector (bit k of wb) are flagged.
 template <int NQ>
-__global__ __launch_bounds__(256) void k_multidot(PlmVecList Q, PlmVecList B, int64_t n4, double *__restrict__ scratch) {
+__global__ __launch_bounds__(256) void k_multidot(PlmVecList Q, PlmVecList B, int64_t n4, double *__restrict__ scratch,
+                                                 const float4 *__restrict__ dinv, unsigned wq, unsigned long long wb) {
     // blockIdx.y selects a chunk of MD_CHUNK basis vectors (keeps the f64 accumulators in registers)
     __shared__ double red[4];
     const int nb = B.n, k0 = blockIdx.y * MD_CHUNK;
     const float4 *bp[MD_CHUNK];
 #pragma unroll
     for (int k = 0; k < MD_CHUNK; k++) bp[k] = (const float4 *)B.v[min(k0 + k, nb - 1)];
+    const unsigned wbc = (unsigned)(wb >> k0) & 0xffu;
+    const bool any_w = dinv != nullptr && wq != 0 && wbc != 0;
     double acc[NQ][MD_CHUNK];
 #pragma unroll
     for (int q = 0; q < NQ; q++)
 #pragma unroll
         for (int k = 0; k < MD_CHUNK; k++) acc[q][k] = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 qv[NQ];
+        float4 qv[NQ], qd[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) qv[q] = ((const float4 *)Q.v[q])[i];
+        for (int q = 0; q < NQ; q++) qd[q] = qv[q] = ((const float4 *)Q.v[q])[i];
+        if (any_w) {
+            const float4 dv = dinv[i];
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if ((wq >> q) & 1u) { qd[q].x *= dv.x; qd[q].y *= dv.y; qd[q].z *= dv.z; qd[q].w *= dv.w; }
+        }
 #pragma unroll
         for (int k = 0; k < MD_CHUNK; k++) {
             const float4 b = bp[k][i];
+            const bool wk = (wbc >> k) & 1u;
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
-                acc[q][k] += (double)qv[q].x * b.x + (double)qv[q].y * b.y + (double)qv[q].z * b.z +
-                             (double)qv[q].w * b.w;
+            for (int q = 0; q < NQ; q++) {
+                const float4 a = wk ? qd[q] : qv[q];
+                acc[q][k] += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+            }
         }
     }
 #pragma unroll
@@ -1720,35 +2099,54 @@ __global__ __launch_bounds__(256) void k_multidot(PlmVecList Q, PlmVecList B, in
         }
 }
 hipError_t plm_launch_multidot(const PlmVecList &queries, const PlmVecList &basis, int64_t n, double *scratch,
-                               double *out, hipStream_t st) {
+                               double *out, const float *dinv, unsigned wq, unsigned long long wb, hipStream_t st) {
     if (queries.n < 1 || queries.n > 4 || basis.n < 1 || basis.n > PLM_MAX_BASIS || (n & 3)) return hipErrorInvalidValue;
     const int64_t n4 = n / 4;
+    const dim3 grid(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), block(256);
+    const float4 *d4 = (const float4 *)dinv;
     switch (queries.n) {
-    case 1: hipLaunchKernelGGL(k_multidot<1>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
-    case 2: hipLaunchKernelGGL(k_multidot<2>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
-    case 3: hipLaunchKernelGGL(k_multidot<3>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
-    default: hipLaunchKernelGGL(k_multidot<4>, dim3(PLM_DOT_BLOCKS, (basis.n + MD_CHUNK - 1) / MD_CHUNK), dim3(256), 0, st, queries, basis, n4, scratch); break;
+    case 1: hipLaunchKernelGGL(k_multidot<1>, grid, block, 0, st, queries, basis, n4, scratch, d4, wq, wb); break;
+    case 2: hipLaunchKernelGGL(k_multidot<2>, grid, block, 0, st, queries, basis, n4, scratch, d4, wq, wb); break;
+    case 3: hipLaunchKernelGGL(k_multidot<3>, grid, block, 0, st, queries, basis, n4, scratch, d4, wq, wb); break;
+    default: hipLaunchKernelGGL(k_multidot<4>, grid, block, 0, st, queries, basis, n4, scratch, d4, wq, wb); break;
     }
     hipLaunchKernelGGL(k_dots_final, dim3(queries.n * basis.n), dim3(256), 0, st, scratch, out);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void k_multiaxpy(float4 *__restrict__ out, PlmVecList B, PlmCoefList C, int64_t n4) {
+// out = sum_{k < kw} c_k b_k  +  dinv (.) sum_{k >= kw} c_k b_k     (dinv == nullptr: plain linear combination)
+__global__ __launch_bounds__(256) void k_multiaxpy(float4 *__restrict__ out, PlmVecList B, PlmCoefList C, int64_t n4,
+                                                  const float4 *__restrict__ dinv, int kw) {
     const int nb = B.n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 r = {0.f, 0.f, 0.f, 0.f};
+        float4 r = {0.f, 0.f, 0.f, 0.f}, t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int k = 0; k < nb; k++) {
+        for (int k = 0; k < kw; k++) {
             const float4 b = ((const float4 *)B.v[k])[i];
             const float c = C.c[k];
             r.x = fmaf(c, b.x, r.x); r.y = fmaf(c, b.y, r.y); r.z = fmaf(c, b.z, r.z); r.w = fmaf(c, b.w, r.w);
         }
+#pragma unroll 4
+        for (int k = kw; k < nb; k++) {
+            const float4 b = ((const float4 *)B.v[k])[i];
+            const float c = C.c[k];
+            t.x = fmaf(c, b.x, t.x); t.y = fmaf(c, b.y, t.y); t.z = fmaf(c, b.z, t.z); t.w = fmaf(c, b.w, t.w);
+        }
+        if (dinv) {
+            const float4 dv = dinv[i];
+            r.x = fmaf(dv.x, t.x, r.x); r.y = fmaf(dv.y, t.y, r.y); r.z = fmaf(dv.z, t.z, r.z); r.w = fmaf(dv.w, t.w, r.w);
+        } else {
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
         out[i] = r;
     }
 }
-hipError_t plm_launch_multiaxpy(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n, hipStream_t st) {
+hipError_t plm_launch_multiaxpy(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n,
+                                const float *dinv, int first_weighted, hipStream_t st) {
     if (basis.n < 1 || basis.n > PLM_MAX_BASIS || (n & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_multiaxpy, dim3(2048), dim3(256), 0, st, (float4 *)out, basis, coef, n / 4);
+    const int kw = dinv ? std::max(0, std::min(basis.n, first_weighted)) : basis.n;
+    hipLaunchKernelGGL(k_multiaxpy, dim3(2048), dim3(256), 0, st, (float4 *)out, basis, coef, n / 4,
+                       (const float4 *)dinv, kw);
     return hipGetLastError();
 }
 

@@ -179,6 +179,8 @@ def direct_information(jij_full, fi, device=0):
 
 FLAG_IGNORE_GAPS = 2
 FLAG_SHARDED_STATE = 4
+FLAG_PRECOND = 8
+FLAG_JOINT_LBFGS = 16
 
 
 def _wrap_collective(collective):
@@ -216,7 +218,7 @@ def _strip_gaps(x, L, q):
 
 
 def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, n_shards, shard,
-             ignore_gaps=False, sharded_state=False):
+             ignore_gaps=False, sharded_state=False, precond=False, joint=False):
     N, L = msa.shape
     p = PlmProblem()
     p.n_seqs, p.n_sites, p.n_states = N, L, q
@@ -225,13 +227,14 @@ def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbf
     p.lambda_h, p.lambda_j = float(lambda_h), float(lambda_j)
     p.max_iter, p.epsilon, p.lbfgs_m = int(max_iter), float(epsilon), int(lbfgs_m)
     p.n_shards, p.shard = int(n_shards), int(shard)
-    p.flags = (FLAG_IGNORE_GAPS if ignore_gaps else 0) | (FLAG_SHARDED_STATE if sharded_state else 0)
+    p.flags = ((FLAG_IGNORE_GAPS if ignore_gaps else 0) | (FLAG_SHARDED_STATE if sharded_state else 0) |
+               (FLAG_PRECOND if precond else 0) | (FLAG_JOINT_LBFGS if joint else 0))
     return p
 
 
 def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
         epsilon=1e-3, lbfgs_m=6, device=0, stream=0, callback=None, n_shards=1, shard=0,
-        exchange=None, want_fij=True, ignore_gaps=False, collective=None):
+        exchange=None, want_fij=True, ignore_gaps=False, collective=None, precond=False, joint=False):
     """
     Whole couplings inference: reweight -> marginals -> L-BFGS -> scores.
 
@@ -242,6 +245,10 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     (parameters, gradient and optimiser state split across the shards, see evcouplings_amd.dist).
     ignore_gaps=True is plmc -g (tools.py:222-224): state 0 is excluded from the model and every
     returned array has q-1 states (fi, hi: (L, q-1); fij, jij: (pairs, q-1, q-1)).
+    joint=True optimises fields and couplings jointly with L-BFGS as libLBFGS-based plmc does
+    (PLM_FLAG_JOINT_LBFGS) instead of the default variable projection (fields solved by Newton for every trial
+    couplings, ~10-20x fewer iterations to the same optimum); precond=True gives L-BFGS a diagonal initial Hessian
+    (PLM_FLAG_PRECOND).
     Returns a dict of numpy arrays and scalars.
     """
     lib = _lib.load()
@@ -271,7 +278,7 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     else:
         xcb = C.cast(None, _lib.EXCHANGE_CB)
     prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
-                    n_shards, shard, ignore_gaps, sharded_state=collective is not None)
+                    n_shards, shard, ignore_gaps, sharded_state=collective is not None, precond=precond, joint=joint)
     if collective is not None:
         ccb = _wrap_collective(collective)
         check(lib.plm_fit_sharded(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
@@ -298,7 +305,7 @@ class PlmContext:
 
     def __init__(self, msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None,
                  max_iter=100, epsilon=1e-3, lbfgs_m=6, device=0, stream=0, n_shards=1, shard=0,
-                 ignore_gaps=False, sharded_state=False):
+                 ignore_gaps=False, sharded_state=False, precond=False, joint=False):
         self.lib = _lib.load()
         msa = _msa(msa)
         self.N, self.L = msa.shape
@@ -307,7 +314,7 @@ class PlmContext:
         self.qm = q - 1 if ignore_gaps else q      # model states (layout of x, g, fi, fij at this API)
         self.lambda_j = default_lambda_j(self.L, self.qm) if lambda_j is None else lambda_j
         prob = _problem(msa, q, theta_id, scale, lambda_h, self.lambda_j, max_iter, epsilon, lbfgs_m,
-                        n_shards, shard, ignore_gaps, sharded_state)
+                        n_shards, shard, ignore_gaps, sharded_state, precond, joint)
         self._h = C.c_void_p()
         check(self.lib.plm_ctx_create(C.byref(prob), int(device), C.c_void_p(int(stream) or None),
                                       C.byref(self._h)))
@@ -420,5 +427,5 @@ class PlmContext:
     def time_kernels(self, reps=5):
         ms = np.zeros(_lib.K_COUNT, np.float32)
         check(self.lib.plm_ctx_time_kernels(self._h, int(reps), _ptr(ms)))
-        names = ["expand", "forward", "backward", "assemble", "total", "reweight"]
+        names = ["expand", "forward", "backward", "assemble", "total", "reweight", "fields"]
         return dict(zip(names, ms.tolist()))

@@ -73,6 +73,16 @@ typedef struct {
  * of replicated.  Needs a plm_collective_cb; per evaluation two all-to-alls of
  * neighbour blocks and one scalar all-reduce replace the all-gather of whole gradient slabs. */
 #define PLM_FLAG_SHARDED_STATE 4
+/* L-BFGS with a diagonal initial Hessian (inverse Hessian diagonal of the independent-site model) instead of the
+ * textbook scalar one.  Same optimum (strictly convex objective), different path.  Measured on MI355X: fewer
+ * iterations on short alignments, MORE at L = 300 -- opt-in. */
+#define PLM_FLAG_PRECOND 8
+/* Optimise fields and couplings jointly with L-BFGS, as libLBFGS-based plmc does, instead of the default variable
+ * projection (fields solved exactly by Newton for every trial couplings, L-BFGS over the couplings only:
+ * DESIGN.md section 2c).  Same objective, same optimum; the joint path needs ~10-20x more iterations to reach
+ * |g|/|x| < epsilon.  With max_iter far below convergence (the reference default 100) the two paths stop at
+ * different points. */
+#define PLM_FLAG_JOINT_LBFGS 16
 
 /* Per-iteration progress: the 7 columns of plmc's stderr table that
  * parse_plmc_log() collects (tools.py:59-83): iter time cond fx -loglk ||h|| ||e||. */
@@ -219,7 +229,8 @@ int plm_ctx_scores(plm_ctx_t *ctx, float *fn_host, float *cn_host);
 #define PLM_K_ASSEMBLE 3
 #define PLM_K_TOTAL 4
 #define PLM_K_REWEIGHT 5
-#define PLM_K_COUNT 6
+#define PLM_K_FIELDS 6      /* variable-projection fit: Newton passes on the fields + residual pass (0 otherwise) */
+#define PLM_K_COUNT 7
 int plm_ctx_time_kernels(plm_ctx_t *ctx, int32_t reps, float *out_ms /* [PLM_K_COUNT] */);
 
 #ifdef __cplusplus

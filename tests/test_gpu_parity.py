@@ -206,7 +206,8 @@ def test_run_plmc_hip_end_to_end_files_and_result(plm, tmp_path):
     assert res.num_valid_seqs == N - 2 and res.num_total_seqs == N and res.focus_seq_index == 1
     assert res.num_valid_sites == L and res.num_total_sites == L and res.region_start == 5
     assert type(res.effective_samples) is float and type(res.num_valid_seqs) is int     # YAML-serialisable
-    assert list(res.iteration_table.columns) == tools.ITER_COLUMNS and len(res.iteration_table) == 60
+    # the variable-projection fit converges well inside the cap on this small problem
+    assert list(res.iteration_table.columns) == tools.ITER_COLUMNS and 1 <= len(res.iteration_table) <= 60
     m = model_io.read_model_file(model)
     assert (m["L"], m["q"], m["n_valid"], m["n_invalid"], m["num_iter"]) == (L, Q, N - 2, 2, 60)
     assert m["theta"] == pytest.approx(0.2) and m["lambda_j"] == pytest.approx(lam_j, rel=1e-6)
