@@ -364,7 +364,7 @@ int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
     double prev = INFINITY;
     int newton = *newton_io, used = 0;
     for (int round = 0;; round++) {
-        PLM_TRY(vp_stage2(c, newton, round > 0 ? c->vp_hess_age > 0 : c->vp_hess_age >= 24));
+        PLM_TRY(vp_stage2(c, newton, round > 0 ? c->vp_hess_age > 0 : c->vp_hess_age >= 64));
         used += newton;
         PLM_TRY(ctx_allreduce_scalars(c, 5, 1));
         PLM_TRY(fetch_scalars(c, 5, 1));
@@ -925,7 +925,11 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     int vp_newton = 2;                       // Newton steps per evaluation (warm start: the L-BFGS extrapolation)
     double gh2 = 0;                          // |grad_h|^2 left by the field solver at the current point
     // field-solver tolerance: a fraction of what the stop rule allows the whole gradient
-    auto vp_tol2 = [&](double xnorm2) { const double t = 0.03 * eps * std::max(1.0, std::sqrt(xnorm2)); return t * t; };
+    // ... and never below the f32 summation floor of the field gradients (measured 3.5e-9 N_eff per entry)
+    auto vp_tol2 = [&](double xnorm2) {
+        const double t = std::max(0.1 * eps * std::max(1.0, std::sqrt(xnorm2)), 4e-9 * c->n_eff * std::sqrt((double)d.L * d.Q));
+        return t * t;
+    };
     // objective and gradient at the start point -- unless this context still holds them (a resumed fit)
     const bool resume = c->eval_valid && c->eval_vp == vp;
     {

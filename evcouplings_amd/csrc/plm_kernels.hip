@@ -1121,12 +1121,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
 #pragma unroll
     for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
     float fxl = 0.f;
-    // statistics area [site][NV] of the workgroup: every lane adds its share with fire-and-forget LDS float adds
-    // (the 4 lanes of a site collide on one address; the LDS resolves that in lane order: deterministic)
-    float *ls = (float *)smem + (size_t)r * NV;
+    // statistics area [wave][site][NV]: every lane adds its share with fire-and-forget LDS float adds (the 4 lanes
+    // of a site collide on one address inside one instruction, resolved in lane order; waves never share an
+    // address, and the areas are summed in wave order at the end: bit-reproducible)
+    float *ls = (float *)smem + ((size_t)wave * 16 + r) * NV;
     if (STATS) {
-        for (int k = tid; k < 16 * NV; k += 512) ((float *)smem)[k] = 0.f;
-        __syncthreads();
+        for (int k = lane; k < 16 * NV; k += 64) ((float *)smem)[(size_t)wave * 16 * NV + k] = 0.f;
     }
     // wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset: no 64-bit per-lane addresses
     const char *hj_u = (const char *)(A.hj + ((size_t)blockIdx.x * 8 + wave) * 2 * Q * 64);
@@ -1226,7 +1226,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     __syncthreads();
     if constexpr (STATS != 0) {
         float *out = A.hpart + (size_t)blockIdx.x * 16 * NV;
-        for (int k = tid; k < 16 * NV; k += 512) out[k] = ((const float *)smem)[k];
+        for (int k = tid; k < 16 * NV; k += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; wv++) v += ((const float *)smem)[(size_t)wv * 16 * NV + k];
+            out[k] = v;
+        }
     }
     if constexpr (WRITE_RT) {
         __syncthreads();
@@ -1241,7 +1246,15 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
     const HpassArgs A{(const float4 *)hj, msa_rm, w, x, (_Float16 *)Rt, fx_part, hpart, ldexpf(1.f, PLM_R_EXP)};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
-        const size_t lds = std::max<size_t>(64, (size_t)16 * ((SS) == 2 ? PLM_HSTATS(QQ) : (QQ)) * sizeof(float)); \
+        const size_t lds = (size_t)8 * 16 * ((SS) == 2 ? PLM_HSTATS(QQ) : (QQ)) * sizeof(float);       \
+        static bool attr_done_dev[PLM_MAX_DEVICES] = {false};                                          \
+        bool &attr_done = attr_done_dev[plm_current_device()];                                         \
+        if (!attr_done && lds > 65536) {                                                               \
+            hipError_t e = hipFuncSetAttribute((const void *)k_hpass<QQ, WW, SS>,                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            if (e != hipSuccess) return e;                                                             \
+            attr_done = true;                                                                          \
+        }                                                                                              \
         hipLaunchKernelGGL((k_hpass<QQ, WW, SS>), grid, block, lds, st, d, A);                         \
     }
 #define HP_CASE(QQ)                                                                                    \
@@ -1287,10 +1300,29 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     }
     const int b16l = il >> 4, r = il & 15;
     const int NV = full ? NVF : Q;
-    for (int k = t; k < NV; k += 64) {
-        double v = 0;
-        for (int tt = 0; tt < d.nstiles; tt++) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NV + k];
-        st[k] = v;
+    if (full) {
+        for (int k = t; k < NV; k += 64) {
+            double v = 0;
+            for (int tt = 0; tt < d.nstiles; tt++) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NV + k];
+            st[k] = v;
+        }
+    } else {
+        // gradient sums only (the common call): lane = sequence tile (mod 64), then the 64 lane sums per state are
+        // added in lane order -- 64 loads in flight per state instead of a chain of nstiles dependent ones
+        double part[Q];
+#pragma unroll
+        for (int k = 0; k < Q; k++) part[k] = 0;
+        for (int tt = t; tt < d.nstiles; tt += 64) {
+            const float *src = hpart + (((size_t)b16l * d.nstiles + tt) * 16 + r) * Q;
+#pragma unroll
+            for (int k = 0; k < Q; k++) part[k] += (double)src[k];
+        }
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            double v = part[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // butterfly: same value in every lane
+            if (t == 0) st[k] = v;
+        }
     }
     __syncthreads();
     const int a0 = d.gap_mode;                      // gap mode: state 0 is not a model state

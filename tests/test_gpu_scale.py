@@ -1,0 +1,137 @@
+"""
+Parity and optimality at BASELINE.json scale.
+
+The oracle (oracle/plm_oracle.c, float64, OpenMP) is the checker: one objective+gradient evaluation of it costs
+2-6 s on the GPU box's 16 host cores at these sizes, so every test here spends a handful of them.
+  * the HIP evaluation (f16 hi/lo MFMA operands, f32 accumulation over up to 50 000 sequences) against the f64
+    oracle at a far-from-optimal point and at the converged point, config 2 (L=200, N=20 000) and headline
+    (L=300, N=50 000);
+  * an optimality certificate for the fit: the ORACLE's gradient at the point the GPU fit stopped satisfies the
+    stop rule (the fit does not merely believe it converged), and pushing the GPU fit 10x further does not move CN;
+  * config 2 "EC scores within 1e-4 of the CPU solver": the GPU's CN against the CN of the point an independent
+    float64 optimiser (scipy L-BFGS-B on the oracle's objective) reaches from there.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED
+
+pytestmark = pytest.mark.gpu
+Q = 21
+CONFIGS = {"config2": (20000, 200, BASE_SEED + 2), "headline": (50000, 300, BASE_SEED + 1)}
+# the "much tighter than the stop rule" fit: |g|/|x| < 2.5e-4.  At N = 50 000 the rounding noise of the f32-class
+# gradient is ~1e-4 in these units, so this is about as far as the headline can be pushed.
+TIGHT = 2.5e-4
+
+
+@pytest.fixture(scope="module")
+def plm():
+    from evcouplings_amd import plm as _plm
+    assert _plm.device_count() >= 1, "no gfx950 device: the HIP path has no fallback"
+    return _plm
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _oracle_threads(oracle64):
+    """These evaluations are big enough to use every core the box grants (cgroup quota aware)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    old = oracle64.num_threads()
+    oracle64.set_num_threads(max(1, min(n, 32)))
+    yield
+    oracle64.set_num_threads(old)
+
+
+@pytest.fixture(scope="module")
+def fits(plm):
+    """Per configuration: alignment, weights, a far-from-optimal point (20 iterations) and the converged fits."""
+    cache = {}
+
+    def get(name):
+        if name in cache:
+            return cache[name]
+        N, L, seed = CONFIGS[name]
+        msa, _ = synthetic_msa(N, L, seed=seed)
+        out = {"msa": msa, "N": N, "L": L, "lambda_j": plm.default_lambda_j(L, Q)}
+        with plm.PlmContext(msa, Q, max_iter=20, epsilon=1e-3) as ctx:
+            out["w"], _, out["n_eff"] = ctx.reweight()
+            ctx.marginals(pairs=False)
+            ctx.set_x(None)
+            ctx.optimize()
+            out["x_far"] = ctx.get_x()
+            ctx.set_options(max_iter=3000, epsilon=1e-3)
+            r = ctx.optimize()
+            out["fit_1e-3"] = dict(r, x=ctx.get_x(), cn=ctx.scores()[1])
+            ctx.set_options(max_iter=3000, epsilon=TIGHT)
+            r = ctx.optimize()
+            out["fit_tight"] = dict(r, x=ctx.get_x(), cn=ctx.scores()[1])
+        cache[name] = out
+        return out
+    return get
+
+
+def _oracle_eval(oracle64, f, x):
+    return oracle64.eval(f["msa"], f["w"].astype(np.float64), Q, 0.01, f["lambda_j"], x.astype(np.float64))
+
+
+@pytest.mark.parametrize("name", ["config2", "headline"])
+def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, fits, name):
+    f = fits(name)
+    # far from the optimum: relative criteria (gradient entries are large)
+    fx, nll, g = plm.evaluate(f["msa"], f["w"], Q, 0.01, f["lambda_j"], f["x_far"])
+    fxo, nllo, go = _oracle_eval(oracle64, f, f["x_far"])
+    gmax_far = np.abs(go).max()
+    assert abs(fx - fxo) <= 2e-6 * abs(fxo) and abs(nll - nllo) <= 2e-6 * abs(nllo)
+    assert np.abs(g - go).max() <= 2e-5 * gmax_far
+    # at the converged point the gradient itself is tiny: the error must stay well inside the stop rule's scale
+    x = f["fit_1e-3"]["x"]
+    fx, nll, g = plm.evaluate(f["msa"], f["w"], Q, 0.01, f["lambda_j"], x)
+    fxo, nllo, go = _oracle_eval(oracle64, f, x)
+    assert abs(fx - fxo) <= 2e-6 * abs(fxo)
+    err = np.linalg.norm(g - go) / max(1.0, np.linalg.norm(x))
+    assert err <= 6e-4, err                      # eps = 1e-3 is the stop rule; measured 4.0e-4 at the headline
+    assert np.abs(g - go).max() <= 2e-5 * gmax_far
+
+
+@pytest.mark.parametrize("name", ["config2", "headline"])
+def test_fit_optimality_certificate(oracle64, fits, name):
+    f = fits(name)
+    a, b = f["fit_1e-3"], f["fit_tight"]
+    assert a["status"] == 0, a["status_msg"]                          # converged by its own rule
+    assert a["table"][-1][2] < 1e-3
+    # the oracle agrees: its float64 gradient at the GPU's final point satisfies the rule up to the evaluation error
+    _, _, go = _oracle_eval(oracle64, f, a["x"])
+    cond64 = np.linalg.norm(go) / max(1.0, np.linalg.norm(a["x"]))
+    assert cond64 < 1.6e-3, cond64
+    # four times tighter moves no EC score by more than 1e-4 (BASELINE.json's tolerance on EC scores)
+    assert b["status"] == 0 and b["table"][-1][2] < TIGHT, (b["status_msg"], b["table"][-1][2])
+    assert np.abs(a["cn"] - b["cn"]).max() < 1e-4
+    _, _, gob = _oracle_eval(oracle64, f, b["x"])
+    assert np.linalg.norm(gob) / max(1.0, np.linalg.norm(b["x"])) < cond64
+
+
+def test_config2_cn_within_1e4_of_an_independent_f64_optimiser(plm, oracle64, fits):
+    """BASELINE.json config 2: 'EC scores vs CPU plmc within 1e-4'.  plmc is unobtainable; the CPU
+    side here is scipy's L-BFGS-B minimising the ORACLE's float64 objective, started from the GPU's answer and
+    given 25 evaluations: it must not find anything better that moves a CN score by 1e-4."""
+    import scipy.optimize as so
+    f = fits("config2")
+    x0 = f["fit_tight"]["x"].astype(np.float64)
+    w64 = f["w"].astype(np.float64)
+
+    def fun(x):
+        fx, _, g = oracle64.eval(f["msa"], w64, Q, 0.01, f["lambda_j"], x)
+        return fx, g
+
+    res = so.minimize(fun, x0, jac=True, method="L-BFGS-B", options=dict(maxfun=25, maxcor=10, ftol=0, gtol=0))
+    assert res.fun <= fun(x0)[0] * (1 + 1e-12)
+    L = f["L"]
+    _, cn_cpu = oracle64.scores(res.x[L * Q:], L, Q)
+    assert np.abs(cn_cpu - f["fit_tight"]["cn"]).max() < 1e-4
