@@ -177,6 +177,7 @@ struct plm_ctx {
     float *hj = nullptr, *hpart = nullptr;
     double *hg2 = nullptr, *hinv = nullptr;
     int vp_newton_total = 0;   // Newton steps on the fields taken by the current optimisation
+    bool vp_refresh_next = false;
     int vp_hess_age = -1;      // field-solver passes since the cached inverse Hessians were refreshed (-1: none yet)
     int hist_m = 0;
     double *h_scal = nullptr;  // pinned host scalars
@@ -326,12 +327,15 @@ int vp_stage1(plm_ctx *c) {
 }
 // stage 2: `newton` Newton steps on the fields from their current values, then the residual pass at the result
 // (Rt, -log P partials) with the gradient norm of the field subproblems -> scal[5].  refresh: the first step
-// recomputes the per-site Hessians (a pass with 12x the arithmetic), otherwise the cached inverses are reused.
-int vp_stage2(plm_ctx *c, int newton, bool refresh) {
+// recomputes the per-site Hessians (a pass with more arithmetic), otherwise the cached inverses are reused.
+// reuse: hpart still holds the gradient sums of the residual pass at the current fields (a previous stage 2 that did
+// not meet the tolerance), so the first step needs no pass of its own.
+int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse) {
     const PlmDims &d = c->d;
     for (int it = 0; it < newton; it++) {
         const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
-        HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 0, full ? 2 : 1, nullptr, nullptr, c->hpart, c->st));
+        if (full || !(it == 0 && reuse))
+            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 0, full ? 2 : 1, nullptr, nullptr, c->hpart, c->st));
         HIP_TRY(plm_launch_hsolve(d, c->hpart, full, c->x, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, c->st));
         c->vp_hess_age = full ? 0 : c->vp_hess_age + 1;
     }
@@ -362,21 +366,30 @@ int fetch_scalars(plm_ctx *c, int first, int count);
 int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
     PLM_TRY(vp_stage1(c));
     double prev = INFINITY;
-    int newton = *newton_io, used = 0;
+    int newton = *newton_io, rounds = 0;
     for (int round = 0;; round++) {
-        PLM_TRY(vp_stage2(c, newton, round > 0 ? c->vp_hess_age > 0 : c->vp_hess_age >= 64));
-        used += newton;
+        // Hessians: refreshed when none exist, periodically, and whenever a round with the cached ones fell short
+        const bool refresh = c->vp_hess_age < 0 ||
+                             (round == 0 ? (c->vp_hess_age >= 64 || c->vp_refresh_next) : c->vp_hess_age > 0);
+        PLM_TRY(vp_stage2(c, newton, refresh && newton > 0, round > 0));
         PLM_TRY(ctx_allreduce_scalars(c, 5, 1));
         PLM_TRY(fetch_scalars(c, 5, 1));
         const double gh2 = c->h_scal[5];
         *gh2_out = gh2;
+        rounds = round;
+        if (getenv("PLM_DEBUG_VP"))
+            fprintf(stderr, "[plm vp] eval %d round %d: newton=%d hess_age=%d |g_h|=%.3e tol=%.3e\n", c->n_evals, round,
+                    newton, c->vp_hess_age, std::sqrt(gh2), std::sqrt(tol2));
         // done: converged, or not finite (the line search deals with that), or no longer improving (summation floor)
-        if (!(gh2 > tol2) || round >= 8 || (round > 0 && gh2 > 0.25 * prev)) break;
+        if (!(gh2 > tol2) || round >= 8 || (round > 1 && gh2 > 0.25 * prev)) break;
         prev = gh2;
         newton = 2;
     }
-    // next evaluation: as many steps as this one needed, one fewer if the first round overshot the tolerance by far
-    *newton_io = std::max(1, std::min(4, used - ((used > 1 && *gh2_out < 1e-3 * tol2) ? 1 : 0)));
+    // steps to try first at the next trial point: one more if this one needed extra rounds, one fewer (down to
+    // none: the L-BFGS extrapolation of the fields is then good enough) if it met the tolerance with room to spare
+    c->vp_refresh_next = rounds > 0;   // the cached Hessians were too stale for this step size: start fresh next time
+    if (rounds > 0) *newton_io = std::min(3, *newton_io + 1);
+    else if (*gh2_out < 0.25 * tol2) *newton_io = std::max(0, *newton_io - 1);
     PLM_TRY(vp_stage3(c));
     c->n_evals++;
     return PLM_OK;
@@ -936,7 +949,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         if (!resume) {
             if (!vp) PLM_TRY(ctx_eval_enqueue(c));
             else {
-                int first = 4;   // J = 0 typically: the start fields are near the independent-site optimum
+                int first = 3;   // J = 0 typically: the start fields are near the independent-site optimum
                 PLM_TRY(ctx_eval_vp(c, &first, vp_tol2((double)d.L), &gh2));
             }
         }
@@ -1207,7 +1220,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         if (vp) {   // the fit's pipeline: forward GEMM -> HJ, 2 Newton steps on the fields, residual pass
             HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
             HIP_TRY(hipEventRecord(ev[2], c->st));
-            PLM_TRY(vp_stage2(c, 2, r == 0));   // 2 Newton steps (Hessians refreshed on the first repetition only)
+            PLM_TRY(vp_stage2(c, 1, r == 0, false));   // 1 Newton step (Hessians refreshed on the first repetition only)
             HIP_TRY(hipEventRecord(ev[5], c->st));
         } else {
             HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));

@@ -1093,6 +1093,17 @@ size_t plm_hj_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d
 // of the solver's forward epilogue.  k_hsolve takes one Newton step per site: H = diag(rowsum M) - M + 2 lambda_h I.
 // =========================================================================================
 #define PLM_HSTATS(Q) ((Q) + (Q) * ((Q) + 1) / 2)
+#define PLM_HESS_SAMPLE 16
+// sum over the 4 lanes {l, l^16, l^32, l^48} (the 4 sequence groups of one site in an accumulator fragment),
+// result in all of them: gfx950's row / half-wave swaps, two VALU ops per step instead of an LDS round trip
+__device__ __forceinline__ float sum_over_g(float v) {
+    unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    u = __float_as_uint(v);
+    auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __global__ void k_sum_partials(const double *__restrict__ p, int n, double *out);
 struct HpassArgs {
     const float4 *hj;
@@ -1121,9 +1132,9 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
 #pragma unroll
     for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
     float fxl = 0.f;
-    // statistics area [wave][site][NV]: every lane adds its share with fire-and-forget LDS float adds (the 4 lanes
-    // of a site collide on one address inside one instruction, resolved in lane order; waves never share an
-    // address, and the areas are summed in wave order at the end: bit-reproducible)
+    // statistics area [wave][site][NV]: the 4 lanes of a site are summed in registers (sum_over_g), one of them
+    // adds the result with a fire-and-forget LDS float add (the two halves of the tile accumulate); waves never
+    // share an address and the areas are summed in wave order at the end: bit-reproducible
     float *ls = (float *)smem + ((size_t)wave * 16 + r) * NV;
     if (STATS) {
         for (int k = lane; k < 16 * NV; k += 64) ((float *)smem)[(size_t)wave * 16 * NV + k] = 0.f;
@@ -1184,14 +1195,21 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                     t[k] = wk[k] * acc[a][k];
                     ga += t[k] - ((xk[k] == a) ? wk[k] : 0.f);
                 }
+                // 21 gradient sums: the 4 lanes of a site add straight into LDS (one instruction, resolved in lane
+                // order); the 231 Hessian sums below are reduced in registers first
                 __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[a]), ga, 0, 0, false);
                 if constexpr (STATS == 2) {
+                    // Hessian sums from every PLM_HESS_SAMPLE-th sequence tile only (scaled up by k_hsolve): a few
+                    // per cent of sampling error in H costs the Newton iteration nothing measurable, the gradient
+                    // sums above stay exact
+                    if ((stile % PLM_HESS_SAMPLE) != 0) continue;
 #pragma unroll
                     for (int b = a; b < Q; b++) {
                         float v = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[b][k], v);
-                        __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[idx]), v, 0, 0, false);
+                        v = sum_over_g(v);
+                        if (g == 0) __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[idx]), v, 0, 0, false);
                         ++idx;
                     }
                 }
@@ -1301,10 +1319,12 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     const int b16l = il >> 4, r = il & 15;
     const int NV = full ? NVF : Q;
     if (full) {
+        const int nsamp = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
         for (int k = t; k < NV; k += 64) {
             double v = 0;
-            for (int tt = 0; tt < d.nstiles; tt++) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NV + k];
-            st[k] = v;
+            const int step = (k < Q) ? 1 : PLM_HESS_SAMPLE;   // Hessian sums exist for the sampled tiles only
+            for (int tt = 0; tt < d.nstiles; tt += step) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NV + k];
+            st[k] = (k < Q) ? v : v * ((double)d.nstiles / nsamp);
         }
     } else {
         // gradient sums only (the common call): lane = sequence tile (mod 64), then the 64 lane sums per state are
