@@ -57,8 +57,10 @@ def iteration_dataframe(table):
 
 
 def format_plmc_log(focus_name, focus_index, n_valid, n_total, n_sites, n_total_sites, region_start,
-                    n_eff, status_msg, table):
-    """Text with every line ``parse_plmc_log`` looks for."""
+                    n_eff, status_msg, table, theta=None):
+    """Text with every line ``parse_plmc_log`` looks for.  `theta` is the identity threshold
+    the run used (default: plmc's own 0.8)."""
+    theta = DEFAULTS["theta"] if theta is None else float(theta)
     lines = []
     if focus_index is not None:
         lines.append("Found focus %s as sequence %d" % (focus_name, focus_index))
@@ -67,7 +69,7 @@ def format_plmc_log(focus_name, focus_index, n_valid, n_total, n_sites, n_total_
         lines.append("%d sites out of %d" % (n_sites, n_total_sites))
         lines.append("Region starts at %d" % region_start)
     lines.append("Effective number of samples: %.1f\t(%.0f%% identical neighborhood = 1.000 samples)"
-                 % (n_eff, 100.0 * DEFAULTS["theta"]))
+                 % (n_eff, 100.0 * theta))
     lines.append("\t".join(ITER_COLUMNS))
     for row in _iter_rows(table):
         lines.append("\t".join(row))
@@ -140,7 +142,9 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
         model_io.write_model_file(
             param_file, L=L, q=len(model_alphabet), n_valid=enc.n_valid_seqs,
             n_invalid=enc.n_total_seqs - enc.n_valid_seqs,
-            num_iter=iterations, theta=1.0 - theta, lambda_h=lambda_h, lambda_j=lambda_J, lambda_group=0.0,
+            # plmc stores its iteration setting here (SURVEY.md App. A field 1); "max" (0 = until converged) is
+            # recorded as the number of iterations actually taken
+            num_iter=iterations if iterations > 0 else int(res["iters"]), theta=1.0 - theta, lambda_h=lambda_h, lambda_j=lambda_J, lambda_group=0.0,
             n_eff=res["n_eff"], alphabet=model_alphabet, weights=weights, target_seq=enc.target_seq,
             index_list=enc.index_list, fi=res["fi"], hi=res["hi"], fij=res["fij"], jij=res["jij"])
     if not _valid_file(couplings_file):
@@ -150,7 +154,8 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
     focus_name = focus_seq.split("/")[0] if focus_seq is not None else None
     log = format_plmc_log(focus_name, enc.focus_index, enc.n_valid_seqs, enc.n_total_seqs, L,
-                          enc.n_total_sites, enc.region_start, res["n_eff"], res["status_msg"], res["table"])
+                          enc.n_total_sites, enc.region_start, res["n_eff"], res["status_msg"], res["table"],
+                          theta=theta)
     in_focus = enc.focus_index is not None
     result = PlmcResult(
         couplings_file, param_file, iteration_dataframe(res["table"]),

@@ -146,7 +146,7 @@ def test_fit_reaches_oracle_optimum_cn_within_1e4(plm, oracle64):
     lj = plm.default_lambda_j(L, Q)
     ref = oracle64.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=3000, epsilon=1e-7)
     res = plm.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=3000, epsilon=2e-6, lbfgs_m=6)
-    assert res["status"] in (0, 2), res["status_msg"]
+    assert res["status"] == 0, res["status_msg"]               # converged by the stop rule, not "line search gave up"
     assert res["n_eff"] == pytest.approx(ref["n_eff"], rel=1e-6)
     np.testing.assert_allclose(res["weights"], ref["weights"], rtol=1e-6)
     assert res["fx"] == pytest.approx(ref["fx"], rel=1e-6)
@@ -546,7 +546,7 @@ def test_model_accel_patches_reference_module(plm, golden_dir):
 
 # ---------------------------------------------------------------- mean-field DCA
 def test_meanfield_golden_reference(plm, golden_dir):
-    """plm_meanfield end to end (reweighting, frequencies, covariance, rocSOLVER inverse, fields, DI) against
+    """plm_meanfield end to end (reweighting, frequencies, covariance, hand-written blocked Cholesky inverse, fields, DI) against
     the reference's own mean_field.py run on the same alignment (golden case "a": L=20, N=96)."""
     zf = np.load(os.path.join(golden_dir, "reweight_freqs.npz"))
     z = np.load(os.path.join(golden_dir, "meanfield_a.npz"))
