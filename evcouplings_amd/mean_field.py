@@ -50,6 +50,16 @@ def fit(self, theta=0.8, pseudo_count=0.5):
     self.regularized_frequencies = ref_mf.regularize_frequencies(ali._frequencies, pseudo_count=pseudo_count)
     self.regularized_pair_frequencies = ref_mf.regularize_pair_frequencies(ali._pair_frequencies,
                                                                            pseudo_count=pseudo_count)
+    # the two documented attributes the reference's fit leaves behind (mean_field.py:196-205): the covariance matrix of
+    # the regularised frequencies and the NEGATIVE of its inverse, both (L (q-1))^2 with index i * (q-1) + alpha
+    # (_flatten_index, :23).  Built from what the GPU returned, vectorised; reshape_invC_to_4d() / fields() work.
+    L, qm = ali.L, q - 1
+    rf, rff = self.regularized_frequencies, self.regularized_pair_frequencies
+    self.covariance_matrix = (
+        rff[:, :, :qm, :qm] - rf[:, None, :qm, None] * rf[None, :, None, :qm]
+    ).transpose(0, 2, 1, 3).reshape(L * qm, L * qm)
+    self.covariance_matrix_inv = np.ascontiguousarray(
+        out["jij_full"][:, :, :qm, :qm].transpose(0, 2, 1, 3)).reshape(L * qm, L * qm)
     return ref_mf.MeanFieldCouplingsModel(
         alignment=ali, index_list=self.index_list, regularized_f_i=self.regularized_frequencies,
         regularized_f_ij=self.regularized_pair_frequencies, h_i=out["hi"], J_ij=out["jij_full"], theta=theta,

@@ -182,12 +182,19 @@ def test_mean_field_drop_in_behind_the_reference_classes(ref, golden_dir, monkey
     from oracle.oracle import Oracle
     monkeypatch.setattr(ref_ali, "num_cluster_members",
                         lambda matrix, thr: Oracle("f64").reweight(np.asarray(matrix).astype(np.int8), thr).astype(float))
-    slow = ref_mf.MeanFieldDCA(ali).fit(theta=0.8, pseudo_count=0.5)           # the reference's own fit
+    slow_dca = ref_mf.MeanFieldDCA(ali)
+    slow = slow_dca.fit(theta=0.8, pseudo_count=0.5)                           # the reference's own fit
     with open(a2m) as f:
         ali2 = Alignment.from_file(f, "fasta")
     our_mf.install(ref_mf)
     try:
-        fast = ref_mf.MeanFieldDCA(ali2).fit(theta=0.8, pseudo_count=0.5)
+        fast_dca = ref_mf.MeanFieldDCA(ali2)
+        fast = fast_dca.fit(theta=0.8, pseudo_count=0.5)
+        # the attributes the reference's fit leaves on the MeanFieldDCA object (mean_field.py:196-205)
+        np.testing.assert_allclose(fast_dca.covariance_matrix, slow_dca.covariance_matrix, atol=1e-6)
+        np.testing.assert_allclose(fast_dca.covariance_matrix_inv, slow_dca.covariance_matrix_inv,
+                                   atol=2e-4 * np.abs(slow_dca.covariance_matrix_inv).max())
+        np.testing.assert_array_equal(fast_dca.reshape_invC_to_4d(), fast.J_ij)
         ecs_fast = fast.ecs
         out_model = str(tmp_path / "mf.model")
         fast.to_file(out_model)
