@@ -48,7 +48,8 @@ def usable_cores():
 
 
 def pmc_traffic_bytes(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary, or None."""
+    """HBM bytes per launch of `kernel` (prefix match on the instantiation name, e.g. "k_fwd<21_3>") from the
+    newest committed PMC summary, or None."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters.csv")))
@@ -57,8 +58,8 @@ def pmc_traffic_bytes(kernel):
     vals = {}
     with open(files[-1]) as f:
         for row in csv.reader(l for l in f if not l.startswith("#")):
-            if len(row) >= 3 and row[0] == kernel:
-                vals[row[1]] = float(row[2])
+            if len(row) >= 3 and row[0].startswith(kernel):
+                vals.setdefault(row[1], float(row[2]))
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
@@ -204,7 +205,7 @@ def main():
             "frac": achieved / PEAK_F32_VALU_TFLOPS,
             "definition": "SURVEY 8(d) primary: flops_alg/2 = N*L*(L-1)*q gathered adds per launch / HIP-event time "
                           "/ 157.3 TFLOP/s f32 vector peak",
-            "traffic": pmc_traffic_bytes("k_fwd" if dom == "forward" else "k_bwd"),
+            "traffic": pmc_traffic_bytes("k_fwd<21_3>" if dom == "forward" else "k_bwd<"),
             "traffic_note": "HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/*pmc_counters.csv:"
                             " 2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); "
                             "not re-collected by this run",

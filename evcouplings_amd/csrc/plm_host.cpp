@@ -176,8 +176,9 @@ struct plm_ctx {
     // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
     float *hj = nullptr, *hpart = nullptr;
     double *hg2 = nullptr, *hinv = nullptr;
-    int vp_newton_total = 0;   // Newton steps on the fields taken by the current optimisation
     bool vp_refresh_next = false;
+    int *vp_flag = nullptr;    // device-side convergence flag (kept zero: see vp_stage2)
+    int vp_newton_total = 0;   // Newton steps on the fields taken by the current optimisation
     int vp_hess_age = -1;      // field-solver passes since the cached inverse Hessians were refreshed (-1: none yet)
     int hist_m = 0;
     double *h_scal = nullptr;  // pinned host scalars
@@ -247,7 +248,7 @@ int ctx_eval_enqueue_sharded(plm_ctx *c) {
                                d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, c->st));
     HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
     HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
-    if (d.nblk_own > 0) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    if (d.nblk_own > 0) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
     PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
     HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->ghalo, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
@@ -264,7 +265,7 @@ int ctx_eval_enqueue(plm_ctx *c) {
     HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
     HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
     HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
-    HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     const float *Gsrc = c->G;
     int ks_count = d.ksplit, n_shard_nll = 0;
     const double *shard_nll = nullptr;
@@ -306,6 +307,7 @@ int vp_alloc(plm_ctx *c) {
     PLM_TRY(dalloc((char **)&c->hpart, plm_hpart_bytes(c->d)));
     PLM_TRY(dalloc(&c->hg2, nsites));
     PLM_TRY(dalloc(&c->hinv, nsites * c->d.Q * c->d.Q));
+    PLM_TRY(dalloc(&c->vp_flag, (size_t)1));
     c->vp_hess_age = -1;
     return PLM_OK;
 }
@@ -330,24 +332,37 @@ int vp_stage1(plm_ctx *c) {
 // recomputes the per-site Hessians (a pass with more arithmetic), otherwise the cached inverses are reused.
 // reuse: hpart still holds the gradient sums of the residual pass at the current fields (a previous stage 2 that did
 // not meet the tolerance), so the first step needs no pass of its own.
+//
+// A variant that enqueues the whole iteration as one chain with a device-side convergence flag (kernels behind a
+// raised flag return at once, per-site convergence, the backward GEMM conditional on the flag) was built and
+// measured: no host round trips, but it needs more passes per evaluation (3.2 s vs 2.95 s for the headline fit).
+// The kernels keep the hooks (skip / run flags); this host logic does not use them.
 int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse) {
     const PlmDims &d = c->d;
+    HIP_TRY(hipMemsetAsync(c->vp_flag, 0, sizeof(int), c->st));
     for (int it = 0; it < newton; it++) {
         const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
         if (full || !(it == 0 && reuse))
-            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 0, full ? 2 : 1, nullptr, nullptr, c->hpart, c->st));
-        HIP_TRY(plm_launch_hsolve(d, c->hpart, full, c->x, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, c->st));
+            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 0, full ? 2 : 1, nullptr, nullptr, c->hpart,
+                                     nullptr, c->st));
+        HIP_TRY(plm_launch_hsolve(d, c->hpart, full, c->x, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
+                                  c->vp_flag, c->st));
         c->vp_hess_age = full ? 0 : c->vp_hess_age + 1;
     }
     c->vp_newton_total += newton;
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 1, 1, c->Rt, c->fx_part, c->hpart, c->st));
-    HIP_TRY(plm_launch_hsolve(d, c->hpart, 0, c->x, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 1, 1, c->Rt, c->fx_part, c->hpart, nullptr, c->st));
+    HIP_TRY(plm_launch_hsolve(d, c->hpart, 0, c->x, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
+                              c->vp_flag, c->st));
     return PLM_OK;
 }
 // stage 3: backward GEMM, gradient of the reduced objective, objective value
-int vp_stage3(plm_ctx *c) {
+int vp_stage3(plm_ctx *c, bool conditional) {
     const PlmDims &d = c->d;
-    if (d.nblk_own > 0 || !d.sharded) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    // conditional: the backward GEMM runs only if the chain in front of it converged -- the host sees the same
+    // gradient norm and repeats stage 3 after finishing the fields.  Not when sharded: a shard judges its own sites
+    // only, the host the all-reduced norm, and the two can disagree.
+    if (d.nblk_own > 0 || !d.sharded)
+        HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, (conditional && !d.sharded) ? c->vp_flag : nullptr, c->st));
     if (d.sharded) {
         HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
         PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
@@ -363,6 +378,8 @@ int vp_stage3(plm_ctx *c) {
 // f32 summation floor); the check costs one extra host synchronisation per evaluation (sharded: one scalar all-reduce)
 int ctx_allreduce_scalars(plm_ctx *c, int first, int count);
 int fetch_scalars(plm_ctx *c, int first, int count);
+// the whole evaluation: the field solver iterates until the subproblem gradient is below tol2 (or stalls at its
+// f32 floor); the check costs one extra host synchronisation per evaluation (sharded: one scalar all-reduce)
 int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
     PLM_TRY(vp_stage1(c));
     double prev = INFINITY;
@@ -380,7 +397,7 @@ int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
         if (getenv("PLM_DEBUG_VP"))
             fprintf(stderr, "[plm vp] eval %d round %d: newton=%d hess_age=%d |g_h|=%.3e tol=%.3e\n", c->n_evals, round,
                     newton, c->vp_hess_age, std::sqrt(gh2), std::sqrt(tol2));
-        // done: converged, or not finite (the line search deals with that), or no longer improving (summation floor)
+        // done: converged, or not finite (the line search deals with that), or no longer improving (f32 floor)
         if (!(gh2 > tol2) || round >= 8 || (round > 1 && gh2 > 0.25 * prev)) break;
         prev = gh2;
         newton = 2;
@@ -390,7 +407,7 @@ int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
     c->vp_refresh_next = rounds > 0;   // the cached Hessians were too stale for this step size: start fresh next time
     if (rounds > 0) *newton_io = std::min(3, *newton_io + 1);
     else if (*gh2_out < 0.25 * tol2) *newton_io = std::max(0, *newton_io - 1);
-    PLM_TRY(vp_stage3(c));
+    PLM_TRY(vp_stage3(c, false));
     c->n_evals++;
     return PLM_OK;
 }
@@ -548,7 +565,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     hipSetDevice(c->device);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->hg2, c->hinv};
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->hg2, c->hinv, c->vp_flag};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);
@@ -723,7 +740,7 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     const PlmDims &d = c->d;
     // weighted one-hot Gram matrix through the backward GEMM: G = X^T diag(w) X
     HIP_TRY(plm_launch_onehot_rt(d, c->msa_rm, c->w, c->Rt, c->st));
-    HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+    HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     // gap mode: raw weighted counts come back (factor 1) and are normalised per site / per pair over
     // the ungapped sequences on the host
     HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->g, c->g, 0.f, 0.f, c->reg_part, 1,
@@ -938,7 +955,9 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     int vp_newton = 2;                       // Newton steps per evaluation (warm start: the L-BFGS extrapolation)
     double gh2 = 0;                          // |grad_h|^2 left by the field solver at the current point
     // field-solver tolerance: a fraction of what the stop rule allows the whole gradient
-    // ... and never below the f32 summation floor of the field gradients (measured 3.5e-9 N_eff per entry)
+    // ... and never below the f32 floor of the field gradients (measured 2e-9 ... 6e-9 N_eff per entry)
+    // (A tolerance relative to the current gradient of the couplings -- inexact field solves far from the optimum --
+    // was measured: 0.3 % of |g| costs 15 % more iterations at the headline and stalls config 2 at |g|/|x| = 0.1.)
     auto vp_tol2 = [&](double xnorm2) {
         const double t = std::max(0.1 * eps * std::max(1.0, std::sqrt(xnorm2)), 4e-9 * c->n_eff * std::sqrt((double)d.L * d.Q));
         return t * t;
@@ -1220,14 +1239,14 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         if (vp) {   // the fit's pipeline: forward GEMM -> HJ, 2 Newton steps on the fields, residual pass
             HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
             HIP_TRY(hipEventRecord(ev[2], c->st));
-            PLM_TRY(vp_stage2(c, 1, r == 0, false));   // 1 Newton step (Hessians refreshed on the first repetition only)
+            PLM_TRY(vp_stage2(c, 1, r == 0, false));   // one Newton step + the residual pass
             HIP_TRY(hipEventRecord(ev[5], c->st));
         } else {
             HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
             HIP_TRY(hipEventRecord(ev[2], c->st));
             HIP_TRY(hipEventRecord(ev[5], c->st));
         }
-        HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, c->st));
+        HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
         HIP_TRY(hipEventRecord(ev[3], c->st));
         HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
                                     c->reg_part, vp ? 2 : 0, 0.f, c->st));

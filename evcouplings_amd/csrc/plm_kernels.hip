@@ -596,7 +596,14 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     constexpr int TILE = 2 * Q * 1024, NBUF = PLM_NBUF, NP = (2 * Q + 7) / 8, R = FwdRing<Q>::R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to be wave-uniform
-    const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
+    // XCD-aware order: block b runs on XCD b % 8, each XCD has its own L2.  The (site block, sequence tile) work
+    // list is site-block major; XCD x takes the contiguous eighth [x, x+1) * ntiles / 8 of it, so the ~32 blocks
+    // resident on an XCD stream the SAME Bt slab (9 MB at the headline) at about the same time and a slab is
+    // fetched from HBM by at most two XCDs instead of all eight.  Everything below indexes by `tile`.
+    const int ntiles = d.nstiles * (d.b16_hi - d.b16_lo), per_xcd = (ntiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
+    const int stile = tile % d.nstiles, b16l = tile / d.nstiles;
     const int b16 = d.b16_lo + b16l;
     const int r = lane & 15, g = lane >> 4;
     const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
 
     if constexpr (MODE == FWD_STORE) {
         const float sc = ldexpf(1.f, -(*A.jexp));
-        float4 *hj = (float4 *)A.out + ((size_t)blockIdx.x * 8 + wave) * 2 * Q * 64 + lane;
+        float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + wave) * 2 * Q * 64 + lane;
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -790,33 +797,38 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             const float invZ = 1.f / Z;
             if (site_ok && !skip) fxl -= ws * (hx - __logf(Z));
             const float wr = site_ok ? ws * A.rscale : 0.f;
-#pragma unroll
+            int xi2 = xi;
+            asm volatile("" : "+v"(xi2));   // fresh compares: sharing the 21 masks of the loop above keeps them all
+#pragma unroll                              // alive in SGPR pairs (this was the source of the kernel's spills)
             for (int a = 0; a < Q; a++)
-                acc[m][a][reg] = wr * (acc[m][a][reg] * invZ - ((a == xi) ? 1.f : 0.f));
+                acc[m][a][reg] = wr * (acc[m][a][reg] * invZ - ((a == xi2) ? 1.f : 0.f));
         }
     }
     // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes) ----------------
-    const int sstep = s_wave >> 5;
-    _Float16 *rt = A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q) * 1024;  // 1024 halves per col frag
+    // wave-uniform base + 32-bit lane offset; one 16-byte store per lane and state (rows swapped so that even-g
+    // lanes hold a whole hi slot and odd-g lanes a whole lo slot, see k_hpass)
+    const int sstep = (stile * PLM_SEQ_TILE + wave_s * 32) >> 5;
+    char *rt_u = (char *)(A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q) * 1024);
 #pragma unroll
     for (int m = 0; m < 2; m++) {
-        const int slot = ((2 * m + (g >> 1)) * 16 + r) * 8 + (g & 1) * 4;   // halves within a 512-half plane
+        const u32 slot16 = (u32)((2 * m + (g >> 1)) * 16 + r) * 16 + (u32)(g & 1) * 1024;
 #pragma unroll
         for (int a = 0; a < Q; a++) {
             const f32x4 v = acc[m][a];
-            half4 hi, lo;
+            union { half4 h; u32 w[2]; } hi, lo;
             // half e = 4*(g&1) + {0,1,2,3} <-> sequence offset perm8(e): regs (0,2,1,3)
-            hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[2]; hi[2] = (_Float16)v[1]; hi[3] = (_Float16)v[3];
-            lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[2] - (float)hi[1]);
-            lo[2] = (_Float16)(v[1] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
-            *(half4 *)(rt + (size_t)a * 1024 + slot) = hi;
-            *(half4 *)(rt + (size_t)a * 1024 + 512 + slot) = lo;
+            hi.h[0] = (_Float16)v[0]; hi.h[1] = (_Float16)v[2]; hi.h[2] = (_Float16)v[1]; hi.h[3] = (_Float16)v[3];
+            lo.h[0] = (_Float16)(v[0] - (float)hi.h[0]); lo.h[1] = (_Float16)(v[2] - (float)hi.h[1]);
+            lo.h[2] = (_Float16)(v[1] - (float)hi.h[2]); lo.h[3] = (_Float16)(v[3] - (float)hi.h[3]);
+            auto p0 = __builtin_amdgcn_permlane16_swap(hi.w[0], lo.w[0], false, false);
+            auto p1 = __builtin_amdgcn_permlane16_swap(hi.w[1], lo.w[1], false, false);
+            *(uint4 *)(rt_u + (size_t)a * 2048 + slot16) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
         }
     }
 #endif
     __syncthreads();   // every wave is done with the B tiles: reuse the LDS for the reduction
     const double tot = block_reduce_sum((double)fxl, (double *)smem);
-    if (tid == 0) A.fx_part[blockIdx.x] = tot;
+    if (tid == 0) A.fx_part[tile] = tot;
 #if PLM_PROBE
     if (lane == 0) {
         const unsigned long long pr_t2 = PROBE_NOW();
@@ -1017,7 +1029,8 @@ __global__ __launch_bounds__(512) void k_fwd_split(PlmDims d, FwdArgs A) {
 
 static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
+    const int ntiles = d.nstiles * (d.b16_hi - d.b16_lo);
+    const dim3 grid_split(ntiles), grid(8 * ((ntiles + 7) / 8)), block(512);   // k_fwd: XCD-aware, padded to 8
     const size_t lds = (size_t)PLM_NBUF * 2 * d.Q * 1024;
 #define FWD_LAUNCH(QQ, MM)                                                                             \
     {                                                                                                  \
@@ -1043,7 +1056,7 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
                 if (e != hipSuccess) return e;                                                         \
                 attr_done = true;                                                                      \
             }                                                                                          \
-            hipLaunchKernelGGL((k_fwd_split<QQ>), grid, block, lds_s, st, d, A);                       \
+            hipLaunchKernelGGL((k_fwd_split<QQ>), grid_split, block, lds_s, st, d, A);                       \
         } else if (mode == FWD_SOLVER) FWD_LAUNCH(QQ, FWD_SOLVER)                                      \
         else if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                        \
         else if (mode == FWD_STORE) FWD_LAUNCH(QQ, FWD_STORE)                                          \
@@ -1094,6 +1107,9 @@ size_t plm_hj_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d
 // =========================================================================================
 #define PLM_HSTATS(Q) ((Q) + (Q) * ((Q) + 1) / 2)
 #define PLM_HESS_SAMPLE 16
+#ifndef PLM_NEWTON_CAP
+#define PLM_NEWTON_CAP 3.0   // largest change of a field in one Newton step
+#endif
 // sum over the 4 lanes {l, l^16, l^32, l^48} (the 4 sequence groups of one site in an accumulator fragment),
 // result in all of them: gfx950's row / half-wave swaps, two VALU ops per step instead of an LDS round trip
 __device__ __forceinline__ float sum_over_g(float v) {
@@ -1112,13 +1128,15 @@ struct HpassArgs {
     const float *h;       // native vector (fields first)
     _Float16 *Rt;
     double *fx_part;
-    float *hpart;         // [workgroup][16 sites][PLM_HSTATS(Q)]
+    float *hpart;         // [workgroup][16 sites][NV]  (NV = Q, or PLM_HSTATS(Q) with Hessian sums)
     float rscale;
+    const int *skip;      // device flag (may be NULL): non-zero = the field solver has converged, do nothing
 };
 template <int Q, bool WRITE_RT, int STATS>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NV = (STATS == 2) ? PLM_HSTATS(Q) : Q;
+    if (A.skip && *A.skip) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
     const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
@@ -1199,12 +1217,20 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 // order); the 231 Hessian sums below are reduced in registers first
                 __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[a]), ga, 0, 0, false);
                 if constexpr (STATS == 2) {
-                    // Hessian sums from every PLM_HESS_SAMPLE-th sequence tile only (scaled up by k_hsolve): a few
-                    // per cent of sampling error in H costs the Newton iteration nothing measurable, the gradient
-                    // sums above stay exact
-                    if ((stile % PLM_HESS_SAMPLE) != 0) continue;
+                    // Hessian sums: the diagonal sum_s w P_a^2 from every tile (rare states live on a handful of
+                    // sequences: sampling them away stalls the Newton iteration), the off-diagonal sums from every
+                    // PLM_HESS_SAMPLE-th sequence tile only (scaled up by k_hsolve) -- a few per cent of sampling
+                    // error there costs nothing measurable
+                    {
+                        float v = 0.f;
 #pragma unroll
-                    for (int b = a; b < Q; b++) {
+                        for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[a][k], v);
+                        __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[Q + a * Q - a * (a - 1) / 2]), v, 0, 0, false);
+                    }
+                    if ((stile % PLM_HESS_SAMPLE) != 0) continue;
+                    idx = Q + a * Q - a * (a - 1) / 2 + 1;
+#pragma unroll
+                    for (int b = a + 1; b < Q; b++) {
                         float v = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[b][k], v);
@@ -1219,7 +1245,8 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes), as in k_fwd ------------
             const int sstep = s_wave >> 5;
             char *rt_u = (char *)(A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q) * 1024);   // wave-uniform
-            const u32 slot2 = (u32)(((2 * m + (g >> 1)) * 16 + r) * 8 + (g & 1) * 4) * 2;        // bytes
+            // byte offset of the lane's 16-byte slot: fragment lane (2m + g/2, r); odd g -> the lo plane (+1 KB)
+            const u32 slot16 = (u32)((2 * m + (g >> 1)) * 16 + r) * 16 + (u32)(g & 1) * 1024;
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 wk[reg] *= A.rscale;
@@ -1231,12 +1258,20 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++)
                     v[reg] = wk[reg] * (acc[a][reg] - ((a == xk[reg]) ? 1.f : 0.f));
-                half4 hi, lo;
-                hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[2]; hi[2] = (_Float16)v[1]; hi[3] = (_Float16)v[3];
-                lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[2] - (float)hi[1]);
-                lo[2] = (_Float16)(v[1] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
-                *(half4 *)(rt_u + (size_t)a * 2048 + slot2) = hi;
-                *(half4 *)(rt_u + (size_t)a * 2048 + 1024 + slot2) = lo;
+                union { half4 h; u32 w[2]; } hi, lo;
+                hi.h[0] = (_Float16)v[0]; hi.h[1] = (_Float16)v[2]; hi.h[2] = (_Float16)v[1]; hi.h[3] = (_Float16)v[3];
+                lo.h[0] = (_Float16)(v[0] - (float)hi.h[0]); lo.h[1] = (_Float16)(v[2] - (float)hi.h[1]);
+                lo.h[2] = (_Float16)(v[1] - (float)hi.h[2]); lo.h[3] = (_Float16)(v[3] - (float)hi.h[3]);
+                // the 16-byte slot of a fragment lane = the 4 halves of sequence group g (even) + those of g + 1:
+                // swap rows so that even-g lanes hold the whole hi slot and odd-g lanes the whole lo slot, then
+                // ONE 16-byte store per lane (v_permlane16_swap: odd rows of the first <-> even rows of the second)
+                uint4 o;
+                {
+                    auto p0 = __builtin_amdgcn_permlane16_swap(hi.w[0], lo.w[0], false, false);
+                    auto p1 = __builtin_amdgcn_permlane16_swap(hi.w[1], lo.w[1], false, false);
+                    o = make_uint4(p0[0], p1[0], p0[1], p1[1]);
+                }
+                *(uint4 *)(rt_u + (size_t)a * 2048 + slot16) = o;
                 __builtin_amdgcn_sched_barrier(0);   // one state at a time (hipcc otherwise hoists all 84 compares)
             }
         }
@@ -1258,10 +1293,11 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     }
 }
 hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const float *x,
-                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, hipStream_t st) {
+                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, const int *skip,
+                            hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
-    const HpassArgs A{(const float4 *)hj, msa_rm, w, x, (_Float16 *)Rt, fx_part, hpart, ldexpf(1.f, PLM_R_EXP)};
+    const HpassArgs A{(const float4 *)hj, msa_rm, w, x, (_Float16 *)Rt, fx_part, hpart, ldexpf(1.f, PLM_R_EXP), skip};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
         const size_t lds = (size_t)8 * 16 * ((SS) == 2 ? PLM_HSTATS(QQ) : (QQ)) * sizeof(float);       \
@@ -1277,7 +1313,8 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
     }
 #define HP_CASE(QQ)                                                                                    \
     case QQ:                                                                                           \
-        if (write_rt) HP_LAUNCH(QQ, true, 1)                                                           \
+        if (write_rt && stats == 2) HP_LAUNCH(QQ, true, 2)                                             \
+        else if (write_rt) HP_LAUNCH(QQ, true, 1)                                                      \
         else if (stats == 2) HP_LAUNCH(QQ, false, 2)                                                   \
         else HP_LAUNCH(QQ, false, 1)                                                                   \
         break;
@@ -1305,8 +1342,10 @@ size_t plm_hpart_bytes(const PlmDims &d) {
 template <int Q>
 __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restrict__ hpart, int full,
                                               float *__restrict__ x, double lambda_h, int update,
-                                              double *__restrict__ hinv, double *__restrict__ g2_site) {
+                                              double *__restrict__ hinv, double *__restrict__ g2_site,
+                                              double tol_site2, const int *__restrict__ skip) {
     constexpr int NVF = PLM_HSTATS(Q);
+    if (skip && *skip) return;
     __shared__ double st[NVF];
     __shared__ double Hm[Q][2 * Q + 1];             // [H | I] -> [I | H^-1] (odd row stride: no bank conflicts)
     __shared__ double gr[Q];
@@ -1321,10 +1360,17 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     if (full) {
         const int nsamp = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
         for (int k = t; k < NV; k += 64) {
+            // gradient sums and the Hessian diagonal come from every tile, the off-diagonal sums from the sampled ones
+            bool exact = k < Q;
+            if (!exact) {
+                int a = 0, rem = k - Q;
+                while (rem >= Q - a) { rem -= Q - a; a++; }
+                exact = rem == 0;
+            }
             double v = 0;
-            const int step = (k < Q) ? 1 : PLM_HESS_SAMPLE;   // Hessian sums exist for the sampled tiles only
+            const int step = exact ? 1 : PLM_HESS_SAMPLE;
             for (int tt = 0; tt < d.nstiles; tt += step) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NV + k];
-            st[k] = (k < Q) ? v : v * ((double)d.nstiles / nsamp);
+            st[k] = exact ? v : v * ((double)d.nstiles / nsamp);
         }
     } else {
         // gradient sums only (the common call): lane = sequence tile (mod 64), then the 64 lane sums per state are
@@ -1347,6 +1393,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     __syncthreads();
     const int a0 = d.gap_mode;                      // gap mode: state 0 is not a model state
     if (t < Q) gr[t] = (t < a0) ? 0.0 : st[t] + 2.0 * lambda_h * (double)x[(size_t)il * Q + t];
+    __syncthreads();
     double *inv = hinv + (size_t)il * Q * Q;
     if (full) {
         for (int k = t; k < Q * Q; k += 64) {
@@ -1383,11 +1430,11 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
         __syncthreads();
     }
     double g2 = 0;
-    if (t == 0) {
-        for (int a = 0; a < Q; a++) g2 += gr[a] * gr[a];
-        g2_site[il] = g2;
-    }
-    if (!update) return;
+    for (int a = 0; a < Q; a++) g2 += gr[a] * gr[a];       // every lane: the branch below must be uniform
+    if (t == 0) g2_site[il] = g2;
+    // the sites are independent problems: one that meets its share of the tolerance is left alone (its residuals of
+    // the pass just taken are final), the others take a Newton step
+    if (!update || !(g2 > tol_site2)) return;
     // dh = H^-1 grad, one lane per state; cap far-away steps (a full Newton step can overshoot)
     double dh = 0;
     if (t < Q) {
@@ -1395,23 +1442,63 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
         else { for (int b = 0; b < Q; b++) dh += inv[t * Q + b] * gr[b]; }
         if (t < a0) dh = 0;
     }
+    // far from the optimum a full Newton step overshoots (saturated softmax: tiny Hessian entries): the step is
+    // scaled so that no field moves by more than PLM_NEWTON_CAP.  Measured alternatives: a bound of 12 diverges (the
+    // fit no longer converges); clamping every component on its own instead of scaling the step doubles the fit time;
+    // an iterative-scaling step (h_a += log(count_a / model_a)) for the capped sites stalls config 2.
     double mxs = fabs(dh);
     for (int o = 32; o > 0; o >>= 1) mxs = fmax(mxs, __shfl_xor(mxs, o, 64));
-    const double cap = (mxs > 3.0) ? 3.0 / mxs : 1.0;
+    const double cap = (mxs > PLM_NEWTON_CAP) ? PLM_NEWTON_CAP / mxs : 1.0;
     if (t < Q && !(mxs != mxs)) x[(size_t)il * Q + t] = (float)((double)x[(size_t)il * Q + t] - cap * dh);
 }
+// g2 = sum of the per-site squared gradient norms of the pass just taken; the device-side convergence flag of the
+// field solver is raised when EVERY site is within its share of the tolerance (then no site was moved by the
+// k_hsolve in front of this kernel and the residuals of that pass are final), or when g2 is not a number (the line
+// search deals with that); it stays raised
+__global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_site, int n, double *g2_out,
+                                                 double tol_site2, int *flag) {
+    __shared__ double red[4];
+    __shared__ int bad[4];
+    if (*flag) return;
+    double s = 0;
+    int open_sites = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double v = g2_site[i];
+        s += v;
+        open_sites += (v > tol_site2) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) open_sites += __shfl_down(open_sites, o, 64);
+    if ((threadIdx.x & 63) == 0) bad[threadIdx.x >> 6] = open_sites;
+    const double t = block_reduce_sum(s, red);     // contains the barrier that publishes bad[]
+    if (threadIdx.x == 0) {
+        g2_out[0] = t;
+        g2_out[1] += 1.0;                 // passes this chain needed (the host resets it)
+        const bool done = bad[0] + bad[1] + bad[2] + bad[3] == 0 || t != t;
+        if (done) *flag = 1;
+        g2_out[2] = done ? 1.0 : 0.0;     // the host reads the verdict with the scalars (sharded: summed over ranks)
+    }
+}
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, int full, float *x, double lambda_h, int update,
-                             double *hinv, double *g2_site, double *g2_out, hipStream_t st) {
+                             double *hinv, double *g2_site, double *g2_out, double tol2, int *flag, hipStream_t st) {
     const int nsites = (d.b16_hi - d.b16_lo) * 16;
-    if (nsites <= 0) return hipMemsetAsync(g2_out, 0, sizeof(double), st);
+    if (nsites <= 0) {
+        hipError_t e = hipMemsetAsync(g2_out, 0, sizeof(double), st);
+        if (e == hipSuccess && flag) e = hipMemsetD32Async((hipDeviceptr_t)flag, 1, 1, st);
+        return e;
+    }
+    // per-site share of the tolerance: twice the equal share in norm -- the largest of a few hundred site gradients
+    // sits ~3x above their rms at the f32 floor, and an equal share would chase that noise (measured: most chains
+    // then run to their last pass); the total stays within 2x of the requested norm, typically at half of it
+    const int live = std::max(1, std::min(d.L, d.own_hi * 16) - d.h_site0);
+    const double tol_site2 = 4.0 * tol2 / live;
     switch (d.Q) {
-    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
-    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
-    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
-    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site); break;
+    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out);
+    hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out, tol_site2, flag);
     return hipGetLastError();
 }
 
@@ -1490,8 +1577,12 @@ __device__ __forceinline__ void bwd_kstep(f32x4 (&acc)[FM][FN], const half8 (&af
 
 template <int Q, int FM, int FN>
 __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict__ msa_cm,
-                                            const char *__restrict__ Rt, float *__restrict__ G) {
+                                            const char *__restrict__ Rt, float *__restrict__ G,
+                                            const int *__restrict__ run) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // variable-projection fit: the launch is enqueued behind the field solver's chain and only does its work when
+    // that chain has converged (device flag); otherwise the host finishes the fields and launches it again
+    if (run && !*run) return;
     constexpr int TILE = 2 * FN * 2 * 1024;  // 2*FN col fragments x 2 planes
     constexpr int NBUF = PLM_NBUF, NP = (4 * FN + 7) / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1624,7 +1715,8 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
 #endif
 }
 
-hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G, hipStream_t st) {
+hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G, const int *run,
+                               hipStream_t st) {
     const int ngroups = d.ncol_tiles * d.ksplit;
     const dim3 grid(8 * ((ngroups + 7) / 8) * d.nrow_tiles), block(512);
 #define BWD_CASE(QQ, M, N)                                                                             \
@@ -1638,7 +1730,7 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
             if (e != hipSuccess) return e;                                                             \
             attr_done = true;                                                                          \
         }                                                                                              \
-        hipLaunchKernelGGL((k_bwd<QQ, M, N>), grid, block, lds, st, d, msa_cm, (const char *)Rt, G);   \
+        hipLaunchKernelGGL((k_bwd<QQ, M, N>), grid, block, lds, st, d, msa_cm, (const char *)Rt, G, run);   \
     } break;
     switch (d.Q) {
         BWD_CASE(21, 7, 7)
