@@ -21,7 +21,7 @@ ITER_CB = C.CFUNCTYPE(None, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_d
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p)
 COLLECTIVE_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
                             C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_void_p)
-COLL_ALLTOALL, COLL_ALLREDUCE_F64, COLL_ALLREDUCE_F32 = 1, 2, 3
+COLL_ALLTOALL, COLL_ALLREDUCE_F64, COLL_ALLREDUCE_F32, COLL_BROADCAST = 1, 2, 3, 4
 
 
 class PlmProblem(C.Structure):

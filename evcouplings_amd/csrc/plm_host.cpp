@@ -98,8 +98,10 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.nshards = nshards;
     d.shard = p.shard;
     d.blk_per_shard = (d.nb16 + nshards - 1) / nshards;
-    d.b16_lo = std::min(d.nb16, d.shard * d.blk_per_shard);
-    d.b16_hi = std::min(d.nb16, d.b16_lo + d.blk_per_shard);
+    d.shard_base = d.nb16 / nshards;
+    d.shard_rem = d.nb16 % nshards;
+    d.b16_lo = plm_shard_lo(d, d.shard);
+    d.b16_hi = d.b16_lo + plm_shard_cnt(d, d.shard);
     d.nnfl = d.blk_per_shard * d.Q;
     d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
     d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
@@ -626,7 +628,7 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
         c->x_send.assign(d.nshards, 0); c->x_recv.assign(d.nshards, 0);
         c->g_send.assign(d.nshards, 0); c->g_recv.assign(d.nshards, 0);
         for (int r = 0; r < d.nshards; r++) {
-            const int lo = std::min(d.nb16, r * d.blk_per_shard), hi = std::min(d.nb16, lo + d.blk_per_shard);
+            const int lo = plm_shard_lo(d, r), hi = lo + plm_shard_cnt(d, r);
             const int64_t bytes = (int64_t)d.nblk_own * (hi - lo) * (int64_t)blk * 4;
             if (r > d.shard) { c->x_send[r] = bytes; c->g_recv[r] = bytes; }
             if (r < d.shard) { c->x_recv[r] = bytes; c->g_send[r] = bytes; }
@@ -794,11 +796,26 @@ int plm_ctx_set_x(plm_ctx_t *c, const float *x_canonical_host) {
 // shard contributes its own entries and an all-reduce (sum) puts the whole vector on every rank
 static int canon_full(plm_ctx_t *c, const float *native) {
     const PlmDims &d = c->d;
-    if (d.sharded) HIP_TRY(hipMemsetAsync(c->canon, 0, sizeof(float) * d.n_canon, c->st));
     HIP_TRY(plm_launch_native_to_canon(d, native, c->canon, c->st));
     if (d.sharded) {
-        const int64_t bytes = (int64_t)sizeof(float) * d.n_canon;
-        PLM_TRY(ctx_collective(c, PLM_COLL_ALLREDUCE_F32, c->canon, c->canon, &bytes, &bytes));
+        // all-gather of the parameter slices: in the canonical order (fields by site, couplings by pair i<j, i
+        // major) the entries a shard owns -- the fields of its sites, the pairs whose first site is one of them --
+        // are two contiguous ranges, so every shard broadcasts its two ranges in place
+        const int64_t L = d.L, QQ = (int64_t)d.Q * d.Q;
+        auto pairs_before = [&](int64_t i) { return i * (2 * L - i - 1) / 2; };    // pairs (i', j) with i' < i
+        for (int r = 0; r < d.nshards; r++) {
+            const int64_t s0 = std::min<int64_t>(L, 16 * (int64_t)plm_shard_lo(d, r));
+            const int64_t s1 = std::min<int64_t>(L, 16 * (int64_t)(plm_shard_lo(d, r) + plm_shard_cnt(d, r)));
+            const int64_t hb = (s1 - s0) * d.Q * (int64_t)sizeof(float);
+            const int64_t jb = (pairs_before(s1) - pairs_before(s0)) * QQ * (int64_t)sizeof(float);
+            // the callback contract hands over count arrays of n_shards entries
+            const std::vector<int64_t> roots(d.nshards, r), hbv(d.nshards, hb), jbv(d.nshards, jb);
+            if (hb > 0)
+                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + s0 * d.Q, nullptr, hbv.data(), roots.data()));
+            if (jb > 0)
+                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + L * d.Q + pairs_before(s0) * QQ, nullptr,
+                                       jbv.data(), roots.data()));
+        }
     }
     return PLM_OK;
 }

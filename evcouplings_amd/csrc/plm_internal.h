@@ -38,7 +38,8 @@ struct PlmDims {
     int FM, FN;    // backward wave tile in fragments
     int nmf;       // row fragments of the backward GEMM: nb16*Q + FM (last FM = "ones" block)
     int nshards, shard;
-    int blk_per_shard;  // ceil(nb16 / nshards) column blocks owned by each shard
+    int blk_per_shard;  // ceil(nb16 / nshards): the most column blocks a shard owns (slab width)
+    int shard_base, shard_rem;   // balanced partition: the first shard_rem shards own shard_base + 1 blocks, the rest shard_base
     int b16_lo, b16_hi; // this shard's column blocks [lo, hi)
     int nnfl;      // local col fragments = blk_per_shard * Q (slab width, padded)
     int ksplit;    // split-K factor of the backward GEMM
@@ -63,6 +64,16 @@ struct PlmDims {
     int64_t ng_halo;   // gradient blocks received per evaluation: nblk_own * (nb16 - own_hi)
 };
 
+// balanced partition of the nb16 column blocks over the shards (19 blocks on 8 GPUs: 3,3,3,2,2,2,2,2 -- no idle GPU)
+static inline __host__ __device__ int plm_shard_lo(const PlmDims &d, int r) {
+    return r * d.shard_base + (r < d.shard_rem ? r : d.shard_rem);
+}
+static inline __host__ __device__ int plm_shard_cnt(const PlmDims &d, int r) { return d.shard_base + (r < d.shard_rem ? 1 : 0); }
+static inline __host__ __device__ int plm_shard_of(const PlmDims &d, int b) {
+    const int big = d.shard_rem * (d.shard_base + 1);
+    if (b < big) return b / (d.shard_base + 1);
+    return d.shard_rem + (d.shard_base > 0 ? (b - big) / d.shard_base : 0);
+}
 static inline __host__ __device__ int64_t plm_bp_index(int I, int J, int nb16) { // I <= J
     return (int64_t)I * nb16 - (int64_t)I * (I - 1) / 2 + (J - I);
 }

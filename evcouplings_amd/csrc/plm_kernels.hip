@@ -1773,8 +1773,8 @@ hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab,
 __device__ __forceinline__ size_t g_frag(const PlmDims &d, int ks_count, size_t slab_stride, int block16,
                                          int state, int mf) {
     // fragment (row fragment mf, column = (block16, state)) -> float offset of partial 0
-    const int sh = block16 / d.blk_per_shard;
-    const int nfl = (block16 - sh * d.blk_per_shard) * d.Q + state;
+    const int sh = plm_shard_of(d, block16);
+    const int nfl = (block16 - plm_shard_lo(d, sh)) * d.Q + state;
     return (size_t)sh * slab_stride + ((size_t)mf * d.nnfl + nfl) * 256;
 }
 __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__restrict__ G, int ks_count,
@@ -2152,8 +2152,8 @@ hipError_t plm_launch_precond(const PlmDims &d, const float *fv, float neff, flo
 __global__ __launch_bounds__(256) void k_pack_x(PlmDims d, const float4 *__restrict__ xj, float4 *__restrict__ out) {
     const int nhigh = d.nb16 - d.own_hi;
     const int jp = blockIdx.x / nhigh, I = d.own_hi + blockIdx.x % nhigh;      // pair (own_lo + jp, I)
-    const int rdst = I / d.blk_per_shard, lo_r = rdst * d.blk_per_shard;
-    const int n_r = min(d.nb16, lo_r + d.blk_per_shard) - lo_r;
+    const int rdst = plm_shard_of(d, I), lo_r = plm_shard_lo(d, rdst);
+    const int n_r = plm_shard_cnt(d, rdst);
     const size_t blk4 = PLM_BLOCK_FLOATS(d) / 4;
     const size_t dst = ((size_t)d.nblk_own * (lo_r - d.own_hi) + (size_t)jp * n_r + (I - lo_r)) * blk4;
     const size_t src = (size_t)(plm_bp_index(d.own_lo + jp, I, d.nb16) - d.bp_base) * blk4;
@@ -2171,10 +2171,11 @@ __global__ __launch_bounds__(256) void k_pack_g(PlmDims d, const float *__restri
     // one block per (own column block J, lower block I, state a); thread t = fragment element
     const int a = blockIdx.y;
     const int jl = blockIdx.x / d.own_lo, I = blockIdx.x % d.own_lo;            // J = own_lo + jl
-    const int rdst = I / d.blk_per_shard;                                        // lower shards are all full
+    const int rdst = plm_shard_of(d, I), lo_r = plm_shard_lo(d, rdst), n_r = plm_shard_cnt(d, rdst);
     const size_t blkf = PLM_BLOCK_FLOATS(d);
-    const size_t dst = ((size_t)rdst * d.blk_per_shard * d.nblk_own + (size_t)jl * d.blk_per_shard +
-                        (I - rdst * d.blk_per_shard)) * blkf + (size_t)a * d.Q * 256 + threadIdx.x;
+    // message to shard rdst: its blocks x my blocks, my block major; messages in rank order
+    const size_t dst = ((size_t)lo_r * d.nblk_own + (size_t)jl * n_r + (I - lo_r)) * blkf + (size_t)a * d.Q * 256 +
+                       threadIdx.x;
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
     for (int b = 0; b < d.Q; b++) {
         const size_t o = ((size_t)(I * d.Q + a) * d.nnfl + (size_t)jl * d.Q + b) * 256 + threadIdx.x;

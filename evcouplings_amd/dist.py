@@ -9,7 +9,8 @@ ROCm -- directly on the library's device buffers.
 Sharded-state mode (default, `make_torch_collective`): parameters, gradient and L-BFGS state
 are split by owning site block; per evaluation two all-to-alls of neighbour blocks (couplings
 towards higher shards, gradient fragments towards lower ones) and one scalar all-reduce, plus
-one scalar all-reduce per iteration for the L-BFGS Gram matrix.
+one scalar all-reduce per iteration for the L-BFGS Gram matrix; at the end of a fit every
+shard broadcasts its slice of the parameters (the all-gather of the J tensor).
 Replicated mode (`make_torch_exchange`): one all-gather of the gradient slabs per evaluation,
 every rank repeats the same L-BFGS step on the full vectors.
 `ThreadedShards` / `LoopbackShards` run either mode with all shards on ONE GPU for tests.
@@ -23,14 +24,15 @@ import numpy as np
 
 
 def shard_blocks(n_sites, n_shards):
-    """Column-block partition used by the library (plm_host.cpp make_dims): list of (lo, hi)
-    16-site block ranges, one per shard; trailing shards may be empty."""
+    """Column-block partition used by the library (plm_internal.h plm_shard_lo / plm_shard_cnt): list of (lo, hi)
+    16-site block ranges, one per shard -- balanced: the first nb16 % n_shards shards own one block more
+    (19 blocks on 8 GPUs: 3,3,3,2,2,2,2,2); shards are empty only when there are more shards than blocks."""
     nb16 = (n_sites + 15) // 16
-    per = (nb16 + n_shards - 1) // n_shards
+    base, rem = divmod(nb16, n_shards)
     out = []
     for r in range(n_shards):
-        lo = min(nb16, r * per)
-        out.append((lo, min(nb16, lo + per)))
+        lo = r * base + min(r, rem)
+        out.append((lo, lo + base + (1 if r < rem else 0)))
     return out
 
 
@@ -100,6 +102,10 @@ def collective_on_tensors(op, send, recv, send_counts, recv_counts, group=None):
     elif op in (_lib.COLL_ALLREDUCE_F64, _lib.COLL_ALLREDUCE_F32):
         dtype = torch.float64 if op == _lib.COLL_ALLREDUCE_F64 else torch.float32
         dist.all_reduce(send.view(dtype), op=dist.ReduceOp.SUM, group=group)
+    elif op == _lib.COLL_BROADCAST:
+        # recv_counts[0] = root rank within the group
+        root = int(recv_counts[0])
+        dist.broadcast(send, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
     else:
         raise ValueError("unknown collective op %r" % (op,))
 
@@ -113,7 +119,7 @@ def make_torch_collective(group=None):
         if op == _lib.COLL_ALLTOALL:
             send = torch.as_tensor(_DeviceBytes(send_ptr, max(1, sum(send_counts))), device="cuda")[:sum(send_counts)]
             recv = torch.as_tensor(_DeviceBytes(recv_ptr, max(1, sum(recv_counts))), device="cuda")[:sum(recv_counts)]
-        else:
+        else:     # all-reduce / broadcast: in place on send_counts[0] bytes
             send = torch.as_tensor(_DeviceBytes(send_ptr, send_counts[0]), device="cuda")
             recv = None
         collective_on_tensors(op, send, recv, send_counts, recv_counts, group=group)
@@ -152,7 +158,7 @@ def make_host_staged_collective(group=None, device=0):
             recv = torch.empty(sum(recv_counts), dtype=torch.uint8)
             collective_on_tensors(op, send, recv, send_counts, recv_counts, group=group)
             h2d(recv_ptr, np.ascontiguousarray(recv.numpy()))
-        else:
+        else:     # all-reduce / broadcast: in place
             buf = torch.from_numpy(d2h(send_ptr, send_counts[0]).copy())
             collective_on_tensors(op, buf, None, send_counts, recv_counts, group=group)
             h2d(send_ptr, buf.numpy())
@@ -184,6 +190,65 @@ def fit_distributed(msa, q=21, group=None, sharded_state=True, transport="rccl",
         raise ValueError("replicated-state mode needs the rccl transport")
     return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device, exchange=make_torch_exchange(group),
                    **kwargs)
+
+
+def resolve_gpu_count(cpu=None):
+    """How many GPUs a run_plmc-style call should use.  plmc's `cpu` option (threads, tools.py:257-259; int or
+    "max") is read as the number of GPUs, capped by what is visible; the environment variable PLM_HIP_GPUS overrides
+    it (PLM_HIP_GPUS=1 pins the single-GPU path whatever the pipeline configuration says)."""
+    import os
+    from evcouplings_amd import plm
+    env = os.environ.get("PLM_HIP_GPUS")
+    want = env if env not in (None, "") else cpu
+    if want is None:
+        return 1
+    have = max(1, plm.device_count())
+    if isinstance(want, str) and want.lower() == "max":
+        return have if env in (None, "") else have
+    n = max(1, int(want))
+    # an explicit PLM_HIP_GPUS may exceed the visible devices only for the gloo flow test (ranks share GPUs)
+    if env not in (None, "") and os.environ.get("PLM_DIST_BACKEND", "nccl") != "nccl":
+        return n
+    return min(n, have)
+
+
+def launch_fit(msa, n_gpus, q=21, timeout=None, **kwargs):
+    """
+    The multi-GPU fit as a child job: `n_gpus` ranks under torch.distributed.run on this node, one per GPU, sites and
+    optimiser state sharded across them (evcouplings_amd/dist_worker.py).  Same keyword arguments and same result
+    dictionary as plm.fit (no per-iteration callback: the iteration table comes back with the result).
+    """
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    kwargs = {k: v for k, v in kwargs.items() if k != "callback"}
+    kwargs["q"] = int(q)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory(prefix="plm_dist_") as tmp:
+        src, dst = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
+        np.savez(src, msa=np.ascontiguousarray(msa, dtype=np.int8), kwargs=json.dumps(kwargs))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "evcouplings_amd.dist_worker", src, dst]
+        run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        if run.returncode != 0 or not os.path.exists(dst):
+            raise RuntimeError("multi-GPU fit failed (exit %d):\n%s\n%s" % (run.returncode, run.stdout[-2000:],
+                                                                            run.stderr[-4000:]))
+        z = np.load(dst)
+        res = {k: z[k] for k in z.files if k not in ("table", "meta")}
+        res.update(json.loads(str(z["meta"])))
+        res["table"] = [tuple([int(r[0])] + [float(v) for v in r[1:]]) for r in z["table"]]
+        if "fij" not in res:
+            res["fij"] = None
+        return res
 
 
 # --------------------------------------------------------------------------------------------
@@ -288,6 +353,15 @@ class ThreadedShards:
                 self._h2d(recv_ptr, np.concatenate(parts) if parts else np.empty(0, np.uint8))
                 if me == 0:
                     self.n_calls["alltoall"] += 1
+            elif op == lib.COLL_BROADCAST:
+                root = int(recv_counts[0])
+                if me == root:
+                    self.slots[root] = self._d2h(send_ptr, send_counts[0])
+                self.barrier.wait()
+                if me != root:
+                    self._h2d(send_ptr, self.slots[root])
+                if me == 0:
+                    self.n_calls["broadcast"] = self.n_calls.get("broadcast", 0) + 1
             else:
                 dtype = np.float64 if op == lib.COLL_ALLREDUCE_F64 else np.float32
                 self.slots[me] = self._d2h(send_ptr, send_counts[0]).view(dtype)

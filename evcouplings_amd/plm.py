@@ -188,7 +188,7 @@ def _wrap_collective(collective):
     def _cb(op, send, recv, scounts, rcounts, n, shard, user):
         try:
             return int(collective(int(op), send, recv, [int(scounts[k]) for k in range(n)],
-                                  [int(rcounts[k]) for k in range(n)] if op == _lib.COLL_ALLTOALL else None,
+                                  [int(rcounts[k]) for k in range(n)] if op in (_lib.COLL_ALLTOALL, _lib.COLL_BROADCAST) else None,
                                   int(n), int(shard)))
         except Exception as exc:   # never let an exception cross the C boundary
             import sys

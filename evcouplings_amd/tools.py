@@ -110,7 +110,13 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
             raise ExternalToolError("iterations must be an integer or 'max', got {!r}".format(iterations))
         iterations = 0                       # until converged (tools.py:226-228 lets "max" through)
     iterations = int(iterations)
-    # `cpu` (threads for plmc -n, tools.py:257-259) has no meaning on the GPU; accepted and ignored
+    # `cpu` (threads for plmc -n, tools.py:257-259; int or "max") is read as the number of GPUs of this node to shard
+    # the fit over (capped by the visible devices; PLM_HIP_GPUS overrides it)
+    from evcouplings_amd import dist as _dist
+    try:
+        n_gpus = 1 if distributed else _dist.resolve_gpu_count(cpu)
+    except (TypeError, ValueError):
+        raise ExternalToolError("cpu must be an integer or 'max', got {!r}".format(cpu))
 
     try:
         enc = alignment_io.encode_alignment(alignment, focus_seq=focus_seq, alphabet=alphabet)
@@ -124,8 +130,9 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
                       lbfgs_m=lbfgs_m, callback=callback)
     try:
         if distributed:
-            from evcouplings_amd import dist
-            res = dist.fit_distributed(enc.msa, **fit_kwargs)
+            res = _dist.fit_distributed(enc.msa, **fit_kwargs)
+        elif n_gpus > 1:
+            res = _dist.launch_fit(enc.msa, n_gpus, **fit_kwargs)     # N ranks under torch.distributed.run
         else:
             res = plm.fit(enc.msa, device=device, **fit_kwargs)
     except Exception as exc:   # PlmError, ImportError (library missing), ...

@@ -21,9 +21,12 @@ def test_shard_partition_covers_all_sites_once():
             covered = [b for lo, hi in blocks for b in range(lo, hi)]
             assert covered == list(range(nb16))
             sizes = [hi - lo for lo, hi in blocks]
-            assert max(sizes) == (nb16 + n - 1) // n        # equal slab width everywhere
+            assert max(sizes) == (nb16 + n - 1) // n        # slab width
+            assert max(sizes) - min(sizes) <= 1             # balanced: no idle shard unless n > nb16
+            assert sizes == sorted(sizes, reverse=True)
             sites = pdist.shard_sites(L, n)
             assert sum(hi - lo for lo, hi in sites) == L
+    assert [hi - lo for lo, hi in pdist.shard_blocks(300, 8)] == [3, 3, 3, 2, 2, 2, 2, 2]
 
 
 def _free_port():
@@ -90,7 +93,13 @@ def _coll_worker(rank, world, port, q):
         pdist.collective_on_tensors(_lib.COLL_ALLREDUCE_F64, v64.view(torch.uint8), None, [40], None)
         v32 = torch.ones(7, dtype=torch.float32) * (rank + 1)
         pdist.collective_on_tensors(_lib.COLL_ALLREDUCE_F32, v32.view(torch.uint8), None, [28], None)
-        q.put((rank, ok_a2a, v64.tolist(), v32.tolist()))
+        # broadcast of the parameter slices (final all-gather of J): every rank is root once
+        ok_bc = True
+        for root in range(world):
+            b = torch.full((24,), 7 * root + 1 if rank == root else 0, dtype=torch.uint8)
+            pdist.collective_on_tensors(_lib.COLL_BROADCAST, b, None, [24] * world, [root] * world)
+            ok_bc = ok_bc and bool((b == 7 * root + 1).all())
+        q.put((rank, ok_a2a and ok_bc, v64.tolist(), v32.tolist()))
     finally:
         dist.destroy_process_group()
 

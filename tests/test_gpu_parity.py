@@ -671,3 +671,30 @@ def test_resumed_optimisation_skips_the_known_start_point(plm):
     assert b2["n_evals"] == a2["n_evals"] + 1
     assert a2["fx"] == b2["fx"] and a2["fx"] < a1["fx"]
     np.testing.assert_array_equal(a.get_x(), b.get_x())
+
+
+def test_run_plmc_hip_launches_ranks_for_cpu_option(plm, tmp_path, monkeypatch):
+    """BASELINE configs 4 / 5 through the boundary: `cpu=N` of run_plmc (tools.py:178-181, 257-259) = number of GPUs.
+    run_plmc_hip starts N ranks under torch.distributed.run (evcouplings_amd.dist_worker), sites and optimiser state
+    sharded; here two ranks share the one GPU of the box with gloo / host-staged collectives (PLM_DIST_BACKEND), the
+    files must match the single-GPU run's."""
+    from evcouplings_amd import tools, model_io, dist
+    from evcouplings_amd.synthetic import msa_to_a2m
+    N, L = 500, 40
+    msa, _ = synthetic_msa(N, L, seed=23)
+    ali = msa_to_a2m(msa, str(tmp_path / "in.a2m"))
+    kw = dict(focus_seq="SYN/1-40", theta=0.8, iterations=40, lambda_h=0.01, lambda_J=plm.default_lambda_j(L, Q))
+    one = tools.run_plmc_hip(ali, str(tmp_path / "a_ECs.txt"), str(tmp_path / "a.model"), cpu=1, **kw)
+    assert dist.resolve_gpu_count(4) == 1 and dist.resolve_gpu_count("max") == 1      # capped by the visible devices
+    monkeypatch.setenv("PLM_HIP_GPUS", "2")
+    monkeypatch.setenv("PLM_DIST_BACKEND", "gloo")
+    assert dist.resolve_gpu_count(None) == 2
+    two = tools.run_plmc_hip(ali, str(tmp_path / "b_ECs.txt"), str(tmp_path / "b.model"), cpu=1, **kw)
+    assert two.num_valid_seqs == one.num_valid_seqs and two.effective_samples == one.effective_samples
+    assert len(two.iteration_table) == len(one.iteration_table) or two.optimization_status == one.optimization_status
+    a, b = model_io.read_model_file(str(tmp_path / "a.model")), model_io.read_model_file(str(tmp_path / "b.model"))
+    np.testing.assert_allclose(b["jij"], a["jij"], atol=2e-4)
+    np.testing.assert_allclose(b["hi"], a["hi"], atol=5e-3)
+    ea = np.loadtxt(str(tmp_path / "a_ECs.txt"), usecols=5)
+    eb = np.loadtxt(str(tmp_path / "b_ECs.txt"), usecols=5)
+    np.testing.assert_allclose(eb, ea, atol=2e-4)
