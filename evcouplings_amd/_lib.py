@@ -66,10 +66,12 @@ SYMBOLS = [
     ("plm_fit_sharded", C.c_int, [C.POINTER(PlmProblem), C.POINTER(PlmResult), C.c_int, _P, ITER_CB, _P,
                                   COLLECTIVE_CB, _P]),
     ("plm_reweight", C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P]),
+    ("plm_reweight_ex", C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P]),
     ("plm_marginals", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("plm_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P,
                            C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     ("plm_scores", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    ("plm_scores_ex", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("plm_hamiltonians", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int, _P, _P]),
     ("plm_potentials", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int, _P, _P]),
     ("plm_meanfield", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int, _P,

@@ -74,6 +74,17 @@ int check_device(int device) {
     return PLM_OK;
 }
 
+// identity threshold of the reweighting: the integer rule, or what a float32 plmc makes of
+// the `-t 1-theta` that run_plmc sends it (tools.py:236-239)
+int cluster_threshold(double theta_id, int L, int conv) {
+    if (conv & PLM_CONV_THRESHOLD_F32) {
+        const float t = (float)(1.0 - theta_id);
+        const float need = (1.0f - t) * (float)L;
+        return (int)std::ceil(need);
+    }
+    return (int)std::ceil(theta_id * (double)L - 1e-9);
+}
+
 int make_dims(const plm_problem_t &p, PlmDims *out) {
     PlmDims d;
     memset(&d, 0, sizeof d);
@@ -129,6 +140,8 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.n_native = d.nh_pad + d.nbp * d.Q * d.Q * 256;
     d.n_canon = (int64_t)d.L * d.Q + (int64_t)d.L * (d.L - 1) / 2 * d.Q * d.Q;
     d.gap_mode = (p.flags & PLM_FLAG_IGNORE_GAPS) ? 1 : 0;
+    d.conv = p.flags & PLM_CONV_MASK;
+    d.theta = p.theta_id;
     d.sharded = ((p.flags & PLM_FLAG_SHARDED_STATE) && nshards > 1) ? 1 : 0;
     d.own_lo = d.sharded ? d.b16_lo : 0;
     d.own_hi = d.sharded ? d.b16_hi : d.nb16;
@@ -705,7 +718,7 @@ int plm_ctx_reweight(plm_ctx_t *c) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     HIP_TRY(hipSetDevice(c->device));
     const PlmDims &d = c->d;
-    const int thresh = (int)std::ceil((double)c->prob.theta_id * d.L - 1e-9);
+    const int thresh = cluster_threshold(c->prob.theta_id, d.L, d.conv);
     std::vector<int32_t> counts(d.N);
     if (thresh <= 0) {
         std::fill(counts.begin(), counts.end(), d.N);  // every pair is a neighbour
@@ -756,10 +769,13 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     HIP_TRY(hipStreamSynchronize(c->st));
     if (d.gap_mode) {
         const int Q = d.Q;
+        // PLM_CONV_G_FREQ_TOTAL: normalised by N_eff (all sequences) instead of the ungapped ones
+        const bool by_total = d.conv & PLM_CONV_G_FREQ_TOTAL;
         for (int i = 0; i < d.L; i++) {
             float *f = &c->h_fi[(size_t)i * Q];
             double tot = 0;
             for (int a = 1; a < Q; a++) tot += f[a];
+            if (by_total) tot = c->n_eff;
             f[0] = 0.f;
             for (int a = 1; a < Q; a++) f[a] = tot > 0 ? (float)(f[a] / tot) : 0.f;
         }
@@ -770,6 +786,7 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
                 double tot = 0;
                 for (int a = 1; a < Q; a++)
                     for (int b = 1; b < Q; b++) tot += f[a * Q + b];
+                if (by_total) tot = c->n_eff;
                 for (int a = 0; a < Q; a++)
                     for (int b = 0; b < Q; b++)
                         f[a * Q + b] = (a && b && tot > 0) ? (float)(f[a * Q + b] / tot) : 0.f;
@@ -1207,9 +1224,9 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
         HIP_TRY(hipMemcpyAsync(c->canon, cut.data(), sizeof(float) * cut.size(), hipMemcpyHostToDevice, c->st));
         PlmDims dn = d;
         dn.Q = Qn;
-        HIP_TRY(plm_launch_fn(dn, c->canon, fn_dev, c->st));
+        HIP_TRY(plm_launch_fn(dn, c->canon, fn_dev, 0, c->st));
     } else {
-        HIP_TRY(plm_launch_fn(d, c->canon + (size_t)d.L * d.Q, fn_dev, c->st));
+        HIP_TRY(plm_launch_fn(d, c->canon + (size_t)d.L * d.Q, fn_dev, (d.conv & PLM_CONV_FN_NO_GAP) ? 1 : 0, c->st));
     }
     HIP_TRY(hipMemcpyAsync(fn_host, fn_dev, sizeof(float) * d.L * d.L, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
@@ -1279,7 +1296,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[4])); acc[PLM_K_TOTAL] += ms;
     }
     {
-        const int thresh = (int)std::ceil((double)c->prob.theta_id * d.L - 1e-9);
+        const int thresh = cluster_threshold(c->prob.theta_id, d.L, d.conv);
         HIP_TRY(hipEventRecord(ev[0], c->st));
         HIP_TRY(plm_launch_reweight(d, c->msa_rm, std::max(1, thresh), c->counts, c->st));
         HIP_TRY(hipEventRecord(ev[1], c->st));
@@ -1304,6 +1321,11 @@ static plm_problem_t basic_problem(const int8_t *msa, int n, int l, int q) {
 }
 
 int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id, int32_t *counts_out) {
+    return plm_reweight_ex(msa, n_seqs, n_sites, theta_id, 0, counts_out);
+}
+
+int plm_reweight_ex(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id, int32_t flags,
+                    int32_t *counts_out) {
     if (!msa || !counts_out) return fail(PLM_EINVAL, "NULL argument");
     // reweighting compares raw bytes; any state value 0..126 is legal here, so borrow q = 21
     // only for the context's tiling and validate the range ourselves
@@ -1311,6 +1333,7 @@ int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double thet
         if (msa[k] < 0 || msa[k] > 126) return fail(PLM_EINVAL, "msa[%zu] outside 0..126", k);
     plm_problem_t p = basic_problem(msa, n_seqs, n_sites, 21);
     p.theta_id = theta_id;
+    p.flags = flags & (PLM_FLAG_IGNORE_GAPS | PLM_CONV_MASK);
     PLM_TRY(check_device(0));
     PlmDims d;
     PLM_TRY(make_dims(p, &d));
@@ -1322,7 +1345,7 @@ int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double thet
     PLM_TRY(dalloc(&dev, rm.size()));
     int rc = dalloc(&cnt, (size_t)d.Np);
     if (rc) { hipFree(dev); return rc; }
-    const int thresh = (int)std::ceil((double)theta_id * d.L - 1e-9);
+    const int thresh = cluster_threshold(theta_id, d.L, d.conv);
     hipError_t e = hipMemcpy(dev, rm.data(), rm.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && thresh > 0) e = plm_launch_reweight(d, dev, thresh, cnt, nullptr);
     if (e == hipSuccess && thresh > 0) e = hipMemcpy(counts_out, cnt, sizeof(int32_t) * d.N, hipMemcpyDeviceToHost);
@@ -1365,6 +1388,10 @@ int plm_eval(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_
 }
 
 int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_out, float *cn_out) {
+    return plm_scores_ex(jij, n_sites, n_states, 0, fn_out, cn_out);
+}
+
+int plm_scores_ex(const float *jij, int32_t n_sites, int32_t n_states, int32_t flags, float *fn_out, float *cn_out) {
     if (!jij || !fn_out || !cn_out) return fail(PLM_EINVAL, "NULL argument");
     if (n_sites < 2 || n_states < 1 || n_states > 32) return fail(PLM_EINVAL, "bad L / q");
     std::vector<int8_t> dummy((size_t)n_sites, 0);
@@ -1379,7 +1406,7 @@ int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_ou
     int rc = dalloc(&dfn, (size_t)n_sites * n_sites);
     if (rc) { hipFree(dj); return rc; }
     hipError_t e = hipMemcpy(dj, jij, sizeof(float) * nj, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = plm_launch_fn(d, dj, dfn, nullptr);
+    if (e == hipSuccess) e = plm_launch_fn(d, dj, dfn, (flags & PLM_CONV_FN_NO_GAP) ? 1 : 0, nullptr);
     if (e == hipSuccess) e = hipMemcpy(fn_out, dfn, sizeof(float) * n_sites * n_sites, hipMemcpyDeviceToHost);
     hipFree(dj);
     hipFree(dfn);

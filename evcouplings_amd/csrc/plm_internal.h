@@ -49,6 +49,8 @@ struct PlmDims {
     int64_t n_native;  // nh_pad + nbp*Q*Q*256
     int64_t n_canon;   // L*Q + L(L-1)/2*Q*Q
     int gap_mode;      // 1: state 0 (gap) excluded from the model (plmc -g)
+    int conv;          // PLM_CONV_* convention switches (include/plm_hip.h)
+    double theta;      // identity threshold (PLM_CONV_G_UNGAPPED_LENGTH evaluates it per pair)
     // ---- sharded-state mode (PLM_FLAG_SHARDED_STATE): parameters, gradient and L-BFGS vectors are
     // split by owning site block; the "local" vector is [h of own sites | pairs (I own, J >= I)].
     // In every other mode the local vector IS the native vector (own_lo = 0, own_hi = nb16).
@@ -142,7 +144,8 @@ hipError_t plm_launch_lincomb(float *out, float ca, const float *a, float cb, co
                               int64_t n, hipStream_t st);
 hipError_t plm_launch_canon_to_native(const PlmDims &d, const float *xc, float *xn, hipStream_t st);
 hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *xc, hipStream_t st);
-hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, hipStream_t st);
+// a_lo = 1: state 0 is left out of the norm (PLM_CONV_FN_NO_GAP), the gauge is still taken over all Q states
+hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, int a_lo, hipStream_t st);
 size_t plm_bt_bytes(const PlmDims &d);
 size_t plm_rt_bytes(const PlmDims &d);
 size_t plm_g_bytes(const PlmDims &d);      // [ksplit][nmf][nnfl][256] floats

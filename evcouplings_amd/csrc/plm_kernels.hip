@@ -18,6 +18,7 @@
 // in registers (never materialised in memory); the dense operand (couplings / residuals)
 // is split into two f16 planes (22-bit significand, power-of-two pre-scaled) and
 // accumulated in f32 by v_mfma_f32_16x16x32_f16.  Written for wave64 / gfx950 only.
+#include "../../include/plm_hip.h"
 #include "plm_internal.h"
 #include <math.h>
 #include <stdlib.h>
@@ -226,24 +227,34 @@ __device__ __forceinline__ u32 gaps_to_sentinel(u32 v) {
     const u32 z = (v - 0x01010101u) & ~v & 0x80808080u;   // 0x80 in every zero byte (all bytes < 0x80)
     return v + (z >> 7) * 0x7cu;
 }
+// 0x80 in every zero byte of v (all bytes < 0x80)
+__device__ __forceinline__ u32 zero_bytes(u32 v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
+// UNGAPPED (PLM_CONV_G_UNGAPPED_LENGTH, gap mode only): the threshold of a pair applies to the n_both positions where
+// both sequences are ungapped, ident >= ceil(theta * n_both - 1e-9); npad = padded columns (they look like matches)
+template <bool UNGAPPED>
 __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32, int Lw, int N,
                                                  int thresh_padded, int t_per_block,
-                                                 int32_t *__restrict__ counts, int gap_mode) {
+                                                 int32_t *__restrict__ counts, int gap_mode, double theta, int npad) {
     const int s = blockIdx.x * 256 + threadIdx.x;  // < Np always (rows exist, padded)
     const int tb0 = blockIdx.y * t_per_block;
     const int tb1 = min(N, tb0 + t_per_block);
     const u32 *__restrict__ myrow = msa32 + (size_t)s * Lw;
     int cnt = 0;
     for (int t0 = tb0; t0 < tb1; t0 += RW_TT) {
-        int ident[RW_TT];
+        int ident[RW_TT], both[UNGAPPED ? RW_TT : 1];
 #pragma unroll
         for (int k = 0; k < RW_TT; k++) ident[k] = 0;
+        if constexpr (UNGAPPED) {
+#pragma unroll
+            for (int k = 0; k < RW_TT; k++) both[k] = 0;
+        }
         for (int c0 = 0; c0 < Lw; c0 += RW_CW) {   // Lw is a multiple of 8
-            u32 mine[RW_CW];
+            u32 mine[RW_CW], mgap[UNGAPPED ? RW_CW : 1];
             const int cw = min(RW_CW, Lw - c0);
 #pragma unroll
             for (int k = 0; k < RW_CW; k++) {
                 mine[k] = k < cw ? myrow[c0 + k] : 0x7e7e7e7eu;
+                if constexpr (UNGAPPED) mgap[k] = zero_bytes(mine[k]);
                 if (gap_mode) mine[k] = gaps_to_sentinel(mine[k]);
             }
 #pragma unroll
@@ -256,13 +267,23 @@ __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32,
                     const u32 other = k < cw ? trow[k] : 0x7d7d7d7du;
                     const u32 y = (mine[k] ^ other) + 0x7f7f7f7fu;      // bit7 set <=> mismatch
                     acc += 4 - __builtin_popcount(y & 0x80808080u);
+                    if constexpr (UNGAPPED)
+                        if (k < cw) both[tt] += 4 - __builtin_popcount(mgap[k] | zero_bytes(other));
                 }
                 ident[tt] = acc;
             }
         }
 #pragma unroll
-        for (int tt = 0; tt < RW_TT; tt++)
-            cnt += (t0 + tt < tb1 && (ident[tt] >= thresh_padded || (gap_mode && t0 + tt == s))) ? 1 : 0;
+        for (int tt = 0; tt < RW_TT; tt++) {
+            bool hit;
+            if constexpr (UNGAPPED) {
+                const int nb = both[tt] - npad, id = ident[tt] - npad;
+                hit = id >= (int)ceil(theta * (double)nb - 1e-9);
+            } else {
+                hit = ident[tt] >= thresh_padded;
+            }
+            cnt += (t0 + tt < tb1 && (hit || (gap_mode && t0 + tt == s))) ? 1 : 0;
+        }
     }
     if (s < N && cnt) atomicAdd(&counts[s], cnt);
 }
@@ -343,13 +364,17 @@ __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ ms
 hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thresh, int32_t *counts,
                                hipStream_t st) {
     const int Lw = d.Lp32 / 4;
+    // -g conventions (include/plm_hip.h): gap-gap identities, threshold on the jointly ungapped length
+    const bool ungapped = d.gap_mode && (d.conv & PLM_CONV_G_UNGAPPED_LENGTH);    // implies: gaps are no identities
+    const int gap_mode = (d.gap_mode && (ungapped || !(d.conv & PLM_CONV_G_GAPS_IDENTICAL))) ? 1 : 0;
+    const bool fast = Lw <= 192 && !ungapped;
     // symmetric kernel: every sequence starts with itself counted; fallback kernel: self is a match
-    hipError_t e = (Lw <= 192) ? hipMemsetD32Async((hipDeviceptr_t)counts, 1, (size_t)d.Np, st)
-                               : hipMemsetAsync(counts, 0, sizeof(int32_t) * d.Np, st);
+    hipError_t e = fast ? hipMemsetD32Async((hipDeviceptr_t)counts, 1, (size_t)d.Np, st)
+                        : hipMemsetAsync(counts, 0, sizeof(int32_t) * d.Np, st);
     if (e != hipSuccess) return e;
     // padded columns (value 127 in every row) always match: shift the threshold instead
     const int thr = thresh + (d.Lp32 - d.L);
-    if (Lw <= 192) {
+    if (fast) {
         int tsplit = std::max(1, (8192 + d.nstiles - 1) / d.nstiles);   // ~half the blocks exit at once
         tsplit = std::max(tsplit, (d.N + 8191) / 8192);                    // LDS column counters <= 32 KB
         int tper = (d.N + tsplit - 1) / tsplit;
@@ -357,11 +382,11 @@ hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thres
         const dim3 grid(d.nstiles, tsplit), block(256);
         const size_t lds = sizeof(int) * (size_t)tper;
         const u32 *m32 = (const u32 *)msa_rm;
-        if (Lw <= 32) hipLaunchKernelGGL(k_reweight_reg<32>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else if (Lw <= 64) hipLaunchKernelGGL(k_reweight_reg<64>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else if (Lw <= 96) hipLaunchKernelGGL(k_reweight_reg<96>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else if (Lw <= 128) hipLaunchKernelGGL(k_reweight_reg<128>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
-        else hipLaunchKernelGGL(k_reweight_reg<192>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, d.gap_mode);
+        if (Lw <= 32) hipLaunchKernelGGL(k_reweight_reg<32>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, gap_mode);
+        else if (Lw <= 64) hipLaunchKernelGGL(k_reweight_reg<64>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, gap_mode);
+        else if (Lw <= 96) hipLaunchKernelGGL(k_reweight_reg<96>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, gap_mode);
+        else if (Lw <= 128) hipLaunchKernelGGL(k_reweight_reg<128>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, gap_mode);
+        else hipLaunchKernelGGL(k_reweight_reg<192>, grid, block, lds, st, m32, Lw, d.N, thr, tper, counts, gap_mode);
         return hipGetLastError();
     }
     int tsplit = (2048 + d.nstiles - 1) / d.nstiles;
@@ -370,8 +395,12 @@ hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thres
     tsplit = (d.N + tper - 1) / tper;
     // the padded rows t in [N, Np) are readable; rows beyond Np are not: cap the tile walk
     // (tb1 <= N and t0+tt < t0+RW_TT <= Np + RW_TT) -> msa_rm is allocated with RW_TT spare rows
-    hipLaunchKernelGGL(k_reweight, dim3(d.nstiles, tsplit), dim3(256), 0, st,
-                       (const u32 *)msa_rm, Lw, d.N, thr, tper, counts, d.gap_mode);
+    if (ungapped)   // the threshold is per pair; a sequence with itself always passes (ident = n_both)
+        hipLaunchKernelGGL(k_reweight<true>, dim3(d.nstiles, tsplit), dim3(256), 0, st, (const u32 *)msa_rm, Lw, d.N,
+                           thr, tper, counts, gap_mode, d.theta, d.Lp32 - d.L);
+    else
+        hipLaunchKernelGGL(k_reweight<false>, dim3(d.nstiles, tsplit), dim3(256), 0, st, (const u32 *)msa_rm, Lw,
+                           d.N, thr, tper, counts, gap_mode, d.theta, d.Lp32 - d.L);
     return hipGetLastError();
 }
 
@@ -2050,7 +2079,8 @@ hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *
 
 // row a8: zero-sum gauge + Frobenius norm per pair (couplings/model.py:208-231, 792),
 // one wave per pair; means and the squared norm are accumulated in f64
-__global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict__ jij, float *__restrict__ fn) {
+__global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict__ jij, float *__restrict__ fn,
+                                          int a_lo) {
     __shared__ float blk[32 * 32];
     __shared__ double rm[32], cm[32];
     __shared__ double red[1];
@@ -2079,7 +2109,7 @@ __global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict
     double ss = 0;
     for (int k = threadIdx.x; k < QQ; k += 64) {
         const double z = (double)blk[k] - rm[k / Q] - cm[k % Q] + m;
-        ss += z * z;
+        if (k / Q >= a_lo && k % Q >= a_lo) ss += z * z;   // a_lo = 1: gap state left out (PLM_CONV_FN_NO_GAP)
     }
     const double t = block_reduce_sum(ss, red);
     if (threadIdx.x == 0) {
@@ -2088,8 +2118,8 @@ __global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict
         fn[(size_t)j * L + i] = v;
     }
 }
-hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, hipStream_t st) {
-    hipLaunchKernelGGL(k_fn, dim3(d.L, d.L), dim3(64), 0, st, d.L, d.Q, jij_canon, fn);
+hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, int a_lo, hipStream_t st) {
+    hipLaunchKernelGGL(k_fn, dim3(d.L, d.L), dim3(64), 0, st, d.L, d.Q, jij_canon, fn, a_lo);
     return hipGetLastError();
 }
 

@@ -38,12 +38,35 @@ def device_count():
     return _lib.load().plm_device_count()
 
 
-def reweight(msa, theta_id=0.8):
-    """Cluster sizes (incl. self) at identity >= theta_id; twin of alignment.py:1193-1233."""
+# convention switches (include/plm_hip.h PLM_CONV_*): selectable conventions of plmc that cannot be verified here
+CONV_THRESHOLD_F32 = 32        # App. D-1: float32 evaluation of the cluster threshold
+CONV_G_GAPS_IDENTICAL = 64     # -g: gap-gap positions count as identical in reweighting
+CONV_G_UNGAPPED_LENGTH = 128   # -g: threshold on the positions where both sequences are ungapped
+CONV_G_FREQ_TOTAL = 256        # -g: frequencies normalised by N_eff instead of the ungapped weight
+CONV_FN_NO_GAP = 512           # App. D-3: Frobenius norm without the gap state
+CONV_MASK = 32 | 64 | 128 | 256 | 512
+
+
+def conventions_from_env(conventions=None):
+    """Explicit value, else the environment variable PLM_HIP_CONVENTIONS (an integer, e.g. "320" or "0x140"), else 0:
+    lets an unmodified pipeline select conventions for the run_plmc drop-in."""
+    import os
+    if conventions is None:
+        conventions = int(os.environ.get("PLM_HIP_CONVENTIONS", "0"), 0)
+    conventions = int(conventions)
+    if conventions & ~CONV_MASK:
+        raise ValueError("unknown convention bits in %d (known: %d)" % (conventions, CONV_MASK))
+    return conventions
+
+
+def reweight(msa, theta_id=0.8, ignore_gaps=False, conventions=0):
+    """Cluster sizes (incl. self) at identity >= theta_id; twin of alignment.py:1193-1233.
+    ignore_gaps / conventions: plmc -g semantics and PLM_CONV_* switches."""
     lib = _lib.load()
     msa = _msa(msa)
     counts = np.zeros(msa.shape[0], dtype=np.int32)
-    check(lib.plm_reweight(_ptr(msa), msa.shape[0], msa.shape[1], float(theta_id), _ptr(counts)))
+    flags = (FLAG_IGNORE_GAPS if ignore_gaps else 0) | int(conventions)
+    check(lib.plm_reweight_ex(_ptr(msa), msa.shape[0], msa.shape[1], float(theta_id), flags, _ptr(counts)))
     return counts
 
 
@@ -75,13 +98,14 @@ def evaluate(msa, weights, q, lambda_h, lambda_j, x):
     return fx.value, nll.value, g
 
 
-def scores(jij, L, q):
-    """FN and CN (APC) matrices from i<j coupling blocks; twin of model.py:179-233, 744-827."""
+def scores(jij, L, q, conventions=0):
+    """FN and CN (APC) matrices from i<j coupling blocks; twin of model.py:179-233, 744-827.
+    conventions & CONV_FN_NO_GAP: state 0 left out of the Frobenius norm."""
     lib = _lib.load()
     jij = np.ascontiguousarray(jij, dtype=np.float32)
     fn = np.zeros((L, L), dtype=np.float32)
     cn = np.zeros((L, L), dtype=np.float32)
-    check(lib.plm_scores(_ptr(jij), L, q, _ptr(fn), _ptr(cn)))
+    check(lib.plm_scores_ex(_ptr(jij), L, q, int(conventions), _ptr(fn), _ptr(cn)))
     return fn, cn
 
 
@@ -218,7 +242,7 @@ def _strip_gaps(x, L, q):
 
 
 def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, n_shards, shard,
-             ignore_gaps=False, sharded_state=False, precond=False, joint=False):
+             ignore_gaps=False, sharded_state=False, precond=False, joint=False, conventions=0):
     N, L = msa.shape
     p = PlmProblem()
     p.n_seqs, p.n_sites, p.n_states = N, L, q
@@ -228,13 +252,13 @@ def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbf
     p.max_iter, p.epsilon, p.lbfgs_m = int(max_iter), float(epsilon), int(lbfgs_m)
     p.n_shards, p.shard = int(n_shards), int(shard)
     p.flags = ((FLAG_IGNORE_GAPS if ignore_gaps else 0) | (FLAG_SHARDED_STATE if sharded_state else 0) |
-               (FLAG_PRECOND if precond else 0) | (FLAG_JOINT_LBFGS if joint else 0))
+               (FLAG_PRECOND if precond else 0) | (FLAG_JOINT_LBFGS if joint else 0) | (int(conventions) & CONV_MASK))
     return p
 
 
 def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
         epsilon=1e-3, lbfgs_m=6, device=0, stream=0, callback=None, n_shards=1, shard=0,
-        exchange=None, want_fij=True, ignore_gaps=False, collective=None, precond=False, joint=False):
+        exchange=None, want_fij=True, ignore_gaps=False, collective=None, precond=False, joint=False, conventions=0):
     """
     Whole couplings inference: reweight -> marginals -> L-BFGS -> scores.
 
@@ -248,7 +272,7 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     joint=True optimises fields and couplings jointly with L-BFGS as libLBFGS-based plmc does
     (PLM_FLAG_JOINT_LBFGS) instead of the default variable projection (fields solved by Newton for every trial
     couplings, ~10-20x fewer iterations to the same optimum); precond=True gives L-BFGS a diagonal initial Hessian
-    (PLM_FLAG_PRECOND).
+    (PLM_FLAG_PRECOND).  conventions: PLM_CONV_* bits (CONV_* above), the selectable conventions of plmc.
     Returns a dict of numpy arrays and scalars.
     """
     lib = _lib.load()
@@ -278,7 +302,8 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     else:
         xcb = C.cast(None, _lib.EXCHANGE_CB)
     prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
-                    n_shards, shard, ignore_gaps, sharded_state=collective is not None, precond=precond, joint=joint)
+                    n_shards, shard, ignore_gaps, sharded_state=collective is not None, precond=precond, joint=joint,
+                    conventions=conventions)
     if collective is not None:
         ccb = _wrap_collective(collective)
         check(lib.plm_fit_sharded(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
@@ -305,7 +330,7 @@ class PlmContext:
 
     def __init__(self, msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None,
                  max_iter=100, epsilon=1e-3, lbfgs_m=6, device=0, stream=0, n_shards=1, shard=0,
-                 ignore_gaps=False, sharded_state=False, precond=False, joint=False):
+                 ignore_gaps=False, sharded_state=False, precond=False, joint=False, conventions=0):
         self.lib = _lib.load()
         msa = _msa(msa)
         self.N, self.L = msa.shape
@@ -314,7 +339,7 @@ class PlmContext:
         self.qm = q - 1 if ignore_gaps else q      # model states (layout of x, g, fi, fij at this API)
         self.lambda_j = default_lambda_j(self.L, self.qm) if lambda_j is None else lambda_j
         prob = _problem(msa, q, theta_id, scale, lambda_h, self.lambda_j, max_iter, epsilon, lbfgs_m,
-                        n_shards, shard, ignore_gaps, sharded_state, precond, joint)
+                        n_shards, shard, ignore_gaps, sharded_state, precond, joint, conventions)
         self._h = C.c_void_p()
         check(self.lib.plm_ctx_create(C.byref(prob), int(device), C.c_void_p(int(stream) or None),
                                       C.byref(self._h)))

@@ -87,7 +87,7 @@ def _valid_file(path):
 def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, alphabet=None, theta=None,
                    scale=None, ignore_gaps=False, iterations=None, lambda_h=None, lambda_J=None,
                    lambda_g=None, cpu=None, epsilon=None, lbfgs_m=6, device=0, distributed=False,
-                   callback=None):
+                   callback=None, conventions=None):
     """Does the work of run_plmc_hip and additionally returns the raw fit dict and the log text."""
     from evcouplings_amd import plm   # imports the HIP library: fails loudly if it is not built
 
@@ -127,7 +127,9 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
     fit_kwargs = dict(q=q, ignore_gaps=bool(ignore_gaps), theta_id=theta, scale=scale, lambda_h=lambda_h, lambda_j=lambda_J,
                       max_iter=iterations, epsilon=DEFAULTS["epsilon"] if epsilon is None else float(epsilon),
-                      lbfgs_m=lbfgs_m, callback=callback)
+                      lbfgs_m=lbfgs_m, callback=callback,
+                      # PLM_CONV_* switches: explicit, or the environment variable PLM_HIP_CONVENTIONS
+                      conventions=plm.conventions_from_env(conventions))
     try:
         if distributed:
             res = _dist.fit_distributed(enc.msa, **fit_kwargs)

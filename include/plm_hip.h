@@ -83,6 +83,29 @@ typedef struct {
  * |g|/|x| < epsilon.  With max_iter far below convergence (the reference default 100) the two paths stop at
  * different points. */
 #define PLM_FLAG_JOINT_LBFGS 16
+/* ---- convention switches ---------------------------------------------------------------------------------------
+ * plmc is not available to this project, so a few of its conventions cannot be checked; each
+ * is a switch here (same bits in the oracle, oracle/plm_oracle.c), so that a plmc binary on a future host pins the
+ * path by choosing bits, not by changing code.  Defaults (bit clear) are the documented ones of DESIGN.md section 2.
+ *   PLM_CONV_THRESHOLD_F32      SURVEY App. D-1: the cluster threshold as a float32 plmc would evaluate what run_plmc
+ *                               sends it (-t 1-theta): ident >= (float)(1 - (float)(1 - theta)) * L, instead of the
+ *                               integer rule ceil(theta * L - 1e-9).  Identical for theta = 0.8 and every L <= 2000.
+ *   PLM_CONV_G_GAPS_IDENTICAL   -g: two gaps at a position count as identical in reweighting, as without -g (plmc's
+ *                               usage text describes -g as excluding the gap from the POTENTIAL calculations only);
+ *                               default: only non-gap matches count.
+ *   PLM_CONV_G_UNGAPPED_LENGTH  -g: the identity threshold applies to the positions where both sequences are
+ *                               ungapped, ident >= ceil(theta * n_both - 1e-9), instead of the full length.
+ *   PLM_CONV_G_FREQ_TOTAL       -g: f_i and f_ij are normalised by N_eff (all sequences), so they sum to the ungapped
+ *                               fraction of a site / pair; default: normalised over the ungapped sequences.
+ *   PLM_CONV_FN_NO_GAP          SURVEY App. D-3: the Frobenius norm of a coupling block (zero-sum gauge over all q
+ *                               states) sums the non-gap states only; default: all q states, as the reference's
+ *                               CouplingsModel does (couplings/model.py:792).  No effect with -g (no gap state). */
+#define PLM_CONV_THRESHOLD_F32 32
+#define PLM_CONV_G_GAPS_IDENTICAL 64
+#define PLM_CONV_G_UNGAPPED_LENGTH 128
+#define PLM_CONV_G_FREQ_TOTAL 256
+#define PLM_CONV_FN_NO_GAP 512
+#define PLM_CONV_MASK (32 | 64 | 128 | 256 | 512)
 
 /* Per-iteration progress: the 7 columns of plmc's stderr table that
  * parse_plmc_log() collects (tools.py:59-83): iter time cond fx -loglk ||h|| ||e||. */
@@ -155,6 +178,9 @@ int plm_fit_sharded(const plm_problem_t *problem, plm_result_t *result, int devi
 /* plmc sequence reweighting; twin: align/alignment.py:1193-1233.  counts[s] = cluster size. */
 int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id,
                  int32_t *counts_out);
+/* the same with plmc -g semantics and / or PLM_CONV_* switches: flags = PLM_FLAG_IGNORE_GAPS | PLM_CONV_... */
+int plm_reweight_ex(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id, int32_t flags,
+                    int32_t *counts_out);
 /* plmc marginals; twins: align/alignment.py:1079-1153.  weights need not be normalised. */
 int plm_marginals(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_sites,
                   int32_t n_states, float *fi_out, float *fij_out);
@@ -165,6 +191,8 @@ int plm_eval(const int8_t *msa, const float *weights, int32_t n_seqs, int32_t n_
 /* plmc EC scoring; twins: couplings/model.py:179-233, 744-775, 790-793.  fn/cn dense LxL. */
 int plm_scores(const float *jij, int32_t n_sites, int32_t n_states, float *fn_out,
                float *cn_out);
+/* the same with PLM_CONV_FN_NO_GAP in flags: state 0 left out of the Frobenius norm */
+int plm_scores_ex(const float *jij, int32_t n_sites, int32_t n_states, int32_t flags, float *fn_out, float *cn_out);
 
 /* ---- statistical energies under a fitted model -------------------
  * Replace the numba loops of evcouplings/couplings/model.py that the mutate stage and

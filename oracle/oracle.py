@@ -69,6 +69,13 @@ class Oracle:
         f.restype = None
         f(int(n))
 
+    def set_conventions(self, conv):
+        """PLM_CONV_* bits of include/plm_hip.h (process-global in the library; reset with 0)."""
+        f = self._f("set_conventions")
+        f.argtypes = [C.c_int]
+        f.restype = None
+        f(int(conv))
+
     def threshold(self, L, theta_id):
         f = self._f("threshold")
         f.argtypes = [C.c_int, C.c_double]

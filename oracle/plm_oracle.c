@@ -90,7 +90,20 @@ int PLMO_NAME(num_threads)(void) {
 /* Integer identity threshold, SURVEY.md App. C.1 / D-1: ident >= ceil(theta*L - 1e-9).
  * Equal to the in-repo rule `pair_id / L >= identity_threshold`
  * (align/alignment.py:1229) for every L the tests sweep. */
+/* Convention switches (the PLM_CONV_* bits of include/plm_hip.h; same numbers): conventions of plmc that cannot be
+ * verified here are selectable, identically in the oracle and in the HIP library.  Process-global (the oracle is
+ * test infrastructure): 32 float32 threshold, 64 -g gap-gap identities, 128 -g threshold on the jointly ungapped
+ * length, 256 -g frequencies normalised by N_eff, 512 Frobenius norm without the gap state. */
+static int g_conv = 0;
+void PLMO_NAME(set_conventions)(int conv) { g_conv = conv; }
+int PLMO_NAME(get_conventions)(void) { return g_conv; }
+
 int PLMO_NAME(threshold)(int L, double theta_id) {
+    if (g_conv & 32) {   /* what a float32 plmc makes of `-t 1-theta` (tools.py:236-239) */
+        const float t = (float)(1.0 - theta_id);
+        const float need = (1.0f - t) * (float)L;
+        return (int)ceilf(need);
+    }
     return (int)ceil(theta_id * (double)L - 1e-9);
 }
 
@@ -247,9 +260,20 @@ int PLMO_NAME(reweight_gaps)(const int8_t *msa, int N, int L, double theta_id, i
         int c = 0;
         for (int t = 0; t < N; t++) {
             const int8_t *b = msa + (size_t)t * L;
-            int id = 0;
-            for (int k = 0; k < L; k++) id += (a[k] == b[k]) && (a[k] != 0);
-            c += (id >= T) || (t == s);   /* a sequence always belongs to its own cluster */
+            int id = 0, nb = 0;
+            if ((g_conv & 64) && !(g_conv & 128)) {          /* gap-gap positions are identities, as without -g */
+                for (int k = 0; k < L; k++) id += (a[k] == b[k]);
+                c += (id >= T) || (t == s);
+                continue;
+            }
+            for (int k = 0; k < L; k++) {
+                id += (a[k] == b[k]) && (a[k] != 0);
+                nb += (a[k] != 0) && (b[k] != 0);
+            }
+            if (g_conv & 128)                                /* threshold on the jointly ungapped length */
+                c += (id >= (int)ceil(theta_id * (double)nb - 1e-9)) || (t == s);
+            else
+                c += (id >= T) || (t == s);   /* a sequence always belongs to its own cluster */
         }
         counts[s] = c;
     }
@@ -260,12 +284,16 @@ int PLMO_NAME(marginals_gaps)(const int8_t *msa, const real *w, int N, int L, in
     if (!msa || !w || !fi || N <= 0 || L <= 0 || q <= 1) return PLMO_EINVAL;
     const int qn = q - 1;
     const size_t qq = (size_t)qn * qn;
+    double neff = 0;
+    for (int s = 0; s < N; s++) neff += w[s];
+    const int by_total = (g_conv & 256) != 0;    /* normalise by N_eff instead of the ungapped weight */
     for (int i = 0; i < L; i++) {
         double c[64] = {0}, tot = 0;
         for (int s = 0; s < N; s++) {
             const int a = msa[(size_t)s * L + i];
             if (a > 0) { c[a - 1] += w[s]; tot += w[s]; }
         }
+        if (by_total) tot = neff;
         for (int a = 0; a < qn; a++) fi[(size_t)i * qn + a] = (real)(tot > 0 ? c[a] / tot : 0);
     }
     if (fij) {
@@ -278,6 +306,7 @@ int PLMO_NAME(marginals_gaps)(const int8_t *msa, const real *w, int N, int L, in
                     const int a = msa[(size_t)s * L + i], b = msa[(size_t)s * L + j];
                     if (a > 0 && b > 0) { c[(size_t)(a - 1) * qn + (b - 1)] += w[s]; tot += w[s]; }
                 }
+                if (by_total) tot = neff;
                 for (size_t k = 0; k < qq; k++) blk[k] = (real)(tot > 0 ? c[k] / tot : 0);
                 free(c);
             }
@@ -368,7 +397,12 @@ int PLMO_NAME(eval_gaps)(const int8_t *msa, const real *w, int N, int L, int q, 
  * evcouplings/couplings/model.py:179-233 (_zero_sum_gauge), :790-793 (FN over all q
  * states) and :744-775 (apc: column means over off-diagonal entries, factor L/(L-1),
  * diagonal blanked).  jij = i<j blocks; fn, cn = dense L x L (symmetric, zero diag). */
+static int scores_impl(const real *jij, int L, int q, int a_lo, double *fn, double *cn);
 int PLMO_NAME(scores)(const real *jij, int L, int q, double *fn, double *cn) {
+    return scores_impl(jij, L, q, (g_conv & 512) ? 1 : 0, fn, cn);
+}
+/* a_lo = 1: the gap state is left out of the Frobenius norm (the gauge is still taken over all q states) */
+static int scores_impl(const real *jij, int L, int q, int a_lo, double *fn, double *cn) {
     if (!jij || !fn || !cn || L <= 1 || q <= 0) return PLMO_EINVAL;
     const size_t qq = (size_t)q * q;
     memset(fn, 0, sizeof(double) * (size_t)L * L);
@@ -388,7 +422,7 @@ int PLMO_NAME(scores)(const real *jij, int L, int q, double *fn, double *cn) {
             for (int a = 0; a < q; a++)
                 for (int b = 0; b < q; b++) {
                     const double v = blk[(size_t)a * q + b] - rm[a] / q - cm[b] / q + m;
-                    ss += v * v;
+                    if (a >= a_lo && b >= a_lo) ss += v * v;
                 }
             fn[(size_t)i * L + j] = fn[(size_t)j * L + i] = sqrt(ss);
         }
@@ -802,7 +836,7 @@ int PLMO_NAME(fit2)(const int8_t *msa, int N, int L, int q, double theta_id, dou
         if (status_out) *status_out = status;
         if (nevals_out) *nevals_out = c.nevals;
         if (fx_out) *fx_out = fx;
-        if (fn && cn) rc = PLMO_NAME(scores)(x_out + nh, L, qm, fn, cn);
+        if (fn && cn) rc = scores_impl(x_out + nh, L, qm, (!gaps && (g_conv & 512)) ? 1 : 0, fn, cn);
     }
     free(counts);
     if (!weights) free(w);

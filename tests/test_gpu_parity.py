@@ -698,3 +698,51 @@ def test_run_plmc_hip_launches_ranks_for_cpu_option(plm, tmp_path, monkeypatch):
     ea = np.loadtxt(str(tmp_path / "a_ECs.txt"), usecols=5)
     eb = np.loadtxt(str(tmp_path / "b_ECs.txt"), usecols=5)
     np.testing.assert_allclose(eb, ea, atol=2e-4)
+
+
+@pytest.mark.parametrize("conv", [0, 32, 64, 128, 256, 64 | 256, 128 | 256, 512, 32 | 64 | 256 | 512])
+def test_convention_switches_match_the_oracle(plm, oracle64, conv):
+    """PLM_CONV_* (include/plm_hip.h): every selectable convention of plmc is implemented identically by the oracle
+    and the HIP path -- counts bit-exact, frequencies to 2e-6, scores to 5e-6, and a fit under the switched
+    conventions lands on the oracle's optimum.  theta = 0.6 and L = 25 make the float32 threshold differ from the
+    integer rule; the synthetic alignment has terminal gap runs, so the -g rules differ too."""
+    N, L, theta = 300, 25, 0.6
+    msa, _ = synthetic_msa(N, L, seed=77)
+    gaps = bool(conv & (64 | 128 | 256))
+    oracle64.set_conventions(conv)
+    try:
+        ref_counts = oracle64.reweight_gaps(msa, theta) if gaps else oracle64.reweight(msa, theta)
+        got = plm.reweight(msa, theta, ignore_gaps=gaps, conventions=conv)
+        np.testing.assert_array_equal(got, ref_counts)
+        if conv & 32:
+            oracle64.set_conventions(conv & ~32)
+            other = oracle64.reweight_gaps(msa, theta) if gaps else oracle64.reweight(msa, theta)
+            oracle64.set_conventions(conv)
+            assert (other != ref_counts).any()                     # the switch really changes something here
+        w = (1.0 / ref_counts).astype(np.float32)
+        with plm.PlmContext(msa, q=Q, theta_id=theta, ignore_gaps=gaps, conventions=conv) as ctx:
+            ctx.set_weights(w)
+            fi, fij = ctx.marginals()
+        rfi, rfij = (oracle64.marginals_gaps if gaps else oracle64.marginals)(msa, w.astype(np.float64), Q)
+        np.testing.assert_allclose(fi, rfi, atol=2e-6)
+        np.testing.assert_allclose(fij, rfij, atol=2e-6)
+        if conv & 256:
+            assert (fi.sum(axis=1) < 1 - 1e-3).any()               # sites with gaps: frequencies sum to the ungapped share
+        rng = np.random.default_rng(3)
+        jij = rng.normal(0, 0.1, (L * (L - 1) // 2, Q, Q)).astype(np.float32)
+        fn, cn = plm.scores(jij, L, Q, conventions=conv)
+        rfn, rcn = oracle64.scores(jij.astype(np.float64), L, Q)
+        np.testing.assert_allclose(fn, rfn, atol=5e-6)
+        np.testing.assert_allclose(cn, rcn, atol=5e-6)
+        if conv & 512:
+            assert np.abs(fn - plm.scores(jij, L, Q)[0]).max() > 1e-3
+        if conv in (64 | 256, 512, 32 | 64 | 256 | 512):
+            lj = plm.default_lambda_j(L, Q - 1 if gaps else Q)
+            ref = oracle64.fit(msa, Q, theta_id=theta, lambda_j=lj, max_iter=3000, epsilon=1e-7, ignore_gaps=gaps,
+                               want_fij=False)
+            res = plm.fit(msa, Q, theta_id=theta, lambda_j=lj, max_iter=3000, epsilon=2e-6, ignore_gaps=gaps,
+                          conventions=conv, want_fij=False)
+            assert res["status"] == 0 and res["n_eff"] == pytest.approx(ref["n_eff"], rel=1e-6)
+            assert np.abs(res["cn"] - ref["cn"]).max() < 1e-4
+    finally:
+        oracle64.set_conventions(0)

@@ -274,3 +274,61 @@ def test_meanfield_restatement_matches_reference_golden(golden_dir, case):
     np.testing.assert_allclose(out["jij_full"], z["jij_full"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(out["hi"], z["hi"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(out["di"], z["di"], rtol=0, atol=1e-12)
+
+
+def test_convention_switches_of_the_oracle_against_brute_force(oracle64):
+    """The PLM_CONV_* rules (include/plm_hip.h), restated in plain Python on a small gapped alignment."""
+    import math
+    rng = np.random.default_rng(12)
+    N, L, q, theta = 40, 25, 6, 0.6
+    msa = rng.integers(0, q, size=(N, L)).astype(np.int8)
+    msa[5:15] = msa[0]                                   # a cluster around sequence 0 ...
+    for s in range(5, 15):
+        msa[s, rng.integers(0, L, size=s - 2)] = 0      # ... with more and more gaps
+    w = rng.uniform(0.2, 1.0, N)
+
+    def counts(rule):
+        out = np.zeros(N, np.int32)
+        T = math.ceil(theta * L - 1e-9)
+        if rule & 32:
+            T = math.ceil(float((np.float32(1) - np.float32(1.0 - theta)) * np.float32(L)))   # float32 throughout
+        for s in range(N):
+            for t in range(N):
+                a, b = msa[s], msa[t]
+                if rule & 128:
+                    both = (a != 0) & (b != 0)
+                    hit = ((a == b) & both).sum() >= math.ceil(theta * both.sum() - 1e-9)
+                elif rule & 64:
+                    hit = (a == b).sum() >= T
+                else:
+                    hit = ((a == b) & (a != 0)).sum() >= T
+                out[s] += 1 if (hit or s == t) else 0
+        return out
+
+    try:
+        for rule in (0, 32, 64, 128, 32 | 64):
+            oracle64.set_conventions(rule)
+            np.testing.assert_array_equal(oracle64.reweight_gaps(msa, theta), counts(rule), err_msg="rule %d" % rule)
+        for rule in (0, 256):
+            oracle64.set_conventions(rule)
+            fi, fij = oracle64.marginals_gaps(msa, w, q)
+            for i in (0, 7, L - 1):
+                live = msa[:, i] != 0
+                tot = w.sum() if rule else w[live].sum()
+                ref = np.array([w[msa[:, i] == a].sum() / tot for a in range(1, q)])
+                np.testing.assert_allclose(fi[i], ref, rtol=1e-12)
+            i, j = 3, 11
+            live = (msa[:, i] != 0) & (msa[:, j] != 0)
+            tot = w.sum() if rule else w[live].sum()
+            blk = fij[i * (2 * L - i - 1) // 2 + (j - i - 1)]
+            assert blk[1, 2] == pytest.approx(w[(msa[:, i] == 2) & (msa[:, j] == 3)].sum() / tot, rel=1e-12)
+        jij = rng.normal(0, 1, (L * (L - 1) // 2, q, q))
+        oracle64.set_conventions(512)
+        fn, _ = oracle64.scores(jij, L, q)
+        b = jij[0] - jij[0].mean(0, keepdims=True) - jij[0].mean(1, keepdims=True) + jij[0].mean()
+        assert fn[0, 1] == pytest.approx(np.sqrt((b[1:, 1:] ** 2).sum()), rel=1e-12)
+        oracle64.set_conventions(0)
+        fn, _ = oracle64.scores(jij, L, q)
+        assert fn[0, 1] == pytest.approx(np.sqrt((b ** 2).sum()), rel=1e-12)
+    finally:
+        oracle64.set_conventions(0)
