@@ -90,12 +90,13 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     memset(&d, 0, sizeof d);
     if (p.n_seqs <= 0 || p.n_sites <= 1) return fail(PLM_EINVAL, "need n_seqs > 0 and n_sites > 1");
     if (!plm_q_supported(p.n_states))
-        return fail(PLM_EUNSUPPORTED, "alphabet size %d not instantiated (supported: 21, 20, 5, 4)", p.n_states);
+        return fail(PLM_EUNSUPPORTED, "alphabet size %d outside 2..21", p.n_states);
     const int nshards = p.n_shards > 0 ? p.n_shards : 1;
     if (p.shard < 0 || p.shard >= nshards) return fail(PLM_EINVAL, "shard %d outside 0..%d", p.shard, nshards - 1);
     d.N = p.n_seqs;
     d.L = p.n_sites;
-    d.Q = p.n_states;
+    d.Qc = p.n_states;                 // the problem's alphabet: stride of the canonical arrays at the API
+    d.Q = plm_q_template(p.n_states);  // the size the kernels run at; states Qc..Q-1 are dead padding
     d.Np = (d.N + PLM_SEQ_TILE - 1) / PLM_SEQ_TILE * PLM_SEQ_TILE;
     d.nb16 = (d.L + 15) / 16;
     d.Lp16 = d.nb16 * 16;
@@ -138,7 +139,7 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
     d.n_native = d.nh_pad + d.nbp * d.Q * d.Q * 256;
-    d.n_canon = (int64_t)d.L * d.Q + (int64_t)d.L * (d.L - 1) / 2 * d.Q * d.Q;
+    d.n_canon = (int64_t)d.L * d.Qc + (int64_t)d.L * (d.L - 1) / 2 * d.Qc * d.Qc;
     d.gap_mode = (p.flags & PLM_FLAG_IGNORE_GAPS) ? 1 : 0;
     d.conv = p.flags & PLM_CONV_MASK;
     d.theta = p.theta_id;
@@ -157,7 +158,7 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.n_local = d.nh_pad_l + d.np_own * d.Q * d.Q * 256;
     d.nx_halo = (int64_t)d.own_lo * d.nblk_own;
     d.ng_halo = (int64_t)d.nblk_own * (d.nb16 - d.own_hi);
-    if (d.gap_mode && d.Q < 3) return fail(PLM_EINVAL, "ignore_gaps needs at least 2 non-gap states");
+    if (d.gap_mode && d.Qc < 3) return fail(PLM_EINVAL, "ignore_gaps needs at least 2 non-gap states");
     *out = d;
     return PLM_OK;
 }
@@ -533,12 +534,12 @@ int set_start_point(plm_ctx *c) {
     for (int i = d.h_site0; i < std::min(d.L, d.own_hi * 16); i++) {
         double mean = 0;
         std::vector<double> v(d.Q);
-        for (int a = a0; a < d.Q; a++) {
-            v[a] = std::log((double)c->h_fi[(size_t)i * d.Q + a] + 1.0 / c->n_eff);
+        for (int a = a0; a < d.Qc; a++) {      // h_fi is a canonical array (Qc states), h the native field part (Q)
+            v[a] = std::log((double)c->h_fi[(size_t)i * d.Qc + a] + 1.0 / c->n_eff);
             mean += v[a];
         }
-        mean /= (d.Q - a0);
-        for (int a = a0; a < d.Q; a++) h[(size_t)(i - d.h_site0) * d.Q + a] = (float)(v[a] - mean);
+        mean /= (d.Qc - a0);
+        for (int a = a0; a < d.Qc; a++) h[(size_t)(i - d.h_site0) * d.Q + a] = (float)(v[a] - mean);
     }
     c->eval_valid = false;
     HIP_TRY(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_local, c->st));
@@ -596,8 +597,8 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     if (!(prob->theta_id >= 0.0 && prob->theta_id <= 1.0)) return fail(PLM_EINVAL, "theta_id must be in [0,1]");
     if (prob->lambda_h < 0 || prob->lambda_j < 0) return fail(PLM_EINVAL, "negative regularisation strength");
     for (size_t k = 0; k < (size_t)d.N * d.L; k++)
-        if (prob->msa[k] < 0 || prob->msa[k] >= d.Q)
-            return fail(PLM_EINVAL, "msa[%zu] = %d outside 0..%d", k, (int)prob->msa[k], d.Q - 1);
+        if (prob->msa[k] < 0 || prob->msa[k] >= d.Qc)
+            return fail(PLM_EINVAL, "msa[%zu] = %d outside 0..%d", k, (int)prob->msa[k], d.Qc - 1);
     plm_ctx *c = new plm_ctx();
     c->prob = *prob;
     c->prob.msa = nullptr;  // host pointer not retained
@@ -761,14 +762,14 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->g, c->g, 0.f, 0.f, c->reg_part, 1,
                                 d.gap_mode ? 1.f : (float)(1.0 / c->n_eff), c->st));
     HIP_TRY(plm_launch_native_to_canon(d, c->g, c->canon, c->st));
-    c->h_fi.resize((size_t)d.L * d.Q);
-    HIP_TRY(hipMemcpyAsync(c->h_fi.data(), c->canon, sizeof(float) * d.L * d.Q, hipMemcpyDeviceToHost, c->st));
+    c->h_fi.resize((size_t)d.L * d.Qc);
+    HIP_TRY(hipMemcpyAsync(c->h_fi.data(), c->canon, sizeof(float) * d.L * d.Qc, hipMemcpyDeviceToHost, c->st));
     if (fij_host)
-        HIP_TRY(hipMemcpyAsync(fij_host, c->canon + (size_t)d.L * d.Q,
-                               sizeof(float) * (d.n_canon - (int64_t)d.L * d.Q), hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipMemcpyAsync(fij_host, c->canon + (size_t)d.L * d.Qc,
+                               sizeof(float) * (d.n_canon - (int64_t)d.L * d.Qc), hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     if (d.gap_mode) {
-        const int Q = d.Q;
+        const int Q = d.Qc;
         // PLM_CONV_G_FREQ_TOTAL: normalised by N_eff (all sequences) instead of the ungapped ones
         const bool by_total = d.conv & PLM_CONV_G_FREQ_TOTAL;
         for (int i = 0; i < d.L; i++) {
@@ -793,7 +794,7 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
             }
         }
     }
-    if (fi_host) memcpy(fi_host, c->h_fi.data(), sizeof(float) * d.L * d.Q);
+    if (fi_host) memcpy(fi_host, c->h_fi.data(), sizeof(float) * d.L * d.Qc);
     return PLM_OK;
 }
 
@@ -818,19 +819,19 @@ static int canon_full(plm_ctx_t *c, const float *native) {
         // all-gather of the parameter slices: in the canonical order (fields by site, couplings by pair i<j, i
         // major) the entries a shard owns -- the fields of its sites, the pairs whose first site is one of them --
         // are two contiguous ranges, so every shard broadcasts its two ranges in place
-        const int64_t L = d.L, QQ = (int64_t)d.Q * d.Q;
+        const int64_t L = d.L, QQ = (int64_t)d.Qc * d.Qc;
         auto pairs_before = [&](int64_t i) { return i * (2 * L - i - 1) / 2; };    // pairs (i', j) with i' < i
         for (int r = 0; r < d.nshards; r++) {
             const int64_t s0 = std::min<int64_t>(L, 16 * (int64_t)plm_shard_lo(d, r));
             const int64_t s1 = std::min<int64_t>(L, 16 * (int64_t)(plm_shard_lo(d, r) + plm_shard_cnt(d, r)));
-            const int64_t hb = (s1 - s0) * d.Q * (int64_t)sizeof(float);
+            const int64_t hb = (s1 - s0) * d.Qc * (int64_t)sizeof(float);
             const int64_t jb = (pairs_before(s1) - pairs_before(s0)) * QQ * (int64_t)sizeof(float);
             // the callback contract hands over count arrays of n_shards entries
             const std::vector<int64_t> roots(d.nshards, r), hbv(d.nshards, hb), jbv(d.nshards, jb);
             if (hb > 0)
-                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + s0 * d.Q, nullptr, hbv.data(), roots.data()));
+                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + s0 * d.Qc, nullptr, hbv.data(), roots.data()));
             if (jb > 0)
-                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + L * d.Q + pairs_before(s0) * QQ, nullptr,
+                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + L * d.Qc + pairs_before(s0) * QQ, nullptr,
                                        jbv.data(), roots.data()));
         }
     }
@@ -901,10 +902,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         const int a0 = d.gap_mode;
         for (int i = 0; i < d.L; i++) {
             double tot = 0;
-            for (int a = a0; a < d.Q; a++) tot += (double)c->h_fi[i * d.Q + a] + 1.0 / c->n_eff;
-            for (int a = a0; a < d.Q; a++) {
-                const double pa = ((double)c->h_fi[i * d.Q + a] + 1.0 / c->n_eff) / tot;   // the start point's P_i(a)
-                fv[i * d.Q + a] = c->h_fi[i * d.Q + a];
+            for (int a = a0; a < d.Qc; a++) tot += (double)c->h_fi[i * d.Qc + a] + 1.0 / c->n_eff;
+            for (int a = a0; a < d.Qc; a++) {
+                const double pa = ((double)c->h_fi[i * d.Qc + a] + 1.0 / c->n_eff) / tot;   // the start point's P_i(a)
+                fv[i * d.Q + a] = c->h_fi[i * d.Qc + a];
                 fv[lq + i * d.Q + a] = (float)(pa * (1.0 - pa));
             }
         }
@@ -1212,7 +1213,7 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
     PLM_TRY(canon_full(c, c->x));
     if (d.gap_mode) {
         // the zero-sum gauge must be taken over the model's (Q-1) states only: repack the blocks
-        const int Q = d.Q, Qn = Q - 1;
+        const int Q = d.Qc, Qn = Q - 1;
         const size_t npair = (size_t)d.L * (d.L - 1) / 2;
         std::vector<float> full(npair * Q * Q), cut(npair * Qn * Qn);
         HIP_TRY(hipMemcpyAsync(full.data(), c->canon + (size_t)d.L * Q, sizeof(float) * full.size(),
@@ -1226,7 +1227,9 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
         dn.Q = Qn;
         HIP_TRY(plm_launch_fn(dn, c->canon, fn_dev, 0, c->st));
     } else {
-        HIP_TRY(plm_launch_fn(d, c->canon + (size_t)d.L * d.Q, fn_dev, (d.conv & PLM_CONV_FN_NO_GAP) ? 1 : 0, c->st));
+        PlmDims dc = d;
+        dc.Q = d.Qc;             // k_fn walks the canonical blocks: the gauge is taken over the problem's states only
+        HIP_TRY(plm_launch_fn(dc, c->canon + (size_t)d.L * d.Qc, fn_dev, (d.conv & PLM_CONV_FN_NO_GAP) ? 1 : 0, c->st));
     }
     HIP_TRY(hipMemcpyAsync(fn_host, fn_dev, sizeof(float) * d.L * d.L, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
@@ -1445,7 +1448,7 @@ static int energies_impl(const int8_t *seqs, int32_t n, int32_t L, int32_t q, co
     std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE);
     for (int s = 0; s < d.N; s++) memcpy(&rm[(size_t)s * d.Lp32], seqs + (size_t)s * d.L, d.L);
     const int nblk = d.b16_hi - d.b16_lo;
-    const size_t out_dev_floats = potentials ? (size_t)d.N * d.L * d.Q : (size_t)d.Np * nblk * 2;
+    const size_t out_dev_floats = potentials ? (size_t)d.N * d.L * d.Qc : (size_t)d.Np * nblk * 2;
     int8_t *msa_rm = nullptr;
     float *canon = nullptr, *x = nullptr, *outd = nullptr;
     char *Bt = nullptr;
@@ -1504,7 +1507,7 @@ int plm_meanfield(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t n_
     plm_ctx_t *c = nullptr;
     PLM_TRY(plm_ctx_create(&p, device, stream, &c));
     const PlmDims d = c->d;
-    const size_t lq = (size_t)d.L * d.Q, pq = (size_t)d.L * (d.L - 1) / 2 * d.Q * d.Q, llqq = lq * lq;
+    const size_t lq = (size_t)d.L * d.Qc, pq = (size_t)d.L * (d.L - 1) / 2 * d.Qc * d.Qc, llqq = lq * lq;
     double *hi = nullptr, *jfull = nullptr, *di = nullptr;
     float *jp = nullptr;
     auto done = [&](int code) {
@@ -1521,7 +1524,7 @@ int plm_meanfield(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t n_
     if ((out->hi && (rc = dalloc(&hi, lq))) || (out->jij_full && (rc = dalloc(&jfull, llqq))) ||
         (out->di && (rc = dalloc(&di, (size_t)d.L * d.L))) || (out->jij && (rc = dalloc(&jp, pq))))
         return done(rc);
-    rc = plm_meanfield_device(c->canon, c->canon + lq, d.L, d.Q, pseudo_count, c->st, hi, jfull, jp, di);
+    rc = plm_meanfield_device(c->canon, c->canon + lq, d.L, d.Qc, pseudo_count, c->st, hi, jfull, jp, di);
     if (rc) return done(rc);
     hipError_t e = hipSuccess;
     if (hi && e == hipSuccess) e = hipMemcpy(out->hi, hi, sizeof(double) * lq, hipMemcpyDeviceToHost);

@@ -26,7 +26,9 @@
 #define PLM_R_EXP 14          // residuals are stored scaled by 2^14 (|r| <= scale <= 1)
 
 struct PlmDims {
-    int N, L, Q;
+    int N, L, Q;       // Q: alphabet size the kernels are instantiated for (4, 5, 20, 21) -- the native layout's stride
+    int Qc;            // alphabet size of the problem (2..Q): stride of every canonical-layout array at the API;
+                       // states Qc..Q-1 exist only as structurally-zero padding of the native layout
     int Np;        // N padded to PLM_SEQ_TILE
     int nb16;      // 16-site blocks covering L
     int Lp16;      // nb16 * 16
@@ -151,7 +153,8 @@ size_t plm_rt_bytes(const PlmDims &d);
 size_t plm_g_bytes(const PlmDims &d);      // [ksplit][nmf][nnfl][256] floats
 size_t plm_slab_bytes(const PlmDims &d);   // [nmf][nnfl][256] floats + 256 B tail (shard nll)
 int plm_reg_parts(const PlmDims &d);       // number of double partials assemble writes
-bool plm_q_supported(int q);
+bool plm_q_supported(int q);     // 2..21
+int plm_q_template(int q);       // the instantiated alphabet size a problem with q symbols runs on
 void plm_pick_tile(int q, int *fm, int *fn);
 
 // ---- vector-free L-BFGS kernels (plm_kernels.hip) ----------------------------------------

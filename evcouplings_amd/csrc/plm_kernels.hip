@@ -201,7 +201,11 @@ static int plm_current_device() {
     (void)hipGetDevice(&dev);
     return (dev >= 0 && dev < PLM_MAX_DEVICES) ? dev : 0;
 }
-bool plm_q_supported(int q) { return q == 21 || q == 20 || q == 5 || q == 4; }
+// Any alphabet of 2..21 symbols runs on the next instantiated size (4, 5, 20, 21): the surplus states are dead
+// padding of the native layout (never observed, masked out of every softmax, parameters structurally zero), the
+// canonical arrays at the API keep the problem's own size (PlmDims::Qc).
+bool plm_q_supported(int q) { return q >= 2 && q <= 21; }
+int plm_q_template(int q) { return q <= 4 ? 4 : q == 5 ? 5 : q <= 20 ? 20 : 21; }
 void plm_pick_tile(int q, int *fm, int *fn) {
     if (q == 21) { *fm = 7; *fn = 7; }
     else if (q == 20) { *fm = 5; *fn = 5; }
@@ -223,12 +227,13 @@ int plm_reg_parts(const PlmDims &d) { return (int)(d.np_own * d.Q) + (int)((d.nh
 #define RW_TT 32   // t-rows per register tile
 #define RW_CW 16   // dwords (64 sites) per column chunk
 // zero bytes (gaps) of a packed word -> 0x7c, a value no alignment byte takes (states < 32, pad 127)
+// 0x80 in every zero byte of v, exactly (all bytes < 0x80: (b & 0x7f) + 0x7f carries into bit 7 iff b != 0, and never
+// into the next byte).  The shorter (v - 0x01010101) & ~v & 0x80808080 is NOT exact per byte: the borrow of a zero byte
+// also flags a byte of value 1 above it -- a residue of state 1 behind a gap would be taken for a gap.
+__device__ __forceinline__ u32 zero_bytes(u32 v) { return ~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u; }
 __device__ __forceinline__ u32 gaps_to_sentinel(u32 v) {
-    const u32 z = (v - 0x01010101u) & ~v & 0x80808080u;   // 0x80 in every zero byte (all bytes < 0x80)
-    return v + (z >> 7) * 0x7cu;
+    return v + (zero_bytes(v) >> 7) * 0x7cu;
 }
-// 0x80 in every zero byte of v (all bytes < 0x80)
-__device__ __forceinline__ u32 zero_bytes(u32 v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
 // UNGAPPED (PLM_CONV_G_UNGAPPED_LENGTH, gap mode only): the threshold of a pair applies to the n_both positions where
 // both sequences are ungapped, ident >= ceil(theta * n_both - 1e-9); npad = padded columns (they look like matches)
 template <bool UNGAPPED>
@@ -775,9 +780,10 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 for (int reg = 0; reg < 4; reg++) {
                     const int s = s_wave + 16 * m + 4 * g + reg;
                     if (site_ok && s < d.N) {
-                        float *o = A.out + ((size_t)s * d.L + i) * Q;
+                        float *o = A.out + ((size_t)s * d.L + i) * d.Qc;   // the API's array: the problem's alphabet
 #pragma unroll
-                        for (int a = 0; a < Q; a++) o[a] = acc[m][a][reg] * sc;
+                        for (int a = 0; a < Q; a++)
+                            if (a < d.Qc) o[a] = acc[m][a][reg] * sc;
                     }
                 }
             }
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             float mx = -INFINITY;
 #pragma unroll
             for (int a = 0; a < Q; a++) {
-                const float H = (gap && a == 0) ? -INFINITY : fmaf(acc[m][a][reg], sc, hv[a]);
+                const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : fmaf(acc[m][a][reg], sc, hv[a]);
                 acc[m][a][reg] = H;
                 mx = fmaxf(mx, H);
             }
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(512) void k_fwd_split(PlmDims d, FwdArgs A) {
             float v = -INFINITY;
 #pragma unroll
             for (int a = 0; a < NS0; a++) {
-                const bool dead = a >= ns || (gap && a_lo + a == 0);
+                const bool dead = a >= ns || (gap && a_lo + a == 0) || a_lo + a >= d.Qc;
                 const float H = dead ? -INFINITY : fmaf(acc[m][a][reg], sc, hv[a]);
                 acc[m][a][reg] = H;
                 v = fmaxf(v, H);
@@ -1211,7 +1217,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             float mx = -INFINITY;
 #pragma unroll
             for (int a = 0; a < Q; a++) {
-                const float H = (gap && a == 0) ? -INFINITY : acc[a][reg] + hv[a];
+                const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : acc[a][reg] + hv[a];
                 acc[a][reg] = H;
                 mx = fmaxf(mx, H);
             }
@@ -1844,7 +1850,7 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__rest
                 for (int k = 0; k < ks_count; k++) v2 += G[o2 + k * kstride];
             }
             const float xv = x[xoff + (size_t)b * 256];
-            const bool live = valid && !(d.gap_mode && (a == 0 || b == 0));
+            const bool live = valid && !(d.gap_mode && (a == 0 || b == 0)) && a < d.Qc && b < d.Qc;
             out = live ? fmaf(scale, v + v2, 2.f * lambda_j * xv) : 0.f;
             if (live) reg += (double)xv * (double)xv;
         } else {
@@ -1876,7 +1882,7 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
             for (int k = 0; k < ks_count; k++) v += G[o + k * kstride];
             if (mode != 1) {
                 const float xv = x[idx];
-                if (!(d.gap_mode && a == 0)) {
+                if (!(d.gap_mode && a == 0) && a < d.Qc) {
                     // mode 2: reduced objective of the variable-projection fit -- the fields are at their optimum
                     // for the current couplings, their gradient entries are zero by construction
                     out = (mode == 2) ? 0.f : fmaf(scale, v, 2.f * lambda_h * xv);
@@ -2031,6 +2037,7 @@ hipError_t plm_launch_lincomb(float *out, float ca, const float *a, float cb, co
 // =========================================================================================
 __global__ __launch_bounds__(256) void k_canon_to_native(PlmDims d, const float *__restrict__ xc,
                                                         float *__restrict__ xn) {
+    // canonical side: the problem's alphabet (Qc states per site); native side: the instantiated size Q
     const int a = blockIdx.y;
     int I = d.own_lo;
     int64_t rem = blockIdx.x;
@@ -2038,20 +2045,27 @@ __global__ __launch_bounds__(256) void k_canon_to_native(PlmDims d, const float 
     const int J = I + (int)rem;
     const int ii = threadIdx.x >> 4, jj = threadIdx.x & 15;
     const int i = I * 16 + ii, j = J * 16 + jj;
-    const bool valid = i < d.L && j < d.L && i < j;
-    const size_t QQ = (size_t)d.Q * d.Q;
-    const size_t src = valid ? (size_t)d.L * d.Q + (size_t)plm_pair_index(i, j, d.L) * QQ + (size_t)a * d.Q : 0;
+    const bool valid = i < d.L && j < d.L && i < j && a < d.Qc;
+    const size_t QQc = (size_t)d.Qc * d.Qc;
+    const size_t src = valid ? (size_t)d.L * d.Qc + (size_t)plm_pair_index(i, j, d.L) * QQc + (size_t)a * d.Qc : 0;
     const size_t dst = d.nh_pad_l + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
-    for (int b = 0; b < d.Q; b++) xn[dst + (size_t)b * 256] = valid ? xc[src + b] : 0.f;
+    for (int b = 0; b < d.Q; b++) xn[dst + (size_t)b * 256] = (valid && b < d.Qc) ? xc[src + b] : 0.f;
 }
 __global__ __launch_bounds__(256) void k_copy_h(PlmDims d, const float *__restrict__ src, float *__restrict__ dst,
                                                int to_native) {
-    // canonical fields [L][Q] <-> local field part (sites h_site0 .. min(L, 16*own_hi))
-    const int64_t nloc = (int64_t)(min(d.L, d.own_hi * 16) - d.h_site0) * d.Q, off = (int64_t)d.h_site0 * d.Q;
-    const int64_t n = to_native ? d.nh_pad_l : nloc;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        if (to_native) dst[i] = (i < nloc) ? src[off + i] : 0.f;
-        else dst[off + i] = src[i];
+    // canonical fields [L][Qc] <-> local field part [sites h_site0 .. min(L, 16*own_hi)][Q]
+    const int nsites = min(d.L, d.own_hi * 16) - d.h_site0;
+    const int64_t n = to_native ? d.nh_pad_l : (int64_t)nsites * d.Qc;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        if (to_native) {
+            const int64_t il = k / d.Q;
+            const int a = (int)(k % d.Q);
+            dst[k] = (il < nsites && a < d.Qc) ? src[(size_t)(d.h_site0 + il) * d.Qc + a] : 0.f;
+        } else {
+            const int64_t il = k / d.Qc;
+            const int a = (int)(k % d.Qc);
+            dst[(size_t)(d.h_site0 + il) * d.Qc + a] = src[(size_t)il * d.Q + a];
+        }
     }
 }
 __global__ __launch_bounds__(64) void k_native_to_canon(PlmDims d, const float *__restrict__ xn,
@@ -2060,10 +2074,11 @@ __global__ __launch_bounds__(64) void k_native_to_canon(PlmDims d, const float *
     if (j <= i) return;
     const int I = i >> 4, J = j >> 4;
     if (I < d.own_lo || I >= d.own_hi) return;          // not an own pair: left untouched (sharded-state)
-    const int QQ = d.Q * d.Q;
-    const size_t src = d.nh_pad_l + (size_t)(plm_bp_index(I, J, d.nb16) - d.bp_base) * QQ * 256 + (i & 15) * 16 + (j & 15);
-    const size_t dst = (size_t)d.L * d.Q + (size_t)plm_pair_index(i, j, d.L) * QQ;
-    for (int ab = threadIdx.x; ab < QQ; ab += 64) xc[dst + ab] = xn[src + (size_t)ab * 256];
+    const int QQc = d.Qc * d.Qc;
+    const size_t src = d.nh_pad_l + (size_t)(plm_bp_index(I, J, d.nb16) - d.bp_base) * d.Q * d.Q * 256 + (i & 15) * 16 + (j & 15);
+    const size_t dst = (size_t)d.L * d.Qc + (size_t)plm_pair_index(i, j, d.L) * QQc;
+    for (int ab = threadIdx.x; ab < QQc; ab += 64)
+        xc[dst + ab] = xn[src + (size_t)((ab / d.Qc) * d.Q + ab % d.Qc) * 256];
 }
 hipError_t plm_launch_canon_to_native(const PlmDims &d, const float *xc, float *xn, hipStream_t st) {
     hipLaunchKernelGGL(k_copy_h, dim3(64), dim3(256), 0, st, d, xc, xn, 1);
@@ -2146,7 +2161,7 @@ __global__ __launch_bounds__(256) void k_precond_j(PlmDims d, const float *__res
     const size_t dst = d.nh_pad_l + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
     for (int b = 0; b < d.Q; b++) {
         float out = 0.f;
-        if (valid && !(d.gap_mode && (a == 0 || b == 0)))
+        if (valid && !(d.gap_mode && (a == 0 || b == 0)) && a < d.Qc && b < d.Qc)
             out = 1.f / (neff * (f[(size_t)j * d.Q + b] * via + fia * v[(size_t)j * d.Q + b]) + 2.f * lambda_j);
         dinv[dst + (size_t)b * 256] = out;
     }
@@ -2159,7 +2174,7 @@ __global__ __launch_bounds__(256) void k_precond_h(PlmDims d, const float *__res
     float out = 0.f;
     if (idx < (int64_t)(site_end - d.h_site0) * d.Q) {
         const int i = d.h_site0 + (int)(idx / d.Q), a = (int)(idx % d.Q);
-        if (!(d.gap_mode && a == 0)) out = 1.f / (neff * fv[(size_t)d.L * d.Q + (size_t)i * d.Q + a] + 2.f * lambda_h);
+        if (!(d.gap_mode && a == 0) && a < d.Qc) out = 1.f / (neff * fv[(size_t)d.L * d.Q + (size_t)i * d.Q + a] + 2.f * lambda_h);
     }
     dinv[idx] = out;
 }

@@ -357,9 +357,12 @@ def test_gap_mode_fit_and_files(plm, oracle64, tmp_path):
 
 
 # ---------------------------------------------------------------- edge cases
-@pytest.mark.parametrize("N,L,q", [(1, 2, 21), (3, 17, 21), (33, 33, 21), (300, 47, 20), (260, 16, 5), (64, 50, 4)])
+@pytest.mark.parametrize("N,L,q", [(1, 2, 21), (3, 17, 21), (33, 33, 21), (300, 47, 20), (260, 16, 5), (64, 50, 4),
+                                   (200, 20, 2), (150, 33, 3), (220, 40, 7), (180, 35, 13), (90, 18, 19)])
 def test_edge_shapes_eval_and_reweight(plm, oracle64, N, L, q):
-    """single sequence, L below/above the 16- and 32-site tiles, every instantiated alphabet size"""
+    """single sequence, L below/above the 16- and 32-site tiles, every instantiated alphabet size, and alphabets
+    that run as dead-padded instances of the next instantiated one (any `alphabet` string of
+    couplings/protocol.py:139-155 with up to 21 symbols)"""
     rng = np.random.default_rng(N * 1000 + L)
     msa = rng.integers(0, q, size=(N, L)).astype(np.int8)
     msa[:, L // 2] = 0                                   # a column of gaps only
@@ -392,7 +395,8 @@ def test_invalid_inputs_fail_with_error_codes(plm):
     bad = good.copy()
     bad[2, 3] = 21
     for call, code in ((lambda: plm.fit(bad, q=21, max_iter=1), -1),          # state outside 0..q-1
-                       (lambda: plm.fit(good, q=7, max_iter=1), -4),           # alphabet size not instantiated
+                       (lambda: plm.fit(good, q=22, max_iter=1), -4),          # alphabets above 21 symbols
+                       (lambda: plm.fit(good, q=1, max_iter=1), -4),
                        (lambda: plm.fit(good[:, :1], q=21, max_iter=1), -1),   # fewer than 2 sites
                        (lambda: plm.evaluate(good, -np.ones(8, np.float32), 21, 0.01, 1.0,
                                              np.zeros(plm.n_params(6, 21), np.float32)), -1)):   # negative weights
@@ -608,9 +612,9 @@ def test_alignment_accel_drop_ins_match_reference_golden(plm, golden_dir):
     assert mod.frequencies is None
 
 
-@pytest.mark.parametrize("q,L,N", [(20, 70, 300), (5, 45, 260), (4, 33, 100)])
+@pytest.mark.parametrize("q,L,N", [(20, 70, 300), (5, 45, 260), (4, 33, 100), (7, 40, 120), (13, 25, 80)])
 def test_hamiltonians_other_alphabets(plm, oracle64, q, L, N):
-    """energies / single-mutant matrix for the other instantiated alphabets (q = 20: gap-free protein models)."""
+    """energies / single-mutant matrix for the other alphabets (q = 20: gap-free protein models; 7, 13: padded)."""
     rng = np.random.default_rng(q)
     seqs = rng.integers(0, q, size=(N, L)).astype(np.int8)
     hi = rng.normal(size=(L, q)).astype(np.float32)
@@ -643,7 +647,7 @@ def test_meanfield_rejects_bad_input(plm):
     with pytest.raises(PlmError):
         plm.mean_field(msa, 21, pseudo_count=0.0)            # pseudo-count outside (0, 1)
     with pytest.raises(PlmError):
-        plm.mean_field(msa, 7)                               # alphabet size not instantiated
+        plm.mean_field(msa, 22)                              # alphabets above 21 symbols
 
 
 def test_resumed_optimisation_skips_the_known_start_point(plm):
@@ -746,3 +750,60 @@ def test_convention_switches_match_the_oracle(plm, oracle64, conv):
             assert np.abs(res["cn"] - ref["cn"]).max() < 1e-4
     finally:
         oracle64.set_conventions(0)
+
+
+@pytest.mark.parametrize("q,ignore_gaps", [(7, False), (13, False), (9, True), (3, False)])
+def test_fit_arbitrary_alphabet_reaches_the_oracle_optimum(plm, oracle64, q, ignore_gaps):
+    """Any alphabet of up to 21 symbols (couplings/protocol.py:139-155 passes `alphabet` through): the fit runs on the
+    next instantiated size with the surplus states dead, and lands on the oracle's optimum for the real alphabet."""
+    rng = np.random.default_rng(q)
+    N, L = 400, 22
+    msa = rng.integers(0, q, size=(N, L)).astype(np.int8)
+    msa[:, 4] = (msa[:, 15] + 1) % q                                      # a coupled pair
+    msa[rng.random((N, L)) < 0.05] = 0
+    qm = q - 1 if ignore_gaps else q
+    lj = plm.default_lambda_j(L, qm)
+    ref = oracle64.fit(msa, q, lambda_j=lj, max_iter=3000, epsilon=1e-7, ignore_gaps=ignore_gaps, want_fij=True)
+    res = plm.fit(msa, q, lambda_j=lj, max_iter=3000, epsilon=1e-5, ignore_gaps=ignore_gaps)
+    assert res["status"] == 0, res["status_msg"]
+    assert res["hi"].shape == (L, qm) and res["jij"].shape == (L * (L - 1) // 2, qm, qm)
+    np.testing.assert_allclose(res["fi"], ref["fi"], atol=2e-6)
+    np.testing.assert_allclose(res["fij"], ref["fij"], atol=2e-6)
+    assert res["fx"] == pytest.approx(ref["fx"], rel=1e-6)
+    assert np.abs(res["cn"] - ref["cn"]).max() < 1e-4
+    np.testing.assert_allclose(res["jij"], ref["jij"], atol=2e-4)
+    i, j = np.unravel_index(np.argmax(res["cn"]), res["cn"].shape)
+    assert {int(i), int(j)} == {4, 15}
+
+
+def test_meanfield_arbitrary_alphabet(plm):
+    """mean-field DCA with a 7-letter alphabet against the numpy oracle fed with the GPU's frequencies."""
+    from oracle import meanfield_ref
+    rng = np.random.default_rng(8)
+    msa = rng.integers(0, 7, size=(300, 21)).astype(np.int8)
+    msa[:, 3] = msa[:, 17]
+    out = plm.mean_field(msa, 7, theta_id=0.9, pseudo_count=0.4)
+    ref = meanfield_ref.mean_field(out["fi"].astype(np.float64), out["fij"].astype(np.float64), 0.4)
+    np.testing.assert_allclose(out["jij_full"], ref["jij_full"], atol=1e-9 * np.abs(ref["jij_full"]).max())
+    np.testing.assert_allclose(out["di"], ref["di"], atol=1e-9)
+
+
+def test_gap_mode_reweighting_residue_one_behind_a_gap(plm, oracle64):
+    """Regression: the per-byte zero test of the -g reweighting flagged a byte of value 1 directly above a zero byte
+    (borrow of the subtraction trick), i.e. state 1 behind a gap counted as a gap.  Pairs exactly at the threshold
+    whose only difference is such a position expose it."""
+    L, theta = 20, 0.8
+    base = np.full(L, 2, np.int8)
+    rows = []
+    for k in range(0, L - 1):
+        a = base.copy()
+        a[k], a[k + 1] = 0, 1                      # gap followed by state 1
+        a[(k + 5) % L], a[(k + 9) % L], a[(k + 13) % L] = 3, 4, 7
+        b = base.copy()                            # 16 identities with `a` incl. the state-1 position: exactly T = 16
+        b[k + 1] = 1
+        b[(k + 5) % L], b[(k + 9) % L], b[(k + 13) % L] = 5, 6, 8
+        rows += [a, b]
+    msa = np.stack(rows)
+    np.testing.assert_array_equal(plm.reweight(msa, theta, ignore_gaps=True), oracle64.reweight_gaps(msa, theta))
+    with plm.PlmContext(msa, q=Q, theta_id=theta, ignore_gaps=True) as ctx:
+        np.testing.assert_array_equal(ctx.reweight()[1], oracle64.reweight_gaps(msa, theta))
