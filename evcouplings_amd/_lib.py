@@ -77,6 +77,7 @@ SYMBOLS = [
     ("plm_meanfield", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int, _P,
                                 C.POINTER(PlmMfResult)]),
     ("plm_direct_information", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int, _P, _P]),
+    ("plm_alignment_stats", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int, _P]),
     ("plm_ctx_create", C.c_int, [C.POINTER(PlmProblem), C.c_int, _P, C.POINTER(_P)]),
     ("plm_ctx_destroy", None, [_P]),
     ("plm_ctx_set_exchange", C.c_int, [_P, EXCHANGE_CB, _P]),

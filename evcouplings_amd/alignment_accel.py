@@ -8,7 +8,10 @@ the upstream preprocessing that is arithmetic).
     num_cluster_members(matrix, identity_threshold)      alignment.py:1193-1233   O(N^2 L)
     frequencies(matrix, seq_weights, num_symbols)        alignment.py:1079-1106
     pair_frequencies(matrix, seq_weights, num_symbols, fi)  alignment.py:1110-1153  O(N L^2)
-`install()` rebinds them to wrappers around the same kernels the solver uses (`plm_reweight`, `plm_marginals`):
+plus `identities_to_seq(seq, matrix)` (:1157-1190, identity of every sequence to the query) and the
+`np.vectorize` encoder `map_matrix` (:479-495).  `install()` rebinds them to wrappers around the kernels the solver
+uses (`plm_reweight`, `plm_marginals`) and `plm_alignment_stats`; `alignment_filters` is the arithmetic of
+`modify_alignment`'s two coverage filters (align/protocol.py:900-943) on the integer matrix:
 same arguments, same return shapes and dtypes (float64; the arithmetic is float32).  Any non-negative weights are
 accepted (rescaled by a power of two into the library's range); alphabets of up to 21 symbols.  No CPU fallback.
 """
@@ -52,15 +55,78 @@ def pair_frequencies(matrix, seq_weights, num_symbols, fi):
     return dense_pair_frequencies(np.asarray(fi, dtype=np.float64), fij.astype(np.float64))
 
 
+def identities_to_seq(seq, matrix):
+    """Drop-in for alignment.identities_to_seq (alignment.py:1157-1190): number of positions at which every sequence
+    of the mapped matrix equals the mapped `seq`, length-N float64 (the numba twin returns np.zeros((N,)) floats)."""
+    from evcouplings_amd import plm
+    _, _, ident = plm.alignment_stats(np.asarray(matrix).astype(np.int8), 0, query=np.asarray(seq).astype(np.int8))
+    return ident.astype(np.float64)
+
+
+def map_matrix(matrix, map_):
+    """Drop-in for alignment.map_matrix (alignment.py:479-495): the reference maps every element through a Python
+    dict with np.vectorize -- one interpreter call per residue, minutes at N = 100 000.  Same result (an integer array
+    of the same shape; unknown symbols get the defaultdict's default) through a code-point lookup table.  Host-side
+    format conversion, no arithmetic: it runs in numpy, not on the GPU."""
+    m = np.asarray(matrix)
+    if m.dtype.kind == "S":
+        codes = m.view(np.uint8).reshape(m.shape) if m.dtype.itemsize == 1 else None
+    elif m.dtype.kind == "U" and m.dtype.itemsize == 4:
+        codes = np.ascontiguousarray(m).view(np.uint32).reshape(m.shape)
+    else:
+        codes = None
+    if codes is None or m.size == 0:
+        return np.vectorize(map_.__getitem__)(matrix)          # exotic dtypes: exactly what the reference does
+    top = int(codes.max()) + 1
+    if top > 0x110000:
+        return np.vectorize(map_.__getitem__)(matrix)
+    present = np.unique(codes)
+    lut = np.zeros(top, dtype=np.int64)
+    for c in present.tolist():
+        key = chr(c) if m.dtype.kind == "U" else bytes([c])
+        lut[c] = map_[key]                                    # defaultdict: unknown symbols -> its default, as upstream
+    return lut[codes]
+
+
+def alignment_filters(matrix_mapped, gap_state=0, minimum_sequence_coverage=None, minimum_column_coverage=None):
+    """The two coverage filters of modify_alignment (align/protocol.py:900-914, 935-943) on the integer matrix:
+    keep_seqs = sequences whose non-gap fraction is >= minimum_sequence_coverage, and -- computed on the kept
+    sequences -- lc_cols = columns whose gap fraction exceeds 1 - minimum_column_coverage (the reference lower-cases
+    them).  Integers are read as percentages, as upstream.  Either threshold may be None (no filter)."""
+    from evcouplings_amd import plm
+    m = np.ascontiguousarray(matrix_mapped, dtype=np.int8)
+    n, L = m.shape
+    keep = np.ones(n, dtype=bool)
+    if minimum_sequence_coverage is not None:
+        cov = minimum_sequence_coverage / 100 if isinstance(minimum_sequence_coverage, int) else minimum_sequence_coverage
+        seq_gaps, _, _ = plm.alignment_stats(m, gap_state)
+        keep = (1 - seq_gaps / L) >= cov
+    lc_cols = None
+    if minimum_column_coverage is not None:
+        cov = minimum_column_coverage / 100 if isinstance(minimum_column_coverage, int) else minimum_column_coverage
+        kept = m[keep] if not keep.all() else m
+        _, col_gaps, _ = plm.alignment_stats(kept, gap_state)
+        lc_cols = col_gaps / kept.shape[0] > 1 - cov
+    return keep, lc_cols
+
+
+_NAMES = ("num_cluster_members", "frequencies", "pair_frequencies", "identities_to_seq", "map_matrix")
+
+
 def install(alignment_module=None):
+    """Rebind the five functions in evcouplings.align.alignment (or the module given).  With them the arithmetic of
+    the align stage's modify_alignment / describe_frequencies / describe_seq_identities / describe_coverage
+    (align/protocol.py:463-640, 806-1016) -- weights, frequencies, identities to the query, the encoding of the
+    character matrix -- runs through this package; the reference code around it is unchanged."""
     if alignment_module is None:
         import evcouplings.align.alignment as alignment_module
     if alignment_module not in _ORIGINAL:
-        _ORIGINAL[alignment_module] = tuple(getattr(alignment_module, n) for n in
-                                            ("num_cluster_members", "frequencies", "pair_frequencies"))
+        _ORIGINAL[alignment_module] = tuple(getattr(alignment_module, n) for n in _NAMES)
     alignment_module.num_cluster_members = num_cluster_members
     alignment_module.frequencies = frequencies
     alignment_module.pair_frequencies = pair_frequencies
+    alignment_module.identities_to_seq = identities_to_seq
+    alignment_module.map_matrix = map_matrix
     return alignment_module
 
 
@@ -68,5 +134,5 @@ def uninstall(alignment_module=None):
     if alignment_module is None:
         import evcouplings.align.alignment as alignment_module
     if alignment_module in _ORIGINAL:
-        (alignment_module.num_cluster_members, alignment_module.frequencies,
-         alignment_module.pair_frequencies) = _ORIGINAL.pop(alignment_module)
+        for name, fn in zip(_NAMES, _ORIGINAL.pop(alignment_module)):
+            setattr(alignment_module, name, fn)

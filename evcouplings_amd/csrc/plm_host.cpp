@@ -1558,6 +1558,39 @@ int plm_direct_information(const double *jij_full, const double *fi, int32_t n_s
     return done(e == hipSuccess ? PLM_OK : fail(PLM_EDEVICE, "download failed: %s", hipGetErrorString(e)));
 }
 
+int plm_alignment_stats(const int8_t *msa, int32_t n, int32_t L, int32_t gap_state, const int8_t *query,
+                        int32_t *seq_gaps, int32_t *col_gaps, int32_t *ident, int device, void *stream) {
+    if (!msa || n <= 0 || L <= 0) return fail(PLM_EINVAL, "NULL alignment or empty shape");
+    if (ident && !query) return fail(PLM_EINVAL, "identities need a query sequence");
+    if (gap_state < 0 || gap_state > 126) return fail(PLM_EINVAL, "gap state outside 0..126");
+    for (size_t k = 0; k < (size_t)n * L; k++)
+        if (msa[k] < 0) return fail(PLM_EINVAL, "msa[%zu] is negative", k);     // the packed compare needs bytes < 0x80
+    PLM_TRY(check_device(device));
+    hipStream_t st = (hipStream_t)stream;
+    int8_t *dm = nullptr, *dq = nullptr;
+    int32_t *dsg = nullptr, *dcg = nullptr, *did = nullptr;
+    auto done = [&](int code) {
+        void *all[] = {dm, dq, dsg, dcg, did};
+        for (void *b : all)
+            if (b) (void)hipFree(b);
+        return code;
+    };
+    int rc;
+    if ((rc = dalloc(&dm, (size_t)n * L + 16)) || (query && (rc = dalloc(&dq, (size_t)L))) ||
+        (seq_gaps && (rc = dalloc(&dsg, (size_t)n))) || (col_gaps && (rc = dalloc(&dcg, (size_t)L))) ||
+        (ident && (rc = dalloc(&did, (size_t)n))))
+        return done(rc);
+    hipError_t e = hipMemcpyAsync(dm, msa, (size_t)n * L, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && query) e = hipMemcpyAsync(dq, query, (size_t)L, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = plm_launch_align_stats(dm, n, L, gap_state, dq, dsg, dcg, did, st);
+    if (e == hipSuccess && seq_gaps) e = hipMemcpyAsync(seq_gaps, dsg, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && col_gaps) e = hipMemcpyAsync(col_gaps, dcg, sizeof(int32_t) * L, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && ident) e = hipMemcpyAsync(ident, did, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(fail(PLM_EDEVICE, "alignment statistics failed: %s", hipGetErrorString(e)));
+    return done(PLM_OK);
+}
+
 static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,
                     void *iter_user, plm_exchange_cb exchange, void *exchange_user, plm_collective_cb collective,
                     void *collective_user) {

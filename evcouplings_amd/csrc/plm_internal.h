@@ -148,6 +148,9 @@ hipError_t plm_launch_canon_to_native(const PlmDims &d, const float *xc, float *
 hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *xc, hipStream_t st);
 // a_lo = 1: state 0 is left out of the norm (PLM_CONV_FN_NO_GAP), the gauge is still taken over all Q states
 hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, int a_lo, hipStream_t st);
+// alignment statistics (row N3): per-sequence gap counts + identities to a query, per-column gap counts
+hipError_t plm_launch_align_stats(const int8_t *msa, int n, int L, int gap_state, const int8_t *query, int32_t *seq_gaps,
+                                  int32_t *col_gaps, int32_t *ident, hipStream_t st);
 size_t plm_bt_bytes(const PlmDims &d);
 size_t plm_rt_bytes(const PlmDims &d);
 size_t plm_g_bytes(const PlmDims &d);      // [ksplit][nmf][nnfl][256] floats

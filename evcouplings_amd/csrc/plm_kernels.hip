@@ -2187,6 +2187,68 @@ hipError_t plm_launch_precond(const PlmDims &d, const float *fv, float neff, flo
 }
 
 // =========================================================================================
+// Alignment statistics of the align stage (row N3; twins: align/alignment.py:707-747 Alignment.count,
+// :1157-1190 identities_to_seq).  HBM-bound byte work: the matrix is read once per kernel.
+//   k_align_rows: one lane per sequence, 16 bytes of its row per load; gaps and identities to the query (the query
+//                 row sits in LDS) counted with the packed-byte compare of the reweighting kernel
+//   k_align_cols: one lane per column, lanes of a wave read consecutive bytes of a row (coalesced), the sequences are
+//                 split over blockIdx.y and merged with integer atomics (order-independent)
+// =========================================================================================
+__device__ __forceinline__ int eq_bytes(u32 a, u32 b) {          // number of equal bytes (all bytes < 0x80)
+    return 4 - __builtin_popcount(((a ^ b) + 0x7f7f7f7fu) & 0x80808080u);
+}
+__global__ __launch_bounds__(256) void k_align_rows(const int8_t *__restrict__ msa, int n, int L, int gap,
+                                                   const int8_t *__restrict__ query, int32_t *__restrict__ seq_gaps,
+                                                   int32_t *__restrict__ ident) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the query row, padded to 4 bytes with 0x7e
+    const int Lw = (L + 3) / 4;
+    for (int k = threadIdx.x; k < Lw * 4; k += 256) smem[k] = (query && k < L) ? query[k] : 0x7e;
+    __syncthreads();
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int8_t *row = msa + (size_t)s * L;
+    const u32 g4 = (u32)gap * 0x01010101u;
+    int ng = 0, id = 0;
+    const u32 *q32 = (const u32 *)smem;
+    int k = 0;
+    if ((((size_t)row) & 3) == 0) {           // aligned rows: dword loads
+        for (; k + 4 <= L; k += 4) {
+            const u32 v = *(const u32 *)(row + k);
+            ng += eq_bytes(v, g4);
+            id += eq_bytes(v, q32[k >> 2]);
+        }
+    }
+    for (; k < L; k++) {
+        ng += row[k] == gap;
+        id += row[k] == smem[k];
+    }
+    if (seq_gaps) seq_gaps[s] = ng;
+    if (ident) ident[s] = id;
+}
+__global__ __launch_bounds__(256) void k_align_cols(const int8_t *__restrict__ msa, int n, int L, int gap,
+                                                   int32_t *__restrict__ col_gaps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int per = (n + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = min(n, s0 + per);
+    if (c >= L) return;
+    int cnt = 0;
+    for (int s = s0; s < s1; s++) cnt += msa[(size_t)s * L + c] == gap;
+    if (cnt) atomicAdd(&col_gaps[c], cnt);
+}
+hipError_t plm_launch_align_stats(const int8_t *msa, int n, int L, int gap_state, const int8_t *query, int32_t *seq_gaps,
+                                  int32_t *col_gaps, int32_t *ident, hipStream_t st) {
+    if (seq_gaps || ident)
+        hipLaunchKernelGGL(k_align_rows, dim3((n + 255) / 256), dim3(256), (size_t)((L + 3) / 4) * 4, st, msa, n, L,
+                           gap_state, query, seq_gaps, ident);
+    if (col_gaps) {
+        hipError_t e = hipMemsetAsync(col_gaps, 0, sizeof(int32_t) * L, st);
+        if (e != hipSuccess) return e;
+        const int ysplit = std::max(1, std::min(1024, n / 256));
+        hipLaunchKernelGGL(k_align_cols, dim3((L + 255) / 256, ysplit), dim3(256), 0, st, msa, n, L, gap_state, col_gaps);
+    }
+    return hipGetLastError();
+}
+
+// =========================================================================================
 // sharded-state exchange staging.  A "block" is the Q*Q*256 floats of one 16x16-site block pair.
 //   x halo : owner of J' (lower shard) -> owner of I (higher shard), pairs (J', I); receiver layout
 //            xhalo[J' * nblk_own + (I - own_lo)]

@@ -116,6 +116,23 @@ def _canonical(hi, jij, L, q):
     return np.concatenate([hi, jij])
 
 
+def alignment_stats(msa, gap_state=0, query=None, device=0):
+    """Per-sequence gap counts, per-column gap counts and (if `query` is given) identities of every sequence to the
+    query, as int32 arrays (n,), (L,), (n,) -- the raw counts behind Alignment.count(gap, axis=...) and
+    identities_to_seq of evcouplings/align/alignment.py:707-747, 1157-1190."""
+    lib = _lib.load()
+    msa = _msa(msa)
+    n, L = msa.shape
+    seq_gaps, col_gaps = np.zeros(n, np.int32), np.zeros(L, np.int32)
+    ident = None
+    if query is not None:
+        query = np.ascontiguousarray(query, dtype=np.int8).reshape(L)
+        ident = np.zeros(n, np.int32)
+    check(lib.plm_alignment_stats(_ptr(msa), n, L, int(gap_state), _ptr(query), _ptr(seq_gaps), _ptr(col_gaps),
+                                  _ptr(ident), int(device), None))
+    return seq_gaps, col_gaps, ident
+
+
 def hamiltonians(seqs, q, hi, jij, device=0):
     """
     Statistical energies of sequences under a model: n x 3 float64 (H, H_J, H_h) with

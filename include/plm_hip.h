@@ -233,6 +233,17 @@ int plm_meanfield(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t n_
 int plm_direct_information(const double *jij_full, const double *fi, int32_t n_sites, int32_t n_states,
                            int device, void *stream, double *di_out);
 
+/* ---- alignment statistics of the upstream align stage -----------------------------
+ * One pass over an integer-coded alignment (n x n_sites, row-major, states 0..126) for the quantities
+ * evcouplings/align/protocol.py:806-1016 (modify_alignment) filters and reports on:
+ *   seq_gaps[s]   = #{i : msa[s][i] == gap_state}        Alignment.count("-", axis="seq")  (alignment.py:707-747)
+ *   col_gaps[i]   = #{s : msa[s][i] == gap_state}        Alignment.count(gap, axis="pos")
+ *   ident[s]      = #{i : msa[s][i] == query[i]}         identities_to_seq(seq, matrix)    (alignment.py:1157-1190)
+ * Raw integer counts (the reference normalises on the host); any output pointer may be NULL, query may be NULL
+ * when ident is.                                                                                              */
+int plm_alignment_stats(const int8_t *msa, int32_t n_seqs, int32_t n_sites, int32_t gap_state, const int8_t *query,
+                        int32_t *seq_gaps, int32_t *col_gaps, int32_t *ident, int device, void *stream);
+
 /* -- resident-context API (bench / multi-GPU host) ---------------------------------------- */
 /* Uploads the alignment once; everything below runs on data resident in HBM. */
 int plm_ctx_create(const plm_problem_t *problem, int device, void *stream, plm_ctx_t **out);

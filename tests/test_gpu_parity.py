@@ -807,3 +807,43 @@ def test_gap_mode_reweighting_residue_one_behind_a_gap(plm, oracle64):
     np.testing.assert_array_equal(plm.reweight(msa, theta, ignore_gaps=True), oracle64.reweight_gaps(msa, theta))
     with plm.PlmContext(msa, q=Q, theta_id=theta, ignore_gaps=True) as ctx:
         np.testing.assert_array_equal(ctx.reweight()[1], oracle64.reweight_gaps(msa, theta))
+
+
+# ---------------------------------------------------------------- align-stage statistics
+def test_alignment_stats_and_filters_match_reference_golden(plm, golden_dir):
+    """plm_alignment_stats / alignment_accel against what the reference's Alignment.count, identities_to and the
+    filters of modify_alignment produced on the same alignment (tests/golden/align_stats.npz)."""
+    from evcouplings_amd import alignment_accel
+    z = np.load(os.path.join(golden_dir, "align_stats.npz"))
+    m = z["mapped"]
+    n, L = m.shape
+    seq_gaps, col_gaps, ident = plm.alignment_stats(m, 0, query=m[0])
+    np.testing.assert_array_equal(seq_gaps / L, z["seq_gap_frac"])
+    np.testing.assert_array_equal(col_gaps / n, z["col_gap_frac"])
+    np.testing.assert_array_equal(ident, z["ident_counts"].astype(np.int32))
+    np.testing.assert_array_equal(alignment_accel.identities_to_seq(m[0], m), z["ident_counts"])
+    keep, lc = alignment_accel.alignment_filters(m, 0, int(z["min_seq"]), float(z["min_col"]))
+    np.testing.assert_array_equal(keep, z["keep_seqs"])
+    np.testing.assert_array_equal(lc, z["lc_cols"])
+    # frequencies of the kept sequences with the reference's weights = the symbol columns of describe_frequencies
+    fi = alignment_accel.frequencies(m[keep], z["weights"], 21)
+    cols = list(z["freq_columns"])
+    ref = z["freq_values"][:, cols.index("-") - 1:]           # freq_values has no A_i column
+    live = ~np.isnan(ref[:, 0])
+    np.testing.assert_allclose(fi[live], ref[live], atol=2e-6)
+
+
+@pytest.mark.parametrize("n,L", [(1, 1), (3, 5), (257, 33), (1000, 128), (4097, 301)])
+def test_alignment_stats_shapes(plm, n, L):
+    rng = np.random.default_rng(n + L)
+    m = rng.integers(0, 21, size=(n, L)).astype(np.int8)
+    m[rng.random((n, L)) < 0.3] = 0
+    q = m[n // 2]
+    seq_gaps, col_gaps, ident = plm.alignment_stats(m, 0, query=q)
+    np.testing.assert_array_equal(seq_gaps, (m == 0).sum(1))
+    np.testing.assert_array_equal(col_gaps, (m == 0).sum(0))
+    np.testing.assert_array_equal(ident, (m == q[None]).sum(1))
+    g5, c5, none = plm.alignment_stats(m, 5)
+    assert none is None
+    np.testing.assert_array_equal(g5, (m == 5).sum(1))
+    np.testing.assert_array_equal(c5, (m == 5).sum(0))

@@ -248,6 +248,57 @@ def test_alignment_accel_installs_into_the_reference_module(ref, golden_dir, mon
     assert fij.shape == (L, L, 21, 21) and np.allclose(fij[3, 3], np.diag(fi[3]))
 
 
+def test_align_stage_descriptions_through_the_drop_ins(ref, golden_dir, monkeypatch):
+    """the reference's describe_frequencies / describe_seq_identities / describe_coverage and
+    the two filters of modify_alignment (align/protocol.py:463-640, 900-943), run with alignment_accel installed,
+    reproduce the tables the unmodified reference produced (tests/golden/align_stats.npz, make_golden_align.py).
+    No GPU here: plm.reweight / marginals / alignment_stats are numpy stand-ins; map_matrix is the real drop-in."""
+    import evcouplings.align.alignment as ref_ali
+    import evcouplings.align.protocol as ref_prot
+    from evcouplings_amd import alignment_accel, plm
+    from oracle.oracle import Oracle
+    o = Oracle("f64")
+    z = np.load(os.path.join(golden_dir, "align_stats.npz"))
+    monkeypatch.setattr(plm, "reweight", lambda msa, thr, **kw: o.reweight(msa, thr))
+
+    def fake_marginals(msa, w, q, pairs=True):
+        fi, fij = o.marginals(msa, np.asarray(w, dtype=np.float64), q, pairs=pairs)
+        return fi.astype(np.float32), (None if fij is None else fij.astype(np.float32))
+
+    def fake_stats(msa, gap_state=0, query=None, device=0):
+        msa = np.asarray(msa)
+        ident = None if query is None else (msa == np.asarray(query)[None, :]).sum(1).astype(np.int32)
+        return (msa == gap_state).sum(1).astype(np.int32), (msa == gap_state).sum(0).astype(np.int32), ident
+
+    monkeypatch.setattr(plm, "marginals", fake_marginals)
+    monkeypatch.setattr(plm, "alignment_stats", fake_stats)
+    chars = z["chars"].astype(str)
+    alignment_accel.install(ref_ali)
+    try:
+        ali = ref_ali.Alignment(chars, np.array(["s%d" % k for k in range(len(chars))]), alphabet=str(z["alphabet"]))
+        np.testing.assert_array_equal(ref_ali.map_matrix(ali.matrix, ali.alphabet_map), z["mapped"])
+        np.testing.assert_array_equal(ref_ali.map_matrix(z["odd_chars"].astype(str), ali.alphabet_map), z["odd_mapped"])
+        np.testing.assert_allclose(ali.identities_to(ali[0]), z["ident_to_target"], rtol=0, atol=0)
+        keep, lc = alignment_accel.alignment_filters(z["mapped"], 0, int(z["min_seq"]), float(z["min_col"]))
+        np.testing.assert_array_equal(keep, z["keep_seqs"])
+        np.testing.assert_array_equal(lc, z["lc_cols"])
+        kept = ali.select(sequences=keep)
+        kept.set_weights(0.8)
+        np.testing.assert_allclose(kept.weights, z["weights"], rtol=1e-12)
+        freq = ref_prot.describe_frequencies(kept, 10, target_seq_index=0)
+        assert list(freq.columns) == list(z["freq_columns"]) and list(freq["A_i"]) == list(z["freq_target"])
+        np.testing.assert_allclose(freq.drop(columns=["A_i"]).to_numpy(dtype=float), z["freq_values"], atol=2e-6)
+        ids = ref_prot.describe_seq_identities(kept, target_seq_index=0)
+        np.testing.assert_allclose(ids["identity_to_query"].to_numpy(dtype=float), z["identities_table"], atol=1e-15)
+        cov = ref_prot.describe_coverage(kept, "p", 10, [0.5, 0.7, 90])
+        assert list(cov.columns) == list(z["coverage_columns"])
+        np.testing.assert_allclose(cov.drop(columns=["prefix"]).to_numpy(dtype=float), z["coverage_values"],
+                                   atol=2e-6, equal_nan=True)
+    finally:
+        alignment_accel.uninstall(ref_ali)
+    assert ref_ali.map_matrix.__module__.startswith("evcouplings.")      # restored
+
+
 def _oracle_backed_plm(monkeypatch):
     """No GPU in this container: stand the numpy / C oracle in for the library calls the drop-ins make."""
     from evcouplings_amd import plm
