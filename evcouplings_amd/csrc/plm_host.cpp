@@ -191,6 +191,7 @@ struct plm_ctx {
     float *dinv = nullptr;     // H0 diagonal of the preconditioned L-BFGS (n_local floats), built by plm_ctx_optimize
     // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
     float *hj = nullptr, *hpart = nullptr;
+    double *gpart = nullptr;
     double *hg2 = nullptr, *hinv = nullptr;
     bool vp_refresh_next = false;
     int *vp_flag = nullptr;    // device-side convergence flag (kept zero: see vp_stage2)
@@ -321,6 +322,7 @@ int vp_alloc(plm_ctx *c) {
     const size_t nsites = (size_t)std::max(1, (c->d.b16_hi - c->d.b16_lo) * 16);
     PLM_TRY(dalloc((char **)&c->hj, plm_hj_bytes(c->d)));
     PLM_TRY(dalloc((char **)&c->hpart, plm_hpart_bytes(c->d)));
+    PLM_TRY(dalloc((char **)&c->gpart, plm_gpart_bytes(c->d)));
     PLM_TRY(dalloc(&c->hg2, nsites));
     PLM_TRY(dalloc(&c->hinv, nsites * c->d.Q * c->d.Q));
     PLM_TRY(dalloc(&c->vp_flag, (size_t)1));
@@ -360,14 +362,14 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse) {
         const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
         if (full || !(it == 0 && reuse))
             HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 0, full ? 2 : 1, nullptr, nullptr, c->hpart,
-                                     nullptr, c->st));
-        HIP_TRY(plm_launch_hsolve(d, c->hpart, full, c->x, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
+                                     c->gpart, nullptr, c->st));
+        HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
                                   c->vp_flag, c->st));
         c->vp_hess_age = full ? 0 : c->vp_hess_age + 1;
     }
     c->vp_newton_total += newton;
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 1, 1, c->Rt, c->fx_part, c->hpart, nullptr, c->st));
-    HIP_TRY(plm_launch_hsolve(d, c->hpart, 0, c->x, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 1, 1, c->Rt, c->fx_part, c->hpart, c->gpart, nullptr, c->st));
+    HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
                               c->vp_flag, c->st));
     return PLM_OK;
 }
@@ -581,7 +583,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     hipSetDevice(c->device);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->hg2, c->hinv, c->vp_flag};
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->vp_flag};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);

@@ -1163,14 +1163,15 @@ struct HpassArgs {
     const float *h;       // native vector (fields first)
     _Float16 *Rt;
     double *fx_part;
-    float *hpart;         // [workgroup][16 sites][NV]  (NV = Q, or PLM_HSTATS(Q) with Hessian sums)
-    float rscale;
+    float *hpart;         // [workgroup][16 sites][NH]  Hessian sums, NH = Q (Q + 1) / 2 (STATS == 2 only)
+    double *gpart;        // [workgroup][16 sites][Q]   gradient sums, f64: their f32 accumulation was the noise floor
+    float rscale;         //                            of the field solver (|g_h| ~ 1e-2 at N = 50 000)
     const int *skip;      // device flag (may be NULL): non-zero = the field solver has converged, do nothing
 };
 template <int Q, bool WRITE_RT, int STATS>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NV = (STATS == 2) ? PLM_HSTATS(Q) : Q;
+    constexpr int NH = (STATS == 2) ? Q * (Q + 1) / 2 : 0;
     if (A.skip && *A.skip) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
@@ -1185,12 +1186,16 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
 #pragma unroll
     for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
     float fxl = 0.f;
-    // statistics area [wave][site][NV]: the 4 lanes of a site are summed in registers (sum_over_g), one of them
-    // adds the result with a fire-and-forget LDS float add (the two halves of the tile accumulate); waves never
-    // share an address and the areas are summed in wave order at the end: bit-reproducible
-    float *ls = (float *)smem + ((size_t)wave * 16 + r) * NV;
+    // statistics areas, one per wave: gradient sums [site][Q] in f64, then Hessian sums [site][NH] in f32.  Lanes add
+    // with fire-and-forget LDS adds (the 4 lanes of a site collide on one address inside one instruction: resolved in
+    // lane order; the two halves of the tile accumulate); waves never share an address and the areas are summed in
+    // wave order at the end: bit-reproducible
+    double *lg = (double *)smem + ((size_t)wave * 16 + r) * Q;
+    float *lh0 = (float *)((double *)smem + (size_t)8 * 16 * Q);
+    float *ls = lh0 + ((size_t)wave * 16 + r) * NH;
     if (STATS) {
-        for (int k = lane; k < 16 * NV; k += 64) ((float *)smem)[(size_t)wave * 16 * NV + k] = 0.f;
+        for (int k = lane; k < 16 * Q; k += 64) ((double *)smem)[(size_t)wave * 16 * Q + k] = 0.0;
+        for (int k = lane; k < 16 * NH; k += 64) lh0[(size_t)wave * 16 * NH + k] = 0.f;
     }
     // wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset: no 64-bit per-lane addresses
     const char *hj_u = (const char *)(A.hj + ((size_t)blockIdx.x * 8 + wave) * 2 * Q * 64);
@@ -1239,7 +1244,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             asm volatile("" : "+v"(xk[reg]));   // no sharing of compare masks between the sections (SGPR spills)
         }
         if constexpr (STATS != 0) {
-            int idx = Q;
+            int idx = 0;
 #pragma unroll
             for (int a = 0; a < Q; a++) {
                 float t[4], ga = 0.f;
@@ -1248,9 +1253,9 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                     t[k] = wk[k] * acc[a][k];
                     ga += t[k] - ((xk[k] == a) ? wk[k] : 0.f);
                 }
-                // 21 gradient sums: the 4 lanes of a site add straight into LDS (one instruction, resolved in lane
-                // order); the 231 Hessian sums below are reduced in registers first
-                __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[a]), ga, 0, 0, false);
+                // Q gradient sums: the 4 lanes of a site add straight into LDS (f64, one ds_add_f64, resolved in
+                // lane order); the Hessian sums below are reduced in registers first
+                unsafeAtomicAdd(&lg[a], (double)ga);
                 if constexpr (STATS == 2) {
                     // Hessian sums: the diagonal sum_s w P_a^2 from every tile (rare states live on a handful of
                     // sequences: sampling them away stalls the Newton iteration), the off-diagonal sums from every
@@ -1260,10 +1265,10 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                         float v = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[a][k], v);
-                        __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[Q + a * Q - a * (a - 1) / 2]), v, 0, 0, false);
+                        __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[a * Q - a * (a - 1) / 2]), v, 0, 0, false);
                     }
                     if ((stile % PLM_HESS_SAMPLE) != 0) continue;
-                    idx = Q + a * Q - a * (a - 1) / 2 + 1;
+                    idx = a * Q - a * (a - 1) / 2 + 1;
 #pragma unroll
                     for (int b = a + 1; b < Q; b++) {
                         float v = 0.f;
@@ -1313,12 +1318,21 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     }
     __syncthreads();
     if constexpr (STATS != 0) {
-        float *out = A.hpart + (size_t)blockIdx.x * 16 * NV;
-        for (int k = tid; k < 16 * NV; k += 512) {
-            float v = 0.f;
+        double *gout = A.gpart + (size_t)blockIdx.x * 16 * Q;
+        for (int k = tid; k < 16 * Q; k += 512) {
+            double v = 0;
 #pragma unroll
-            for (int wv = 0; wv < 8; wv++) v += ((const float *)smem)[(size_t)wv * 16 * NV + k];
-            out[k] = v;
+            for (int wv = 0; wv < 8; wv++) v += ((const double *)smem)[(size_t)wv * 16 * Q + k];
+            gout[k] = v;
+        }
+        if constexpr (STATS == 2) {
+            float *out = A.hpart + (size_t)blockIdx.x * 16 * NH;
+            for (int k = tid; k < 16 * NH; k += 512) {
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 8; wv++) v += lh0[(size_t)wv * 16 * NH + k];
+                out[k] = v;
+            }
         }
     }
     if constexpr (WRITE_RT) {
@@ -1328,14 +1342,14 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     }
 }
 hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const float *x,
-                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, const int *skip,
-                            hipStream_t st) {
+                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, double *gpart,
+                            const int *skip, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
-    const HpassArgs A{(const float4 *)hj, msa_rm, w, x, (_Float16 *)Rt, fx_part, hpart, ldexpf(1.f, PLM_R_EXP), skip};
+    const HpassArgs A{(const float4 *)hj, msa_rm, w, x, (_Float16 *)Rt, fx_part, hpart, gpart, ldexpf(1.f, PLM_R_EXP), skip};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
-        const size_t lds = (size_t)8 * 16 * ((SS) == 2 ? PLM_HSTATS(QQ) : (QQ)) * sizeof(float);       \
+        const size_t lds = (size_t)8 * 16 * ((QQ) * sizeof(double) + ((SS) == 2 ? (QQ) * ((QQ) + 1) / 2 : 0) * sizeof(float)); \
         static bool attr_done_dev[PLM_MAX_DEVICES] = {false};                                          \
         bool &attr_done = attr_done_dev[plm_current_device()];                                         \
         if (!attr_done && lds > 65536) {                                                               \
@@ -1366,8 +1380,9 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
     return hipGetLastError();
 }
 size_t plm_hpart_bytes(const PlmDims &d) {
-    return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 16 * PLM_HSTATS(d.Q) * sizeof(float);
+    return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 16 * (d.Q * (d.Q + 1) / 2) * sizeof(float);
 }
+size_t plm_gpart_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 16 * d.Q * sizeof(double); }
 
 // Newton step on the fields of one site (one wave per site).  The workgroup partials of the last pass are summed
 // in f64 (fixed order).  full = 1: the pass carried Hessian sums -- H = diag(rowsum M) - M + 2 lambda_h I is
@@ -1375,7 +1390,8 @@ size_t plm_hpart_bytes(const PlmDims &d) {
 // (simplified Newton: the Hessian moves slowly from one trial point to the next).  update = 0: only the squared
 // gradient norm of the subproblem is recorded (verification of the point the residuals were computed at).
 template <int Q>
-__global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restrict__ hpart, int full,
+__global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restrict__ hpart,
+                                              const double *__restrict__ gpart, int full,
                                               float *__restrict__ x, double lambda_h, int update,
                                               double *__restrict__ hinv, double *__restrict__ g2_site,
                                               double tol_site2, const int *__restrict__ skip) {
@@ -1391,38 +1407,36 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
         return;
     }
     const int b16l = il >> 4, r = il & 15;
-    const int NV = full ? NVF : Q;
-    if (full) {
-        const int nsamp = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
-        for (int k = t; k < NV; k += 64) {
-            // gradient sums and the Hessian diagonal come from every tile, the off-diagonal sums from the sampled ones
-            bool exact = k < Q;
-            if (!exact) {
-                int a = 0, rem = k - Q;
-                while (rem >= Q - a) { rem -= Q - a; a++; }
-                exact = rem == 0;
-            }
-            double v = 0;
-            const int step = exact ? 1 : PLM_HESS_SAMPLE;
-            for (int tt = 0; tt < d.nstiles; tt += step) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NV + k];
-            st[k] = exact ? v : v * ((double)d.nstiles / nsamp);
-        }
-    } else {
-        // gradient sums only (the common call): lane = sequence tile (mod 64), then the 64 lane sums per state are
-        // added in lane order -- 64 loads in flight per state instead of a chain of nstiles dependent ones
+    constexpr int NH = Q * (Q + 1) / 2;
+    {
+        // gradient sums: lane = sequence tile (mod 64), then the 64 lane sums per state are added in a fixed butterfly
+        // -- 64 loads in flight per state instead of a chain of nstiles dependent ones
         double part[Q];
 #pragma unroll
         for (int k = 0; k < Q; k++) part[k] = 0;
         for (int tt = t; tt < d.nstiles; tt += 64) {
-            const float *src = hpart + (((size_t)b16l * d.nstiles + tt) * 16 + r) * Q;
+            const double *src = gpart + (((size_t)b16l * d.nstiles + tt) * 16 + r) * Q;
 #pragma unroll
-            for (int k = 0; k < Q; k++) part[k] += (double)src[k];
+            for (int k = 0; k < Q; k++) part[k] += src[k];
         }
 #pragma unroll
         for (int k = 0; k < Q; k++) {
             double v = part[k];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // butterfly: same value in every lane
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // same value in every lane
             if (t == 0) st[k] = v;
+        }
+    }
+    if (full) {
+        const int nsamp = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
+        for (int k = t; k < NH; k += 64) {
+            // the Hessian diagonal comes from every tile, the off-diagonal sums from the sampled ones
+            int a = 0, rem = k;
+            while (rem >= Q - a) { rem -= Q - a; a++; }
+            const bool exact = rem == 0;
+            double v = 0;
+            const int step = exact ? 1 : PLM_HESS_SAMPLE;
+            for (int tt = 0; tt < d.nstiles; tt += step) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NH + k];
+            st[Q + k] = exact ? v : v * ((double)d.nstiles / nsamp);
         }
     }
     __syncthreads();
@@ -1513,8 +1527,9 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
         g2_out[2] = done ? 1.0 : 0.0;     // the host reads the verdict with the scalars (sharded: summed over ranks)
     }
 }
-hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, int full, float *x, double lambda_h, int update,
-                             double *hinv, double *g2_site, double *g2_out, double tol2, int *flag, hipStream_t st) {
+hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x,
+                             double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
+                             int *flag, hipStream_t st) {
     const int nsites = (d.b16_hi - d.b16_lo) * 16;
     if (nsites <= 0) {
         hipError_t e = hipMemsetAsync(g2_out, 0, sizeof(double), st);
@@ -1527,10 +1542,10 @@ hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, int full, flo
     const int live = std::max(1, std::min(d.L, d.own_hi * 16) - d.h_site0);
     const double tol_site2 = 4.0 * tol2 / live;
     switch (d.Q) {
-    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
     default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out, tol_site2, flag);

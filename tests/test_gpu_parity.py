@@ -596,7 +596,7 @@ def test_alignment_accel_drop_ins_match_reference_golden(plm, golden_dir):
     import types
     from evcouplings_amd import alignment_accel
     mod = types.ModuleType("fake_alignment")
-    mod.num_cluster_members = mod.frequencies = mod.pair_frequencies = None
+    mod.num_cluster_members = mod.frequencies = mod.pair_frequencies = mod.identities_to_seq = mod.map_matrix = None
     alignment_accel.install(mod)
     for name, c in _golden_cases(golden_dir).items():
         matrix = c["msa"].astype(np.int64)                       # the reference passes its mapped int matrix
