@@ -9,6 +9,9 @@
 //                fitted model (row N2); k_fwd_split is a measured alternative tiling (PLM_FWD_SPLIT)
 //   k_bwd        one-hot(MSA)^T x residuals on MFMA -> asymmetric gradient slab
 //   k_assemble   slab + slab^T + L2 term -> gradient, regulariser partial sums
+//   k_hpass / k_hsolve   variable-projection fit: k_fwd only stores the coupling potentials, the fields are solved
+//                per site by Newton on them (gradient / Hessian sums, residuals), DESIGN.md 2c, 4.8
+//   k_align_rows / k_align_cols   gap counts and identities of the align stage (row N3)
 // plus small streaming kernels for L-BFGS (dots / linear combinations) and scoring.  Mean-field DCA
 // (covariance inverse, fields, direct information) lives in plm_meanfield.hip.
 // Compile-time experiment switches (all off / neutral in the product build; DESIGN.md 4.3 has the measurements):
@@ -1257,20 +1260,14 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 // lane order); the Hessian sums below are reduced in registers first
                 unsafeAtomicAdd(&lg[a], (double)ga);
                 if constexpr (STATS == 2) {
-                    // Hessian sums: the diagonal sum_s w P_a^2 from every tile (rare states live on a handful of
-                    // sequences: sampling them away stalls the Newton iteration), the off-diagonal sums from every
-                    // PLM_HESS_SAMPLE-th sequence tile only (scaled up by k_hsolve) -- a few per cent of sampling
-                    // error there costs nothing measurable
-                    {
-                        float v = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[a][k], v);
-                        __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[a * Q - a * (a - 1) / 2]), v, 0, 0, false);
-                    }
+                    // Hessian sums M_ab = sum_s w P_a P_b from every PLM_HESS_SAMPLE-th sequence tile only (scaled up
+                    // by k_hsolve): the Newton iteration tolerates a few per cent of sampling error in H, the
+                    // gradient sums above stay exact.  (Taking the diagonal M_aa from every tile buys nothing:
+                    // H_aa = sum_b M_ab - M_aa + 2 lambda_h, it cancels.)
                     if ((stile % PLM_HESS_SAMPLE) != 0) continue;
-                    idx = a * Q - a * (a - 1) / 2 + 1;
+                    idx = a * Q - a * (a - 1) / 2;
 #pragma unroll
-                    for (int b = a + 1; b < Q; b++) {
+                    for (int b = a; b < Q; b++) {
                         float v = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[b][k], v);
@@ -1428,15 +1425,11 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     }
     if (full) {
         const int nsamp = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
-        for (int k = t; k < NH; k += 64) {
-            // the Hessian diagonal comes from every tile, the off-diagonal sums from the sampled ones
-            int a = 0, rem = k;
-            while (rem >= Q - a) { rem -= Q - a; a++; }
-            const bool exact = rem == 0;
+        for (int k = t; k < NH; k += 64) {      // Hessian sums exist for the sampled tiles only
             double v = 0;
-            const int step = exact ? 1 : PLM_HESS_SAMPLE;
-            for (int tt = 0; tt < d.nstiles; tt += step) v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NH + k];
-            st[Q + k] = exact ? v : v * ((double)d.nstiles / nsamp);
+            for (int tt = 0; tt < d.nstiles; tt += PLM_HESS_SAMPLE)
+                v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NH + k];
+            st[Q + k] = v * ((double)d.nstiles / nsamp);
         }
     }
     __syncthreads();
