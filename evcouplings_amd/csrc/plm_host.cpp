@@ -358,6 +358,9 @@ int vp_stage1(plm_ctx *c) {
 int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse) {
     const PlmDims &d = c->d;
     HIP_TRY(hipMemsetAsync(c->vp_flag, 0, sizeof(int), c->st));
+    // slots 6, 7 (pass counter and verdict of k_vp_check) lie inside the all-reduced scalar range: a counter that is
+    // never reset is multiplied by the shard count at every all-reduce and overflows after a few hundred of them
+    HIP_TRY(hipMemsetAsync(c->scal + 6, 0, 2 * sizeof(double), c->st));
     for (int it = 0; it < newton; it++) {
         const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
         if (full || !(it == 0 && reuse))
