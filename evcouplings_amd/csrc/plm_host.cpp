@@ -192,7 +192,7 @@ struct plm_ctx {
     // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
     float *hj = nullptr, *hpart = nullptr;
     double *gpart = nullptr;
-    double *hg2 = nullptr, *hinv = nullptr;
+    double *hg2 = nullptr, *hinv = nullptr, *h64 = nullptr;   // h64: the field solver's f64 copy of the fields
     bool vp_refresh_next = false;
     int *vp_flag = nullptr;    // device-side convergence flag (kept zero: see vp_stage2)
     int vp_newton_total = 0;   // Newton steps on the fields taken by the current optimisation
@@ -325,6 +325,7 @@ int vp_alloc(plm_ctx *c) {
     PLM_TRY(dalloc((char **)&c->gpart, plm_gpart_bytes(c->d)));
     PLM_TRY(dalloc(&c->hg2, nsites));
     PLM_TRY(dalloc(&c->hinv, nsites * c->d.Q * c->d.Q));
+    PLM_TRY(dalloc(&c->h64, nsites * c->d.Q));
     PLM_TRY(dalloc(&c->vp_flag, (size_t)1));
     c->vp_hess_age = -1;
     return PLM_OK;
@@ -343,6 +344,7 @@ int vp_stage1(plm_ctx *c) {
         HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
     }
     HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
+    HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
     return PLM_OK;
 }
 // stage 2: `newton` Newton steps on the fields from their current values, then the residual pass at the result
@@ -364,15 +366,15 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse) {
     for (int it = 0; it < newton; it++) {
         const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
         if (full || !(it == 0 && reuse))
-            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 0, full ? 2 : 1, nullptr, nullptr, c->hpart,
+            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, nullptr, nullptr, c->hpart,
                                      c->gpart, nullptr, c->st));
-        HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
+        HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
                                   c->vp_flag, c->st));
         c->vp_hess_age = full ? 0 : c->vp_hess_age + 1;
     }
     c->vp_newton_total += newton;
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->x, 1, 1, c->Rt, c->fx_part, c->hpart, c->gpart, nullptr, c->st));
-    HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->Rt, c->fx_part, c->hpart, c->gpart, nullptr, c->st));
+    HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
                               c->vp_flag, c->st));
     return PLM_OK;
 }
@@ -586,7 +588,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     hipSetDevice(c->device);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->vp_flag};
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->vp_flag};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);
@@ -994,12 +996,18 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     c->vp_newton_total = 0;
     int vp_newton = 2;                       // Newton steps per evaluation (warm start: the L-BFGS extrapolation)
     double gh2 = 0;                          // |grad_h|^2 left by the field solver at the current point
-    // field-solver tolerance: a fraction of what the stop rule allows the whole gradient
-    // ... and never below the f32 floor of the field gradients (measured 2e-9 ... 6e-9 N_eff per entry)
+    // field-solver tolerance: a fraction of what the stop rule allows the whole gradient, and never below what the
+    // solver can reach.  The fields themselves are iterated in f64 (k_hsolve); what is left is the random f32
+    // rounding of the stored potentials and of the softmax, ~1e-7 per (sequence, site) term, i.e.
+    // ~sqrt(N_eff) per entry (measured with scripts/vp_floor_probe.py: 3e-8 ... 3e-7 sqrt(N_eff L q) in norm).  Below
+    // it an evaluation only burns rounds until the stall test of ctx_eval_vp ends it.
     // (A tolerance relative to the current gradient of the couplings -- inexact field solves far from the optimum --
     // was measured: 0.3 % of |g| costs 15 % more iterations at the headline and stalls config 2 at |g|/|x| = 0.1.)
+    double vp_floor = 2e-7;
+    if (const char *e = getenv("PLM_VP_FLOOR")) vp_floor = atof(e);   // probes only
     auto vp_tol2 = [&](double xnorm2) {
-        const double t = std::max(0.1 * eps * std::max(1.0, std::sqrt(xnorm2)), 4e-9 * c->n_eff * std::sqrt((double)d.L * d.Q));
+        const double t = std::max(0.1 * eps * std::max(1.0, std::sqrt(xnorm2)),
+                                  vp_floor * std::sqrt(c->n_eff * (double)d.L * d.Q));
         return t * t;
     };
     // objective and gradient at the start point -- unless this context still holds them (a resumed fit)

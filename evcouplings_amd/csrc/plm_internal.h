@@ -109,14 +109,15 @@ hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, cons
 // one pass over HJ with the fields of x: per-workgroup per-site sums for the field solver (stats 1: gradient sums
 // into gpart (f64), 2: also Hessian sums -- exact diagonal, sampled off-diagonal -- into hpart (f32)) and, with write_rt, the residual fragments (Rt) and -log P partials
 // (fx_part) of the solver's forward epilogue.  skip (device int, may be NULL): non-zero = do nothing.
-hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const float *x,
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const double *h64,
                             int write_rt, int stats, void *Rt, double *fx_part, float *hpart, double *gpart,
                             const int *skip, hipStream_t st);
 // Per-site gradient norms of the last pass (their sum -> g2_out[0]); update = 1: sites above their share of tol2 take a
 // Newton step on the field part of x (full = that pass carried Hessian sums: inverse recomputed and cached in hinv
 // [sites][Q][Q]; else the cached inverse).  *flag (device, required) is raised when no site is above its share and
 // makes later launches return at once; tol2 = 0 and a zeroed flag give the plain "step everywhere" behaviour.
-hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x,
+hipError_t plm_launch_h64_init(const PlmDims &d, const float *x, double *h64, hipStream_t st);
+hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
                              int *flag, hipStream_t st);
 size_t plm_hj_bytes(const PlmDims &d);

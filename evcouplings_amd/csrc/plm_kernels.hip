@@ -1163,7 +1163,7 @@ struct HpassArgs {
     const float4 *hj;
     const int8_t *msa_rm;
     const float *w;
-    const float *h;       // native vector (fields first)
+    const double *h;      // fields of the local sites in f64 (the solver's copy: see k_hsolve)
     _Float16 *Rt;
     double *fx_part;
     float *hpart;         // [workgroup][16 sites][NH]  Hessian sums, NH = Q (Q + 1) / 2 (STATS == 2 only)
@@ -1185,9 +1185,16 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     const int gap = d.gap_mode;
     const int i = b16 * 16 + r;
     const bool site_ok = i < d.L;
-    float hv[Q];
+    // the fields as hi + lo f32 pairs of their f64 values.  A field rounded to f32 shifts H of EVERY sequence by the
+    // same ~1e-7, a systematic error of the gradient sums that put a floor of ~1e-2 under |g_h| at N = 50 000; with
+    // the low part added separately the rounding of (HJ + lo) + hi differs from sequence to sequence and averages out
+    float hv[Q], hl[Q];
 #pragma unroll
-    for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
+    for (int a = 0; a < Q; a++) {
+        const double h64 = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.0;
+        hv[a] = (float)h64;
+        hl[a] = (float)(h64 - (double)hv[a]);
+    }
     float fxl = 0.f;
     // statistics areas, one per wave: gradient sums [site][Q] in f64, then Hessian sums [site][NH] in f32.  Lanes add
     // with fire-and-forget LDS adds (the 4 lanes of a site collide on one address inside one instruction: resolved in
@@ -1225,7 +1232,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             float mx = -INFINITY;
 #pragma unroll
             for (int a = 0; a < Q; a++) {
-                const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : acc[a][reg] + hv[a];
+                const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : (acc[a][reg] + hl[a]) + hv[a];
                 acc[a][reg] = H;
                 mx = fmaxf(mx, H);
             }
@@ -1338,12 +1345,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
         if (tid == 0) A.fx_part[blockIdx.x] = tot;
     }
 }
-hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const float *x,
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const double *h64,
                             int write_rt, int stats, void *Rt, double *fx_part, float *hpart, double *gpart,
                             const int *skip, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
-    const HpassArgs A{(const float4 *)hj, msa_rm, w, x, (_Float16 *)Rt, fx_part, hpart, gpart, ldexpf(1.f, PLM_R_EXP), skip};
+    const HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (_Float16 *)Rt, fx_part, hpart, gpart, ldexpf(1.f, PLM_R_EXP), skip};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
         const size_t lds = (size_t)8 * 16 * ((QQ) * sizeof(double) + ((SS) == 2 ? (QQ) * ((QQ) + 1) / 2 : 0) * sizeof(float)); \
@@ -1389,7 +1396,8 @@ size_t plm_gpart_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi 
 template <int Q>
 __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restrict__ hpart,
                                               const double *__restrict__ gpart, int full,
-                                              float *__restrict__ x, double lambda_h, int update,
+                                              float *__restrict__ x, double *__restrict__ h64,
+                                              double lambda_h, int update,
                                               double *__restrict__ hinv, double *__restrict__ g2_site,
                                               double tol_site2, const int *__restrict__ skip) {
     constexpr int NVF = PLM_HSTATS(Q);
@@ -1434,7 +1442,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     }
     __syncthreads();
     const int a0 = d.gap_mode;                      // gap mode: state 0 is not a model state
-    if (t < Q) gr[t] = (t < a0) ? 0.0 : st[t] + 2.0 * lambda_h * (double)x[(size_t)il * Q + t];
+    if (t < Q) gr[t] = (t < a0) ? 0.0 : st[t] + 2.0 * lambda_h * h64[(size_t)il * Q + t];
     __syncthreads();
     double *inv = hinv + (size_t)il * Q * Q;
     if (full) {
@@ -1491,7 +1499,23 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     double mxs = fabs(dh);
     for (int o = 32; o > 0; o >>= 1) mxs = fmax(mxs, __shfl_xor(mxs, o, 64));
     const double cap = (mxs > PLM_NEWTON_CAP) ? PLM_NEWTON_CAP / mxs : 1.0;
-    if (t < Q && !(mxs != mxs)) x[(size_t)il * Q + t] = (float)((double)x[(size_t)il * Q + t] - cap * dh);
+    if (t < Q && !(mxs != mxs)) {
+        // the solver iterates on an f64 copy of the fields; the parameter vector gets the rounded value
+        const double hn = h64[(size_t)il * Q + t] - cap * dh;
+        h64[(size_t)il * Q + t] = hn;
+        x[(size_t)il * Q + t] = (float)hn;
+    }
+}
+// start of an evaluation: the solver's f64 fields <- the trial point's f32 fields
+__global__ __launch_bounds__(256) void k_h64_init(const float *__restrict__ x, double *__restrict__ h64, int n) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) h64[k] = (double)x[k];
+}
+hipError_t plm_launch_h64_init(const PlmDims &d, const float *x, double *h64, hipStream_t st) {
+    const int n = (std::min(d.L, d.own_hi * 16) - d.h_site0) * d.Q;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_h64_init, dim3((n + 255) / 256), dim3(256), 0, st, x, h64, n);
+    return hipGetLastError();
 }
 // g2 = sum of the per-site squared gradient norms of the pass just taken; the device-side convergence flag of the
 // field solver is raised when EVERY site is within its share of the tolerance (then no site was moved by the
@@ -1520,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
         g2_out[2] = done ? 1.0 : 0.0;     // the host reads the verdict with the scalars (sharded: summed over ranks)
     }
 }
-hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x,
+hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
                              int *flag, hipStream_t st) {
     const int nsites = (d.b16_hi - d.b16_lo) * 16;
@@ -1535,10 +1559,10 @@ hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double 
     const int live = std::max(1, std::min(d.L, d.own_hi * 16) - d.h_site0);
     const double tol_site2 = 4.0 * tol2 / live;
     switch (d.Q) {
-    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
     default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out, tol_site2, flag);

@@ -421,7 +421,7 @@ def test_field_objective_scaling_matches_reference_independent_model(plm, golden
 
 
 # ---------------------------------------------------------------- sharded-state multi-GPU mode on one GPU
-@pytest.mark.parametrize("L,n_shards", [(40, 2), (40, 3), (40, 4), (100, 2), (100, 3), (100, 4)])
+@pytest.mark.parametrize("L,n_shards", [(40, 2), (40, 3), (40, 4), (100, 2), (100, 3), (100, 4), (300, 8), (500, 8)])
 def test_sharded_state_evaluation_matches_single_gpu(plm, oracle64, L, n_shards):
     """every shard in its own thread on the same GPU, collectives through host memory (dist.ThreadedShards):
     objective and gradient must equal the single-GPU evaluation (L=40 with 4 shards leaves one shard empty)"""
@@ -468,6 +468,24 @@ def test_sharded_state_fit_matches_single_gpu(plm, n_shards):
     ref = plm.fit(msa, Q, max_iter=3000, epsilon=2e-6)
     outs = ThreadedShards(n_shards).fit(msa, q=Q, max_iter=3000, epsilon=2e-6)
     np.testing.assert_allclose(outs[0]["cn"], ref["cn"], atol=1e-5)
+
+
+@pytest.mark.parametrize("L", [300, 500])
+def test_eight_shard_fit_matches_single_gpu(plm, L):
+    """the 8-rank layout of one MI355X node (BASELINE configs 4/5 ask for it) at the headline widths, every shard in
+    its own thread on this GPU: same fit as the unsharded context (variable projection on both sides)"""
+    from evcouplings_amd.dist import ThreadedShards, shard_blocks
+    parts = shard_blocks(L, 8)
+    assert len(parts) == 8 and all(hi > lo for lo, hi in parts)              # no idle rank at these widths
+    assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+    msa, _ = synthetic_msa(384, L, seed=L)
+    ref = plm.fit(msa, Q, max_iter=12, epsilon=1e-12, want_fij=False)
+    outs = ThreadedShards(8).fit(msa, q=Q, max_iter=12, epsilon=1e-12, want_fij=False)
+    for o in outs:
+        assert o["iters"] == ref["iters"] == 12
+        np.testing.assert_array_equal(o["cn"], outs[0]["cn"])
+        np.testing.assert_allclose(o["fx"], ref["fx"], rtol=2e-6)
+        np.testing.assert_allclose(o["cn"], ref["cn"], atol=3e-4)
 
 
 def test_two_process_fit_over_gloo(plm, tmp_path):
