@@ -115,13 +115,17 @@ def main():
     if world > 1:
         # sharded-state mode: parameters, gradient and L-BFGS state split by owning site block; per
         # evaluation two all-to-alls of neighbour blocks + scalar all-reduces over RCCL
-        from evcouplings_amd.dist import make_torch_collective, make_host_staged_collective
+        from evcouplings_amd.dist import (make_torch_collective, make_host_staged_collective, native_rccl_requested,
+                                          share_rccl_id)
         x0 = ctx1.get_x()
         ctx1.close()
         ctx = plm.PlmContext(msa, q=q, lambda_h=0.01, lambda_j=lam_j, device=local_rank, n_shards=world,
                              shard=rank, max_iter=args.warmup, epsilon=1e-12, sharded_state=True)
-        ctx.set_collective(make_torch_collective() if backend == "nccl" else
-                           make_host_staged_collective(device=local_rank))
+        if native_rccl_requested():
+            ctx.attach_rccl(share_rccl_id())       # collectives issued by the library on its own stream
+        else:
+            ctx.set_collective(make_torch_collective() if backend == "nccl" else
+                               make_host_staged_collective(device=local_rank))
         ctx.set_weights(w)
         ctx.set_x(x0)
     else:
@@ -173,7 +177,9 @@ def main():
                                % (L, q, N, lam_j),
                    "n_eff": n_eff,
                    "parallelism": "single GPU" if world == 1 else "sites + state sharded x%d (%s)" % (
-                       world, "RCCL all-to-all" if backend == "nccl" else "gloo, host-staged: flow test only"),
+                       world, ("RCCL all-to-all, issued by the library" if os.environ.get("PLM_NATIVE_RCCL", "0") not in ("", "0")
+                               else "RCCL all-to-all via torch.distributed") if backend == "nccl"
+                       else "gloo, host-staged: flow test only"),
                    "evals_per_iteration": res["n_evals"] / max(1, res["iters"])},
     }
 

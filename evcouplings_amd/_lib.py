@@ -65,6 +65,11 @@ SYMBOLS = [
                           EXCHANGE_CB, _P]),
     ("plm_fit_sharded", C.c_int, [C.POINTER(PlmProblem), C.POINTER(PlmResult), C.c_int, _P, ITER_CB, _P,
                                   COLLECTIVE_CB, _P]),
+    ("plm_fit_sharded_rccl", C.c_int, [C.POINTER(PlmProblem), C.POINTER(PlmResult), C.c_int, _P, ITER_CB, _P, _P]),
+    ("plm_rccl_unique_id", C.c_int, [_P]),
+    ("plm_rccl_runtime_version", C.c_int, []),
+    ("plm_rccl_selftest", C.c_int, [C.c_int, _P]),
+    ("plm_ctx_attach_rccl", C.c_int, [_P, _P]),
     ("plm_reweight", C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P]),
     ("plm_reweight_ex", C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P]),
     ("plm_marginals", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

@@ -179,8 +179,9 @@ struct plm_ctx {
     void *Bt = nullptr, *Rt = nullptr;
     float *G = nullptr;        // split-K partial slabs (local)
     float *gather = nullptr;   // exchange buffer [nshards][slab] (replicated multi-shard mode only)
-    plm_collective_cb collective = nullptr;   // sharded-state mode
+    plm_collective_cb collective = nullptr;   // sharded-state mode: collectives through the host ...
     void *collective_user = nullptr;
+    PlmRccl *rccl = nullptr;                  // ... or issued here, on st (plm_ctx_attach_rccl)
     float *xhalo = nullptr, *ghalo = nullptr, *xsend = nullptr, *gsend = nullptr;
     std::vector<int64_t> x_send, x_recv, g_send, g_recv;   // all-to-all byte counts per rank
     double *fx_part = nullptr, *reg_part = nullptr, *dot_scratch = nullptr, *scal = nullptr;
@@ -242,7 +243,12 @@ int ctx_alloc_lbfgs(plm_ctx *c, int m) {
 // enqueue one objective+gradient evaluation at c->x -> c->g, scal[0] = fx, scal[1] = nll
 // one collective of the sharded-state mode (stream is synchronised first: the host runs it with RCCL)
 int ctx_collective(plm_ctx *c, int op, void *send, void *recv, const int64_t *scounts, const int64_t *rcounts) {
-    if (!c->collective) return fail(PLM_EINVAL, "sharded-state mode needs a collective callback");
+    if (c->rccl) {   // stream-ordered: nothing to wait for
+        if (plm_rccl_collective(c->rccl, op, send, recv, scounts, rcounts, c->st) != 0)
+            return fail(PLM_ECALLBACK, "RCCL collective failed (op %d): %s", op, plm_rccl_error());
+        return PLM_OK;
+    }
+    if (!c->collective) return fail(PLM_EINVAL, "sharded-state mode needs a collective callback or an RCCL communicator");
     HIP_TRY(hipStreamSynchronize(c->st));
     if (c->collective(op, send, recv, scounts, rcounts, c->d.nshards, c->d.shard, c->collective_user) != 0)
         return fail(PLM_ECALLBACK, "collective callback failed (op %d)", op);
@@ -592,6 +598,10 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);
+    if (c->rccl) {
+        hipStreamSynchronize(c->st);
+        plm_rccl_destroy(c->rccl);
+    }
     delete c;
 }
 
@@ -687,6 +697,60 @@ int plm_ctx_set_collective(plm_ctx_t *c, plm_collective_cb collective, void *use
     c->collective = collective;
     c->collective_user = user;
     return PLM_OK;
+}
+
+int plm_ctx_attach_rccl(plm_ctx_t *c, const void *rccl_id) {
+    if (!c || !rccl_id) return fail(PLM_EINVAL, "NULL ctx / id");
+    if (c->rccl) return fail(PLM_EINVAL, "context already has a communicator");
+    HIP_TRY(hipSetDevice(c->device));
+    if (plm_rccl_init(rccl_id, c->d.nshards, c->d.shard, &c->rccl) != 0)
+        return fail(PLM_ECALLBACK, "RCCL communicator of %d ranks: %s", c->d.nshards, plm_rccl_error());
+    return PLM_OK;
+}
+
+int plm_rccl_unique_id(void *id_out) {
+    if (!id_out) return fail(PLM_EINVAL, "NULL id");
+    if (plm_rccl_id(id_out) != 0) return fail(PLM_ECALLBACK, "%s", plm_rccl_error());
+    return PLM_OK;
+}
+int plm_rccl_runtime_version(void) { return plm_rccl_version(); }
+
+// every collective of the sharded-state mode on a one-rank communicator (the only kind a single GPU can form)
+int plm_rccl_selftest(int device, void *stream) {
+    PLM_TRY(check_device(device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char id[PLM_RCCL_ID_BYTES];
+    PLM_TRY(plm_rccl_unique_id(id));
+    PlmRccl *r = nullptr;
+    if (plm_rccl_init(id, 1, 0, &r) != 0) return fail(PLM_ECALLBACK, "%s", plm_rccl_error());
+    const int n = 1000;
+    double *buf = nullptr;
+    int rc = dalloc(&buf, (size_t)2 * n);
+    std::vector<double> h(2 * n, 0.0), back(2 * n, -1.0);
+    for (int k = 0; k < n; k++) h[k] = 0.5 * k - 7.0;
+    const int64_t bytes = (int64_t)sizeof(double) * n, root = 0;
+    auto run = [&](int op, void *s, void *d) {
+        if (rc == PLM_OK && plm_rccl_collective(r, op, s, d, &bytes, op == PLM_COLL_BROADCAST ? &root : &bytes, st) != 0)
+            rc = fail(PLM_ECALLBACK, "op %d: %s", op, plm_rccl_error());
+    };
+    if (rc == PLM_OK && hipMemcpyAsync(buf, h.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = fail(PLM_EDEVICE, "upload failed");
+    run(PLM_COLL_ALLREDUCE_F64, buf, buf);
+    run(PLM_COLL_ALLREDUCE_F32, buf, buf);
+    run(PLM_COLL_BROADCAST, buf, nullptr);
+    run(PLM_COLL_ALLTOALL, buf, buf + n);
+    if (rc == PLM_OK && (hipMemcpyAsync(back.data(), buf, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                         hipStreamSynchronize(st) != hipSuccess))
+        rc = fail(PLM_EDEVICE, "download failed");
+    if (rc == PLM_OK)
+        for (int k = 0; k < n; k++)
+            if (back[k] != h[k] || back[n + k] != h[k]) {
+                rc = fail(PLM_ECALLBACK, "one-rank collectives changed the data at %d", k);
+                break;
+            }
+    if (buf) hipFree(buf);
+    plm_rccl_destroy(r);
+    return rc;
 }
 
 int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, double epsilon, int32_t lbfgs_m) {
@@ -1606,7 +1670,7 @@ int plm_alignment_stats(const int8_t *msa, int32_t n, int32_t L, int32_t gap_sta
 
 static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream, plm_iter_cb iter_cb,
                     void *iter_user, plm_exchange_cb exchange, void *exchange_user, plm_collective_cb collective,
-                    void *collective_user) {
+                    void *collective_user, const void *rccl_id = nullptr) {
     if (!problem || !result) return fail(PLM_EINVAL, "NULL problem / result");
     const double t0 = now_s();
     const int nshards = problem->n_shards > 0 ? problem->n_shards : 1;
@@ -1637,6 +1701,7 @@ static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int devi
             c->h_fi = c1->h_fi;
             plm_ctx_set_exchange(c, exchange, exchange_user);
             plm_ctx_set_collective(c, collective, collective_user);
+            if (rccl_id) rc = plm_ctx_attach_rccl(c, rccl_id);
         }
         plm_ctx_destroy(c1);
         c1 = nullptr;
@@ -1682,6 +1747,16 @@ int plm_fit_sharded(const plm_problem_t *problem, plm_result_t *result, int devi
     plm_problem_t p = *problem;
     p.flags |= PLM_FLAG_SHARDED_STATE;
     return fit_impl(&p, result, device, stream, iter_cb, iter_user, nullptr, nullptr, collective, collective_user);
+}
+
+int plm_fit_sharded_rccl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
+                         plm_iter_cb iter_cb, void *iter_user, const void *rccl_id) {
+    if (!problem || !result) return fail(PLM_EINVAL, "NULL problem / result");
+    if (problem->n_shards > 1 && !rccl_id) return fail(PLM_EINVAL, "n_shards > 1 needs the communicator id");
+    plm_problem_t p = *problem;
+    p.flags |= PLM_FLAG_SHARDED_STATE;
+    return fit_impl(&p, result, device, stream, iter_cb, iter_user, nullptr, nullptr, nullptr, nullptr,
+                    problem->n_shards > 1 ? rccl_id : nullptr);
 }
 
 }  // extern "C"

@@ -116,6 +116,15 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
 // Newton step on the field part of x (full = that pass carried Hessian sums: inverse recomputed and cached in hinv
 // [sites][Q][Q]; else the cached inverse).  *flag (device, required) is raised when no site is above its share and
 // makes later launches return at once; tol2 = 0 and a zeroed flag give the plain "step everywhere" behaviour.
+// plm_rccl.cpp: RCCL resolved at run time
+struct PlmRccl;
+int plm_rccl_id(void *id128);
+int plm_rccl_version();
+int plm_rccl_init(const void *id128, int nranks, int rank, PlmRccl **out);
+void plm_rccl_destroy(PlmRccl *p);
+int plm_rccl_collective(PlmRccl *p, int op, void *send, void *recv, const int64_t *scounts, const int64_t *rcounts,
+                        hipStream_t st);
+const char *plm_rccl_error();
 hipError_t plm_launch_h64_init(const PlmDims &d, const float *x, double *h64, hipStream_t st);
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,

@@ -19,6 +19,7 @@ The reference has nothing to compare with here: plmc parallelises with OpenMP th
 only (evcouplings/couplings/tools.py:257-259, the `cpu` option).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -167,22 +168,44 @@ def make_host_staged_collective(group=None, device=0):
     return collective
 
 
-def fit_distributed(msa, q=21, group=None, sharded_state=True, transport="rccl", **kwargs):
+def share_rccl_id(group=None):
+    """rank 0 creates the id of the library's own RCCL communicator, every rank of the group receives it"""
+    import torch.distributed as dist
+    from evcouplings_amd import plm
+    box = [plm.rccl_unique_id() if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return box[0]
+
+
+def native_rccl_requested():
+    """PLM_NATIVE_RCCL=1: collectives issued by the library (RCCL on its stream) instead of torch.distributed calls
+    from a host callback.  Opt-in until it has run on a multi-GPU node (single-GPU boxes can only form a one-rank
+    communicator: plm.rccl_selftest)."""
+    return os.environ.get("PLM_NATIVE_RCCL", "0") not in ("", "0")
+
+
+def fit_distributed(msa, q=21, group=None, sharded_state=True, transport=None, **kwargs):
     """
     plm.fit on every rank of an initialised process group, sites sharded across ranks.
     sharded_state=True (default): parameters, gradient and L-BFGS state are split by owning site block;
     per evaluation two all-to-alls of neighbour blocks + scalar all-reduces.  False: replicated state,
     one all-gather of the gradient slabs per evaluation.
-    transport "rccl": collectives on the library's device buffers (backend nccl); "host": staged through
-    host memory (backend gloo; sharded-state mode only).
+    transport "rccl": torch.distributed collectives on the library's device buffers (backend nccl); "native": the
+    library issues the RCCL calls itself on its stream (torch.distributed only carries the communicator id); "host":
+    staged through host memory (backend gloo; sharded-state mode only).  Default: "rccl", or "native" with
+    PLM_NATIVE_RCCL=1.
     """
     import torch
     import torch.distributed as dist
     from evcouplings_amd import plm
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     device = kwargs.pop("device", torch.cuda.current_device())
+    if transport is None:
+        transport = "native" if native_rccl_requested() else "rccl"
     if world == 1:
         return plm.fit(msa, q=q, device=device, **kwargs)
+    if sharded_state and transport == "native":
+        return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device, rccl_id=share_rccl_id(group), **kwargs)
     if sharded_state:
         coll = make_torch_collective(group) if transport == "rccl" else make_host_staged_collective(group, device)
         return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device, collective=coll, **kwargs)

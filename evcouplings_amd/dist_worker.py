@@ -31,7 +31,7 @@ def main(argv=None):
     try:
         z = np.load(src)
         kwargs = json.loads(str(z["kwargs"]))
-        res = fit_distributed(z["msa"], transport="rccl" if backend == "nccl" else "host", device=local_rank, **kwargs)
+        res = fit_distributed(z["msa"], transport=None if backend == "nccl" else "host", device=local_rank, **kwargs)
         if dist.get_rank() == 0:
             arrays = {k: v for k, v in res.items() if isinstance(v, np.ndarray)}
             meta = {k: v for k, v in res.items() if not isinstance(v, np.ndarray) and k != "table"}

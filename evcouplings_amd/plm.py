@@ -275,7 +275,8 @@ def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbf
 
 def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
         epsilon=1e-3, lbfgs_m=6, device=0, stream=0, callback=None, n_shards=1, shard=0,
-        exchange=None, want_fij=True, ignore_gaps=False, collective=None, precond=False, joint=False, conventions=0):
+        exchange=None, want_fij=True, ignore_gaps=False, collective=None, precond=False, joint=False, conventions=0,
+        rccl_id=None):
     """
     Whole couplings inference: reweight -> marginals -> L-BFGS -> scores.
 
@@ -283,7 +284,9 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     exchange(dev_ptr, bytes_per_shard, n_shards, shard) -> 0 implements the all-gather of
     the site-sharded gradient slabs (see evcouplings_amd.dist) and is required iff n_shards > 1
     in the replicated mode; pass `collective` instead to run the sharded-state mode
-    (parameters, gradient and optimiser state split across the shards, see evcouplings_amd.dist).
+    (parameters, gradient and optimiser state split across the shards, see evcouplings_amd.dist), or `rccl_id`
+    (the bytes of rccl_unique_id() made on rank 0) to run that mode with the collectives issued by the library
+    itself over RCCL on its own stream (one process per GPU, rank = shard).
     ignore_gaps=True is plmc -g (tools.py:222-224): state 0 is excluded from the model and every
     returned array has q-1 states (fi, hi: (L, q-1); fij, jij: (pairs, q-1, q-1)).
     joint=True optimises fields and couplings jointly with L-BFGS as libLBFGS-based plmc does
@@ -319,9 +322,13 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     else:
         xcb = C.cast(None, _lib.EXCHANGE_CB)
     prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
-                    n_shards, shard, ignore_gaps, sharded_state=collective is not None, precond=precond, joint=joint,
-                    conventions=conventions)
-    if collective is not None:
+                    n_shards, shard, ignore_gaps, sharded_state=collective is not None or rccl_id is not None,
+                    precond=precond, joint=joint, conventions=conventions)
+    if rccl_id is not None:
+        idbuf = C.create_string_buffer(bytes(rccl_id), RCCL_ID_BYTES)
+        check(lib.plm_fit_sharded_rccl(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
+                                       None, idbuf))
+    elif collective is not None:
         ccb = _wrap_collective(collective)
         check(lib.plm_fit_sharded(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
                                   None, ccb, None))
@@ -340,6 +347,26 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
         seconds=dict(reweight=res.seconds_reweight, marginals=res.seconds_marginals,
                      optimize=res.seconds_optimize, total=res.seconds_total))
     return out
+
+
+RCCL_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """plm_rccl_unique_id: the communicator id rank 0 creates and every rank attaches (128 bytes)."""
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    check(_lib.load().plm_rccl_unique_id(buf))
+    return buf.raw
+
+
+def rccl_version():
+    """NCCL version code of the RCCL the library resolved at run time (0: none found)."""
+    return int(_lib.load().plm_rccl_runtime_version())
+
+
+def rccl_selftest(device=0, stream=0):
+    """every collective of the sharded-state mode on a one-rank communicator; raises on any failure"""
+    check(_lib.load().plm_rccl_selftest(int(device), C.c_void_p(int(stream) or None)))
 
 
 class PlmContext:
@@ -384,6 +411,12 @@ class PlmContext:
         cb = _wrap_collective(collective)
         self._keep.append(cb)
         check(self.lib.plm_ctx_set_collective(self._h, cb, None))
+
+    def attach_rccl(self, rccl_id):
+        """collectives of the sharded-state mode from the library itself (RCCL on the context's stream); a collective
+        call: every rank, with the id rank 0 made (rccl_unique_id)"""
+        idbuf = C.create_string_buffer(bytes(rccl_id), RCCL_ID_BYTES)
+        check(self.lib.plm_ctx_attach_rccl(self._h, idbuf))
 
     def set_options(self, max_iter=-1, epsilon=-1.0, lbfgs_m=-1):
         check(self.lib.plm_ctx_set_options(self._h, int(max_iter), float(epsilon), int(lbfgs_m)))

@@ -31,7 +31,7 @@ extern "C" {
 #define PLM_EDEVICE (-3)     /* HIP runtime error / no gfx950 device */
 #define PLM_EUNSUPPORTED (-4)/* alphabet size outside 2..21 (any size in that range runs, padded to 4 / 5 / 20 / 21) */
 #define PLM_ENUMERIC (-5)    /* NaN/Inf met in objective */
-#define PLM_ECALLBACK (-6)   /* exchange callback reported failure */
+#define PLM_ECALLBACK (-6)   /* exchange / collective callback or an RCCL call reported failure */
 
 /* optimisation end states (plm_result_t.status) -> "Gradient optimization: (.+)" line that
  * tools.py:56,99 parses */
@@ -174,6 +174,20 @@ int plm_fit(const plm_problem_t *problem, plm_result_t *result, int device, void
 int plm_fit_sharded(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
                     plm_iter_cb iter_cb, void *iter_user, plm_collective_cb collective, void *collective_user);
 
+/* The same with the collectives issued by the library itself: RCCL calls on the context's stream (one process per
+ * GPU, ranks = shards), no host callback and no stream synchronisation around a collective.  Rank 0 creates an id
+ * (plm_rccl_unique_id), the host hands its PLM_RCCL_ID_BYTES bytes to every rank by its own means (MPI, a file,
+ * torch.distributed), then every rank calls plm_fit_sharded_rccl -- or plm_ctx_attach_rccl on a resident context
+ * (a collective call: all ranks, each with its GPU current).  librccl is resolved at run time (a copy already in
+ * the process first, then /opt/rocm's; PLM_RCCL_LIB overrides).  plm_rccl_selftest runs every collective on a
+ * one-rank communicator. */
+#define PLM_RCCL_ID_BYTES 128
+int plm_rccl_unique_id(void *id_out);
+int plm_rccl_runtime_version(void);          /* NCCL version code of the resolved library, 0 if none */
+int plm_rccl_selftest(int device, void *stream);
+int plm_fit_sharded_rccl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
+                         plm_iter_cb iter_cb, void *iter_user, const void *rccl_id);
+
 /* -- fine-grained, host buffers (parity tests) ------------------------------------------- */
 /* plmc sequence reweighting; twin: align/alignment.py:1193-1233.  counts[s] = cluster size. */
 int plm_reweight(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double theta_id,
@@ -250,6 +264,7 @@ int plm_ctx_create(const plm_problem_t *problem, int device, void *stream, plm_c
 void plm_ctx_destroy(plm_ctx_t *ctx);
 int plm_ctx_set_exchange(plm_ctx_t *ctx, plm_exchange_cb exchange, void *user);
 int plm_ctx_set_collective(plm_ctx_t *ctx, plm_collective_cb collective, void *user);
+int plm_ctx_attach_rccl(plm_ctx_t *ctx, const void *rccl_id);   /* ranks = problem.n_shards, rank = problem.shard */
 /* change the stop rule / history of later plm_ctx_optimize calls (negative = keep) */
 int plm_ctx_set_options(plm_ctx_t *ctx, int32_t max_iter, double epsilon, int32_t lbfgs_m);
 /* number of floats of the solver's internal ("native", 16-site blocked) parameter vector */

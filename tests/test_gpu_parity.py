@@ -488,6 +488,24 @@ def test_eight_shard_fit_matches_single_gpu(plm, L):
         np.testing.assert_allclose(o["cn"], ref["cn"], atol=3e-4)
 
 
+def test_native_rccl_collectives_on_one_rank(plm):
+    """plm_rccl_*: librccl resolved at run time, a communicator formed from an id, every collective of the
+    sharded-state mode issued on the library's stream.  One GPU can only form a one-rank communicator: this pins the
+    loading, the symbols and the call signatures; the multi-rank semantics are those of the gloo flow test."""
+    assert plm.rccl_version() >= 20000
+    ident = plm.rccl_unique_id()
+    assert len(ident) == plm.RCCL_ID_BYTES and ident != plm.rccl_unique_id()
+    plm.rccl_selftest()
+    msa, _ = synthetic_msa(300, 40, seed=5)
+    ref = plm.fit(msa, Q, max_iter=8, epsilon=1e-12, want_fij=False)
+    got = plm.fit(msa, Q, max_iter=8, epsilon=1e-12, want_fij=False, rccl_id=ident)      # n_shards = 1: no exchange
+    np.testing.assert_array_equal(got["cn"], ref["cn"])
+    with plm.PlmContext(msa, q=Q, max_iter=5, epsilon=1e-12) as ctx:
+        ctx.attach_rccl(plm.rccl_unique_id())
+        ctx.reweight(); ctx.marginals(pairs=False); ctx.set_x(None)
+        assert ctx.optimize()["iters"] == 5
+
+
 def test_two_process_fit_over_gloo(plm, tmp_path):
     """The multi-process flow of fit_distributed / bench.py --gpus N: two torch.distributed.run ranks share GPU 0,
     collectives staged through host memory (gloo).  Must reproduce the in-process sharded fit exactly."""
