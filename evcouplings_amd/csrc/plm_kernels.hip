@@ -1170,6 +1170,7 @@ struct HpassArgs {
     double *gpart;        // [workgroup][16 sites][Q]   gradient sums, f64: their f32 accumulation was the noise floor
     float rscale;         //                            of the field solver (|g_h| ~ 1e-2 at N = 50 000)
     const int *skip;      // device flag (may be NULL): non-zero = the field solver has converged, do nothing
+    int sel;              // sequence tiles of this launch: 0 all, 1 the Hessian-sampled ones, 2 all the others
 };
 template <int Q, bool WRITE_RT, int STATS>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
@@ -1178,7 +1179,13 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     if (A.skip && *A.skip) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
-    const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
+    // a Hessian pass is two launches: the sampled tiles with the big LDS statistics area (one workgroup per CU), all
+    // other tiles with the small one (three per CU) -- one launch for both ran every tile at the low occupancy
+    const int ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
+    const int nst = A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1);
+    const int kt = blockIdx.x % nst, b16l = blockIdx.x / nst;
+    const int stile = A.sel == 0 ? kt : (A.sel == 1 ? kt * PLM_HESS_SAMPLE : kt + kt / (PLM_HESS_SAMPLE - 1) + 1);
+    const int blk = b16l * d.nstiles + stile;          // index of the (site block, sequence tile) pair everywhere
     const int b16 = d.b16_lo + b16l;
     const int r = lane & 15, g = lane >> 4;
     const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
@@ -1208,7 +1215,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
         for (int k = lane; k < 16 * NH; k += 64) lh0[(size_t)wave * 16 * NH + k] = 0.f;
     }
     // wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset: no 64-bit per-lane addresses
-    const char *hj_u = (const char *)(A.hj + ((size_t)blockIdx.x * 8 + wave) * 2 * Q * 64);
+    const char *hj_u = (const char *)(A.hj + ((size_t)blk * 8 + wave) * 2 * Q * 64);
     const u32 lane16 = (u32)lane * 16;
     // the wave's 32 sequences are handled in two halves of 16 (4 per lane): half the registers of the whole tile
     int m_end = 2;
@@ -1322,7 +1329,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     }
     __syncthreads();
     if constexpr (STATS != 0) {
-        double *gout = A.gpart + (size_t)blockIdx.x * 16 * Q;
+        double *gout = A.gpart + (size_t)blk * 16 * Q;
         for (int k = tid; k < 16 * Q; k += 512) {
             double v = 0;
 #pragma unroll
@@ -1330,7 +1337,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             gout[k] = v;
         }
         if constexpr (STATS == 2) {
-            float *out = A.hpart + (size_t)blockIdx.x * 16 * NH;
+            float *out = A.hpart + (size_t)blk * 16 * NH;
             for (int k = tid; k < 16 * NH; k += 512) {
                 float v = 0.f;
 #pragma unroll
@@ -1342,17 +1349,19 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     if constexpr (WRITE_RT) {
         __syncthreads();
         const double tot = block_reduce_sum((double)fxl, (double *)smem);
-        if (tid == 0) A.fx_part[blockIdx.x] = tot;
+        if (tid == 0) A.fx_part[blk] = tot;
     }
 }
 hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const double *h64,
                             int write_rt, int stats, void *Rt, double *fx_part, float *hpart, double *gpart,
                             const int *skip, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    const dim3 grid(d.nstiles * (d.b16_hi - d.b16_lo)), block(512);
-    const HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (_Float16 *)Rt, fx_part, hpart, gpart, ldexpf(1.f, PLM_R_EXP), skip};
+    const int nb = d.b16_hi - d.b16_lo, ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
+    const dim3 block(512);
+    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (_Float16 *)Rt, fx_part, hpart, gpart, ldexpf(1.f, PLM_R_EXP), skip, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
+        const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
         const size_t lds = (size_t)8 * 16 * ((QQ) * sizeof(double) + ((SS) == 2 ? (QQ) * ((QQ) + 1) / 2 : 0) * sizeof(float)); \
         static bool attr_done_dev[PLM_MAX_DEVICES] = {false};                                          \
         bool &attr_done = attr_done_dev[plm_current_device()];                                         \
@@ -1368,8 +1377,12 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
     case QQ:                                                                                           \
         if (write_rt && stats == 2) HP_LAUNCH(QQ, true, 2)                                             \
         else if (write_rt) HP_LAUNCH(QQ, true, 1)                                                      \
-        else if (stats == 2) HP_LAUNCH(QQ, false, 2)                                                   \
-        else HP_LAUNCH(QQ, false, 1)                                                                   \
+        else if (stats == 2) {                                                                         \
+            A.sel = 2;                                                                                 \
+            if (d.nstiles > ns1) HP_LAUNCH(QQ, false, 1)                                               \
+            A.sel = 1;                                                                                 \
+            HP_LAUNCH(QQ, false, 2)                                                                    \
+        } else HP_LAUNCH(QQ, false, 1)                                                                 \
         break;
     switch (d.Q) {
         HP_CASE(21)
