@@ -302,6 +302,8 @@ def test_torch_exchange_zero_copy_and_nccl_single_rank(plm):
         v = torch.arange(8, dtype=torch.float64, device="cuda")
         assert coll(_lib.COLL_ALLREDUCE_F64, v.data_ptr(), v.data_ptr(), [64], None, 1, 0) == 0
         assert v.tolist() == list(range(8))
+        assert coll(_lib.COLL_BROADCAST, v.data_ptr(), None, [64], [0], 1, 0) == 0      # root 0, in place
+        assert v.tolist() == list(range(8))
         msa, _ = synthetic_msa(300, 20, seed=3)
         a = pdist.fit_distributed(msa, q=Q, max_iter=10, epsilon=1e-12)
         b = plm.fit(msa, Q, max_iter=10, epsilon=1e-12)
