@@ -261,6 +261,18 @@ int ctx_allreduce_scalars(plm_ctx *c, int first, int count) {
     return ctx_collective(c, PLM_COLL_ALLREDUCE_F64, c->scal + first, c->scal + first, &bytes, &bytes);
 }
 
+// forward half of an evaluation at the fields and couplings of c->x (joint L-BFGS, plm_ctx_eval): the GEMM stores the
+// coupling potentials, one pass of the field kernel turns them into residuals (Rt) and -log P partials
+int vp_alloc(plm_ctx *c);
+int forward_at_x(plm_ctx *c) {
+    const PlmDims &d = c->d;
+    PLM_TRY(vp_alloc(c));
+    HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
+    HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr, c->st));
+    return PLM_OK;
+}
+
 // sharded-state evaluation: local x (+ halo from lower shards) -> local g; scal[0..1] = this shard's
 // part of fx and nll (summed over shards by the caller together with its dot products)
 int ctx_eval_enqueue_sharded(plm_ctx *c) {
@@ -270,7 +282,7 @@ int ctx_eval_enqueue_sharded(plm_ctx *c) {
     HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
                                d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, c->st));
     HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
-    HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
+    PLM_TRY(forward_at_x(c));
     if (d.nblk_own > 0) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
     PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
@@ -287,7 +299,7 @@ int ctx_eval_enqueue(plm_ctx *c) {
     if (d.sharded) return ctx_eval_enqueue_sharded(c);
     HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
     HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
-    HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
+    PLM_TRY(forward_at_x(c));
     HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     const float *Gsrc = c->G;
     int ks_count = d.ksplit, n_shard_nll = 0;
@@ -1356,7 +1368,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
             PLM_TRY(vp_stage2(c, 1, r == 0, false));   // one Newton step + the residual pass
             HIP_TRY(hipEventRecord(ev[5], c->st));
         } else {
-            HIP_TRY(plm_launch_forward(d, c->msa_rm, c->w, c->Bt, c->x, c->jexp, c->Rt, c->fx_part, c->st));
+            PLM_TRY(forward_at_x(c));
             HIP_TRY(hipEventRecord(ev[2], c->st));
             HIP_TRY(hipEventRecord(ev[5], c->st));
         }

@@ -95,9 +95,6 @@ hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, uint32_t *maxbits
                              hipStream_t st);
 hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhalo, const int32_t *jexp,
                              void *Bt, hipStream_t st);
-hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
-                              const float *x, const int32_t *jexp, void *Rt, double *fx_part,
-                              hipStream_t st);
 // statistical energies of sequences under a model (k_fwd modes 1/2)
 hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
                                      const int32_t *jexp, int potentials, float *out, hipStream_t st);

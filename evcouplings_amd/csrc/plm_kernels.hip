@@ -4,18 +4,20 @@
 // process that evcouplings/couplings/tools.py:266 launches:
 //   k_reweight   N x N Hamming identity counts on the packed int8 alignment (VALU, integer)
 //   k_expand     parameters -> forward B operand (f16 hi/lo MFMA fragments)
-//   k_fwd        one-hot(MSA) x J on MFMA + per-site softmax + residuals + -log P (fused); two more
-//                epilogues turn the same GEMM into statistical energies / potentials of sequences under a
-//                fitted model (row N2); k_fwd_split is a measured alternative tiling (PLM_FWD_SPLIT)
+//   k_fwd        one-hot(MSA) x J on MFMA -> the coupling part of every conditional (HJ), stored for k_hpass; two
+//                more epilogues turn the same GEMM into statistical energies / potentials of sequences under a
+//                fitted model (row N2)
 //   k_bwd        one-hot(MSA)^T x residuals on MFMA -> asymmetric gradient slab
 //   k_assemble   slab + slab^T + L2 term -> gradient, regulariser partial sums
-//   k_hpass / k_hsolve   variable-projection fit: k_fwd only stores the coupling potentials, the fields are solved
-//                per site by Newton on them (gradient / Hessian sums, residuals), DESIGN.md 2c, 4.8
+//   k_hpass      per-site softmax over HJ + fields -> residuals (the backward operand), -log P, and the gradient /
+//                Hessian sums of the field subproblems; k_hsolve: per-site Newton step (variable-projection fit,
+//                DESIGN.md 2c, 4.8).  (Rounds 1-2 also had the softmax fused into k_fwd: 71 spilled registers; the
+//                split costs the same time, spills nothing and serves both optimisers.)
 //   k_align_rows / k_align_cols   gap counts and identities of the align stage (row N3)
 // plus small streaming kernels for L-BFGS (dots / linear combinations) and scoring.  Mean-field DCA
 // (covariance inverse, fields, direct information) lives in plm_meanfield.hip.
 // Compile-time experiment switches (all off / neutral in the product build; DESIGN.md 4.3 has the measurements):
-// PLM_PIPE, PLM_FWD_SPLIT, PLM_DMA_STAGGER_*, PLM_ASYNC_A, PLM_ABLATE, PLM_PROBE.
+// PLM_PIPE, PLM_DMA_STAGGER_*, PLM_ASYNC_A, PLM_ABLATE, PLM_PROBE.
 //
 // The alignment is int8 in HBM; one-hot MFMA A fragments are expanded from 8 packed bytes
 // in registers (never materialised in memory); the dense operand (couplings / residuals)
@@ -44,7 +46,7 @@ typedef unsigned int u32;
 #endif
 // PLM_ABLATE bit mask for timing experiments with PLM_PIPE=0 (RESULTS INVALID): 1 no per-step vmcnt wait +
 // barrier, 2 no LDS-DMA in the K loop, 4 no LDS reads in the K loop (first fragments reused), 8 no one-hot
-// expansion (raw bytes as the A operand), 16 no epilogue arithmetic in k_fwd
+// expansion (raw bytes as the A operand)
 #ifndef PLM_ABLATE
 #define PLM_ABLATE 0
 #endif
@@ -52,14 +54,6 @@ typedef unsigned int u32;
 // the step, waves 4-7 (the SIMD partners of 0-3) this far into it.  Issuing a piece blocks a wave for
 // ~100-200 cycles; when both waves of a SIMD do that at the same time the MFMA pipe idles, but pieces issued
 // late land late.  Measured on MI355X (ms, stagger 0/4/8/12): k_fwd 5.42/5.27/5.59/5.69, k_bwd 5.19/5.46/5.50/5.46.
-// PLM_FWD_SPLIT=1: the solver's forward pass runs k_fwd_split (states of a site block split over the two waves
-// of a SIMD, B fragments reused by 4 row fragments: half the LDS fragment reads, no register spills) instead of
-// k_fwd.  Parity-green and measured on MI355X: the same time (5.27 vs 5.14-5.42 ms) from 8 % MORE shader cycles --
-// the chip runs these kernels at its power limit (clock ~15 % below the first version's), so the LDS energy
-// saved is spent again on twice the one-hot expansions.  Kept as an alternative, not the default.
-#ifndef PLM_FWD_SPLIT
-#define PLM_FWD_SPLIT 0
-#endif
 #ifndef PLM_DMA_STAGGER_FWD
 #define PLM_DMA_STAGGER_FWD 4
 #endif
@@ -570,14 +564,12 @@ struct FwdArgs {
     float rscale;
     float *out;           // MODE 1: float2 [Np][blocks] energy partials; MODE 2: potentials [N][L][Q]
 };
-// k_fwd MODE: 0 = conditional softmax, residuals, -log P (the solver).  The same GEMM also yields the
-// statistical energies of sequences under a fitted model (reference twins
-// couplings/model.py:25-60 _hamiltonians and :63-109 _single_mutant_hamiltonians):
-// 1 = per (sequence, site block) the pair (sum_i HJ[s,i,x_si], sum_i h_i(x_si)) with
-//     HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj); 2 = the potentials HJ[s,i,a] themselves.
-// 3 = the coupling part of every conditional, HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj), stored in accumulator order
-//     (float4 per lane and state) for the field solver of the variable-projection fit (k_hpass below).
-enum { FWD_SOLVER = 0, FWD_ENERGY = 1, FWD_POTENTIALS = 2, FWD_STORE = 3 };
+// k_fwd MODE.  The GEMM yields HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj), the coupling part of every conditional:
+// 1 = statistical energies of sequences under a fitted model (reference twins
+//     couplings/model.py:25-60 _hamiltonians and :63-109 _single_mutant_hamiltonians): per (sequence, site block)
+//     the pair (sum_i HJ[s,i,x_si], sum_i h_i(x_si)); 2 = the potentials HJ[s,i,a] themselves;
+// 3 = HJ stored in accumulator order (float4 per lane and state) for k_hpass below: the solver's forward pass.
+enum { FWD_ENERGY = 1, FWD_POTENTIALS = 2, FWD_STORE = 3 };
 
 
 // one K step of the forward GEMM for one wave: Q states x (hi, lo) planes x 2 row fragments.
@@ -732,6 +724,12 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
 #if PLM_PROBE
     const unsigned long long pr_t1 = PROBE_NOW();
 #endif
+#if PLM_PROBE
+    if (lane == 0) {
+        atomicAdd(&plm_probe_acc[0][0], pr_wait); atomicAdd(&plm_probe_acc[0][3], pr_t1 - pr_t0);
+        atomicAdd(&plm_probe_acc[0][5], 1ull);
+    }
+#endif
 
     if constexpr (MODE == FWD_STORE) {
         const float sc = ldexpf(1.f, -(*A.jexp));
@@ -745,7 +743,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             }
         return;
     }
-    if constexpr (MODE != FWD_SOLVER) {
+    {
         // ---- statistical energies / potentials of the given sequences (no softmax) ------------
         const float sc = ldexpf(1.f, -(*A.jexp));
         const int i = b16 * 16 + r;
@@ -793,282 +791,12 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
         }
         return;
     }
-#if PLM_ABLATE & 16
-    float fxl = 0.f;   // timing experiment: consume the accumulators, skip the real epilogue
-#pragma unroll
-    for (int a = 0; a < Q; a++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) fxl += acc[0][a][k] + acc[1][a][k];
-#else
-    // ---- epilogue: softmax over states, residuals, -log P -------------------------------
-    const float sc = ldexpf(1.f, -(*A.jexp));
-    const int i = b16 * 16 + r;
-    const bool site_ok = i < d.L;
-    float hv[Q];
-#pragma unroll
-    for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
-    float fxl = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int s = s_wave + 16 * m + 4 * g + reg;
-            const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
-            const bool skip = gap && xi == 0;            // gapped site: no conditional for (s, i)
-            const float ws = skip ? 0.f : A.w[s];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int a = 0; a < Q; a++) {
-                const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : fmaf(acc[m][a][reg], sc, hv[a]);
-                acc[m][a][reg] = H;
-                mx = fmaxf(mx, H);
-            }
-            float Z = 0.f, hx = 0.f;
-#pragma unroll
-            for (int a = 0; a < Q; a++) {
-                const float H = acc[m][a][reg] - mx;
-                hx = (a == xi) ? H : hx;
-                const float ev = __expf(H);
-                acc[m][a][reg] = ev;
-                Z += ev;
-            }
-            const float invZ = 1.f / Z;
-            if (site_ok && !skip) fxl -= ws * (hx - __logf(Z));
-            const float wr = site_ok ? ws * A.rscale : 0.f;
-            int xi2 = xi;
-            asm volatile("" : "+v"(xi2));   // fresh compares: sharing the 21 masks of the loop above keeps them all
-#pragma unroll                              // alive in SGPR pairs (this was the source of the kernel's spills)
-            for (int a = 0; a < Q; a++)
-                acc[m][a][reg] = wr * (acc[m][a][reg] * invZ - ((a == xi2) ? 1.f : 0.f));
-        }
-    }
-    // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes) ----------------
-    // wave-uniform base + 32-bit lane offset; one 16-byte store per lane and state (rows swapped so that even-g
-    // lanes hold a whole hi slot and odd-g lanes a whole lo slot, see k_hpass)
-    const int sstep = (stile * PLM_SEQ_TILE + wave_s * 32) >> 5;
-    char *rt_u = (char *)(A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q) * 1024);
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const u32 slot16 = (u32)((2 * m + (g >> 1)) * 16 + r) * 16 + (u32)(g & 1) * 1024;
-#pragma unroll
-        for (int a = 0; a < Q; a++) {
-            const f32x4 v = acc[m][a];
-            union { half4 h; u32 w[2]; } hi, lo;
-            // half e = 4*(g&1) + {0,1,2,3} <-> sequence offset perm8(e): regs (0,2,1,3)
-            hi.h[0] = (_Float16)v[0]; hi.h[1] = (_Float16)v[2]; hi.h[2] = (_Float16)v[1]; hi.h[3] = (_Float16)v[3];
-            lo.h[0] = (_Float16)(v[0] - (float)hi.h[0]); lo.h[1] = (_Float16)(v[2] - (float)hi.h[1]);
-            lo.h[2] = (_Float16)(v[1] - (float)hi.h[2]); lo.h[3] = (_Float16)(v[3] - (float)hi.h[3]);
-            auto p0 = __builtin_amdgcn_permlane16_swap(hi.w[0], lo.w[0], false, false);
-            auto p1 = __builtin_amdgcn_permlane16_swap(hi.w[1], lo.w[1], false, false);
-            *(uint4 *)(rt_u + (size_t)a * 2048 + slot16) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
-        }
-    }
-#endif
-    __syncthreads();   // every wave is done with the B tiles: reuse the LDS for the reduction
-    const double tot = block_reduce_sum((double)fxl, (double *)smem);
-    if (tid == 0) A.fx_part[tile] = tot;
-#if PLM_PROBE
-    if (lane == 0) {
-        const unsigned long long pr_t2 = PROBE_NOW();
-        atomicAdd(&plm_probe_acc[0][0], pr_wait); atomicAdd(&plm_probe_acc[0][3], pr_t2 - pr_t0);
-        atomicAdd(&plm_probe_acc[0][4], pr_t2 - pr_t1); atomicAdd(&plm_probe_acc[0][5], 1ull);
-    }
-#endif
-}
-
-// =========================================================================================
-// K_fwd_split: the solver's forward kernel with the states of a site block split over the two waves of a
-// SIMD (PLM_FWD_SPLIT).  Workgroup = 256 sequences x one 16-site block as in k_fwd, but wave w owns the 64
-// sequences of group w & 3 and the states of half w >> 2 (ceil(Q/2) states for half 0, floor(Q/2) for half 1;
-// waves w and w+4 share a SIMD, so every SIMD still sees all Q states).  Every B fragment read from LDS now
-// feeds 4 row fragments instead of 2: half the LDS fragment traffic of k_fwd for the same MFMA work.  The
-// softmax over states needs the partner wave's maximum and sum: two small exchanges through LDS.
-// =========================================================================================
-// B fragment number F = 2 * state + plane of a K step: one ds_read_b128, 4 MFMAs (one per row fragment).  A ring
-// of three single fragments (12 VGPRs): fragment F+2 is requested before fragment F computes.
-template <int N> __device__ __forceinline__ void lds_wait1(half8 &a) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
-}
-// One code path for both halves: NS0 = ceil(Q/2) states are stepped through; for odd Q the half with one state
-// less still reads the two fragments of the surplus state (they lie just behind its own; the launcher adds 1 KB of
-// LDS for the very last one) but skips their MFMAs -- a wave-uniform branch around 4 instructions.
-template <int Q, int F>
-__device__ __forceinline__ void fwds_frag(f32x4 (&acc)[4][(Q + 1) / 2], const half8 (&af)[4], u32 lb, half8 (&bq)[3],
-                                          const DmaPlan &dma, bool last_state_live) {
-    constexpr int NS0 = (Q + 1) / 2, NP = (2 * Q + 7) / 8, TOT = 2 * NS0, A = F / 2;
-    constexpr int F2 = F + 2;
-    if constexpr (F2 < TOT) bq[F2 % 3] = lds_read_b128<((F2 & 1) ? Q + F2 / 2 : F2 / 2) * 1024>(lb);
-    lds_wait1<(TOT - 1 - F < 2) ? (TOT - 1 - F) : 2>(bq[F % 3]);
-    if (A < NS0 - 1 || (Q % 2 == 0) || last_state_live) {
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-            acc[m][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bq[F % 3], acc[m][A], 0, 0, 0);
-    }
-    if constexpr ((F & 1) == 0) dma_at<NS0, A, NP, PLM_DMA_STAGGER_FWD>(dma);
-}
-template <int Q, int... F>
-__device__ __forceinline__ void fwds_kstep(f32x4 (&acc)[4][(Q + 1) / 2], const half8 (&af)[4], u32 lb,
-                                           const DmaPlan &dma, bool last_state_live,
-                                           std::integer_sequence<int, F...>) {
-    half8 bq[3];
-    bq[0] = lds_read_b128<0>(lb);
-    bq[1] = lds_read_b128<Q * 1024>(lb);
-    (fwds_frag<Q, F>(acc, af, lb, bq, dma, last_state_live), ...);
-}
-
-template <int Q>
-__global__ __launch_bounds__(512) void k_fwd_split(PlmDims d, FwdArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE = 2 * Q * 1024, NP = (2 * Q + 7) / 8, NS0 = (Q + 1) / 2, NS1 = Q / 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int sg = wave_s & 3, sh = wave_s >> 2;          // sequence group, state half
-    const int a_lo = sh ? NS0 : 0, ns = sh ? NS1 : NS0;   // own states [a_lo, a_lo + ns)
-    const int stile = blockIdx.x % d.nstiles, b16l = blockIdx.x / d.nstiles;
-    const int b16 = d.b16_lo + b16l;
-    const int r = lane & 15, g = lane >> 4;
-    const int s_wave = stile * PLM_SEQ_TILE + sg * 64;
-    const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE;
-    u32 arow[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) arow[m] = (u32)(s_wave + 16 * m + r) * (u32)d.Lp32 + 8 * g;
-
-    f32x4 acc[4][NS0];
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int a = 0; a < NS0; a++) acc[m][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int gap = d.gap_mode, nsteps = d.nu * (Q - gap);
-    {
-        const DmaPlan first{bt + (size_t)gap * TILE, smem, wave_s, 2 * Q, (u32)lane * 16, false};
-        dma_issue_all<NP>(first);
-    }
-    // alignment bytes of the 4 row fragments for the current 32 sites; the next 32 are fetched IN PLACE during
-    // the last K step of this u (after its one-hot fragments are built) and land under that step's MFMAs
-    u64 xa[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) xa[m] = *(const u64 *)(A.msa_rm + arow[m]);
-    int t = 0;
-    for (int u = 0; u < d.nu; ++u) {
-        for (int b = gap; b < Q; ++b, ++t) {
-            const int ks_next = (b + 1 < Q) ? u * Q + b + 1 : (u + 1) * Q + gap;
-            vm_wait<0>();
-            __syncthreads();
-            const DmaPlan dma{bt + (size_t)ks_next * TILE, smem + ((t + 1) & 1) * TILE, wave_s,
-                              (t + 1 < nsteps) ? 2 * Q : 0, (u32)lane * 16, wave_s >= 4};
-            const u32 lb = lds_addr(smem + (t & 1) * TILE + a_lo * 1024 + lane * 16);
-            const u32 bb = (u32)b * 0x01010101u;
-            half8 af[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                vm_landed(xa[m]);
-                af[m] = onehot8((u32)xa[m], (u32)(xa[m] >> 32), bb);
-            }
-            if (b == Q - 1 && u + 1 < d.nu) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) load_b64_inplace(xa[m], A.msa_rm, arow[m] + 32 * (u + 1));
-            }
-            fwds_kstep<Q>(acc, af, lb, dma, ns == NS0, std::make_integer_sequence<int, 2 * NS0>{});
-        }
-    }
-
-    // ---- epilogue: softmax over all Q states = own states + the partner wave's (max, sum) ----------
-    // Three phases separated by barriers; nothing but the accumulators stays in registers across them (the
-    // per-(sequence, site) scalars go through LDS or are reloaded: 256 VGPRs hold 176 accumulator registers).
-    __syncthreads();                                  // the B tiles are dead: LDS becomes the exchange area
-    float *ex = (float *)smem;                         // [half][sg][k = 4 m + reg][lane]: max, then sum
-    float *exh = ex + 2 * 4 * 16 * 64;                 // [wave][k][lane]: H of the observed state - max
-    const int my = ((sh * 4 + sg) * 16) * 64 + lane, other = (((1 - sh) * 4 + sg) * 16) * 64 + lane;
-    const float sc = ldexpf(1.f, -(*A.jexp));
-    const int i = b16 * 16 + r;
-    const bool site_ok = i < d.L;
-    {
-        float hv[NS0];
-#pragma unroll
-        for (int a = 0; a < NS0; a++) hv[a] = (site_ok && a < ns) ? A.h[(size_t)(i - d.h_site0) * Q + a_lo + a] : 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int m = k >> 2, reg = k & 3;
-            float v = -INFINITY;
-#pragma unroll
-            for (int a = 0; a < NS0; a++) {
-                const bool dead = a >= ns || (gap && a_lo + a == 0) || a_lo + a >= d.Qc;
-                const float H = dead ? -INFINITY : fmaf(acc[m][a][reg], sc, hv[a]);
-                acc[m][a][reg] = H;
-                v = fmaxf(v, H);
-            }
-            ex[my + k * 64] = v;
-        }
-    }
-    __syncthreads();
-    float mx[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) mx[k] = fmaxf(ex[my + k * 64], ex[other + k * 64]);
-    __syncthreads();                                  // everybody has read the maxima: the area now takes the sums
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int m = k >> 2, reg = k & 3;
-        const int s = s_wave + 16 * m + 4 * g + reg;
-        const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
-        float Z = 0.f, h = 0.f;
-#pragma unroll
-        for (int a = 0; a < NS0; a++) {
-            const float H = acc[m][a][reg] - mx[k];   // -inf for states this wave does not own
-            h = (a_lo + a == xi && a < ns) ? H : h;
-            const float ev = __expf(H);
-            acc[m][a][reg] = ev;
-            Z += ev;
-        }
-        ex[my + k * 64] = Z;
-        exh[(wave_s * 16 + k) * 64 + lane] = h;
-    }
-    __syncthreads();
-    float fxl = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int m = k >> 2, reg = k & 3;
-        const int s = s_wave + 16 * m + 4 * g + reg;
-        const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
-        const bool skip = gap && xi == 0;            // gapped site: no conditional for (s, i)
-        const float ws = skip ? 0.f : A.w[s];
-        const float Z = ex[my + k * 64] + ex[other + k * 64];
-        const float invZ = 1.f / Z;
-        const bool mine = xi >= a_lo && xi < a_lo + ns && !skip;
-        // -w log P(x_si | rest) is added by the wave that owns the observed state
-        if (site_ok && mine) fxl -= ws * (exh[(wave_s * 16 + k) * 64 + lane] - __logf(Z));
-        const float wr = site_ok ? ws * A.rscale : 0.f;
-#pragma unroll
-        for (int a = 0; a < NS0; a++)
-            acc[m][a][reg] = wr * (acc[m][a][reg] * invZ - ((a_lo + a == xi) ? 1.f : 0.f));
-    }
-    // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes), own states only ---------
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int sstep = (s_wave >> 5) + (m >> 1);
-        _Float16 *rt = A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q + a_lo) * 1024;
-        const int slot = ((2 * (m & 1) + (g >> 1)) * 16 + r) * 8 + (g & 1) * 4;
-#pragma unroll
-        for (int a = 0; a < NS0; a++) {
-            if (a < ns) {
-                const f32x4 v = acc[m][a];
-                half4 hi, lo;
-                hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[2]; hi[2] = (_Float16)v[1]; hi[3] = (_Float16)v[3];
-                lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[2] - (float)hi[1]);
-                lo[2] = (_Float16)(v[1] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
-                *(half4 *)(rt + (size_t)a * 1024 + slot) = hi;
-                *(half4 *)(rt + (size_t)a * 1024 + 512 + slot) = lo;
-            }
-        }
-    }
-    __syncthreads();
-    const double tot = block_reduce_sum((double)fxl, (double *)smem);
-    if (tid == 0) A.fx_part[blockIdx.x] = tot;
 }
 
 static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const int ntiles = d.nstiles * (d.b16_hi - d.b16_lo);
-    const dim3 grid_split(ntiles), grid(8 * ((ntiles + 7) / 8)), block(512);   // k_fwd: XCD-aware, padded to 8
+    const dim3 grid(8 * ((ntiles + 7) / 8)), block(512);   // XCD-aware order, padded to 8
     const size_t lds = (size_t)PLM_NBUF * 2 * d.Q * 1024;
 #define FWD_LAUNCH(QQ, MM)                                                                             \
     {                                                                                                  \
@@ -1084,19 +812,7 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
     }
 #define FWD_CASE(QQ)                                                                                   \
     case QQ:                                                                                           \
-        if (mode == FWD_SOLVER && PLM_FWD_SPLIT && !PLM_PIPE) {                                        \
-            const size_t lds_s = (lds > 65536 ? lds : 65536) + 1024;   /* tiles (+1 KB overread), 64 KB exchange */ \
-            static bool attr_done_dev[PLM_MAX_DEVICES] = {false};                                      \
-            bool &attr_done = attr_done_dev[plm_current_device()];                                     \
-            if (!attr_done) {                                                                          \
-                hipError_t e = hipFuncSetAttribute((const void *)k_fwd_split<QQ>,                      \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); \
-                if (e != hipSuccess) return e;                                                         \
-                attr_done = true;                                                                      \
-            }                                                                                          \
-            hipLaunchKernelGGL((k_fwd_split<QQ>), grid_split, block, lds_s, st, d, A);                       \
-        } else if (mode == FWD_SOLVER) FWD_LAUNCH(QQ, FWD_SOLVER)                                      \
-        else if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                        \
+        if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                             \
         else if (mode == FWD_STORE) FWD_LAUNCH(QQ, FWD_STORE)                                          \
         else FWD_LAUNCH(QQ, FWD_POTENTIALS)                                                            \
         break;
@@ -1111,11 +827,6 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
 #undef FWD_CASE
 #undef FWD_LAUNCH
     return hipGetLastError();
-}
-hipError_t plm_launch_forward(const PlmDims &d, const int8_t *msa_rm, const float *w, const void *Bt,
-                              const float *x, const int32_t *jexp, void *Rt, double *fx_part, hipStream_t st) {
-    const FwdArgs A{msa_rm, w, (const char *)Bt, x, jexp, (_Float16 *)Rt, fx_part, ldexpf(1.f, PLM_R_EXP), nullptr};
-    return launch_forward_mode(d, A, FWD_SOLVER, st);
 }
 // statistical energies: mode 1 -> out = float2 [Np][blocks] partial sums, mode 2 -> out = potentials [N][L][Q]
 hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
@@ -1375,7 +1086,8 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
     }
 #define HP_CASE(QQ)                                                                                    \
     case QQ:                                                                                           \
-        if (write_rt && stats == 2) HP_LAUNCH(QQ, true, 2)                                             \
+        if (write_rt && stats == 2) return hipErrorInvalidValue;   /* never needed: residuals come last */ \
+        else if (write_rt && stats == 0) HP_LAUNCH(QQ, true, 0)                                        \
         else if (write_rt) HP_LAUNCH(QQ, true, 1)                                                      \
         else if (stats == 2) {                                                                         \
             A.sel = 2;                                                                                 \
