@@ -102,7 +102,7 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.Lp16 = d.nb16 * 16;
     d.nu = (d.L + 31) / 32;
     d.Lp32 = d.nu * 32;
-    d.nksteps = d.nu * d.Q;
+    d.nksteps = d.nu * PLM_FWD_SPU(d.Q);
     d.nssteps = d.Np / 32;
     d.nstiles = d.Np / PLM_SEQ_TILE;
     plm_pick_tile(d.Q, &d.FM, &d.FN);

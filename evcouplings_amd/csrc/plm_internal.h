@@ -25,6 +25,21 @@
 #define PLM_SEQ_TILE 256      // sequences per forward workgroup (8 waves x 32)
 #define PLM_R_EXP 14          // residuals are stored scaled by 2^14 (|r| <= scale <= 1)
 
+// Forward GEMM on the 2:4 sparse MFMA (v_smfmac_f32_16x16x64_f16): the K index is ordered (site, state) with the
+// alphabet padded to a multiple of 4, so that every group of 4 dense K slots holds 4 states of ONE site -- at most
+// one non-zero of the one-hot operand, the pattern the instruction requires, by construction.
+// State 0 is the reference state and has no K slots: sum_j J_ij(a, x_sj) = sum_j J_ij(a, 0) + sum_{j: x_sj != 0}
+// (J_ij(a, x_sj) - J_ij(a, 0)) -- the first sum is a constant per (i, a) (k_fwd_ref, added in k_fwd's epilogues), the
+// GEMM runs on the differences and on Q - 1 states: 20 = 5 groups of 4 for the protein alphabet, no padding.
+// A K step covers, for the 32 sites of a block u, one of 2 * NG instruction slices (NG = ceil((Q - 1) / 4) state
+// groups per site, 4 (site, group) pairs per lane and instruction) and one of the two f16 planes.  0 = the dense
+// v_mfma_f32_16x16x32_f16 formulation of rounds 1-2 (K step = 32 sites x one state, both planes).
+#ifndef PLM_SPARSE_FWD
+#define PLM_SPARSE_FWD 1
+#endif
+#define PLM_FWD_NG(Q) (((Q) + 2) / 4)
+#define PLM_FWD_SPU(Q) (PLM_SPARSE_FWD ? 4 * PLM_FWD_NG(Q) : (Q))   // K steps per 32-site block
+
 struct PlmDims {
     int N, L, Q;       // Q: alphabet size the kernels are instantiated for (4, 5, 20, 21) -- the native layout's stride
     int Qc;            // alphabet size of the problem (2..Q): stride of every canonical-layout array at the API;
@@ -34,7 +49,7 @@ struct PlmDims {
     int Lp16;      // nb16 * 16
     int nu;        // 32-site K blocks covering L
     int Lp32;      // nu * 32
-    int nksteps;   // nu * Q      forward K steps (32 sites x one state)
+    int nksteps;   // nu * PLM_FWD_SPU(Q)   forward K steps (tiles of 2 Q KB)
     int nssteps;   // Np / 32     backward K steps (32 sequences)
     int nstiles;   // Np / PLM_SEQ_TILE
     int FM, FN;    // backward wave tile in fragments

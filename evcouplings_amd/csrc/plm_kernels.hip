@@ -31,6 +31,7 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
@@ -209,7 +210,11 @@ void plm_pick_tile(int q, int *fm, int *fn) {
     else if (q == 5) { *fm = 5; *fn = 5; }
     else { *fm = 4; *fn = 4; }
 }
-size_t plm_bt_bytes(const PlmDims &d) { return (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024; }
+// forward operand: the K-step tiles of every local column block, then (sparse formulation) the reference-state
+// constants C[local site][Q] as floats
+size_t plm_bt_bytes(const PlmDims &d) {
+    return (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024 + (size_t)d.blk_per_shard * 16 * d.Q * sizeof(float);
+}
 size_t plm_rt_bytes(const PlmDims &d) { return (size_t)d.nssteps * d.nnfl * 2 * 1024; }
 size_t plm_g_bytes(const PlmDims &d) { return (size_t)d.ksplit * d.nmf * d.nnfl * 1024; }
 size_t plm_slab_bytes(const PlmDims &d) { return (size_t)d.nmf * d.nnfl * 1024 + 256; }
@@ -510,6 +515,64 @@ __device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__
     if (ii > jj) return xj[((plm_bp_index(I, I, d.nb16) - d.bp_base) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
     return 0.f;
 }
+#if PLM_SPARSE_FWD
+// Sparse-MFMA layout (PLM_SPARSE_FWD, plm_internal.h).  One workgroup writes the two tiles (hi plane, lo plane) of an
+// instruction slice ci of block u.  Tile = for every state a a dense B fragment of v_smfmac_f32_16x16x64_f16, 64
+// lanes x 16 halves, stored as two 1 KB halves: slots 0-7 of every lane at fragment a, slots 8-15 at fragment Q + a
+// (the two ds_read_b128 of k_fwd).  Which (site j, state b) a slot holds follows from the instruction's operand
+// pairing (profiles/r02_smfmac_probe.txt): pair p of A lane (row, ga) multiplies B lane (n, gb = 2 (ga % 2) + p / 2),
+// slots 8 (ga / 2) + 4 (p % 2) + e, and k_fwd gives pair p of slice ci the (site, state group)
+//     gl = 4 ci + p,  site 32 u + 8 ga + gl / NG,  states 1 + 4 (gl % NG) + e  (as differences to state 0).
+// k_fwd_ref: the constant the differences leave out, C[i][a] = sum_{j != i} J_ij(a, 0) (zero in gap mode, where state 0
+// is not a model state), unscaled, behind the tiles.
+__global__ __launch_bounds__(64) void k_fwd_ref(PlmDims d, const float *__restrict__ x, const float *__restrict__ xhalo,
+                                               float *__restrict__ cref) {
+    const int b16l = blockIdx.x, b16 = d.b16_lo + b16l, r = blockIdx.y, a = blockIdx.z, t = threadIdx.x;
+    const int i = b16 * 16 + r;
+    const float *__restrict__ xj = x + d.nh_pad_l;
+    double s = 0;
+    if (!d.gap_mode && i < d.L)
+        for (int j = t; j < d.L; j += 64)
+            if (j != i) s += (double)load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (t == 0) cref[((size_t)b16l * 16 + r) * d.Q + a] = (float)s;
+}
+__global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restrict__ x,
+                                               const float *__restrict__ xhalo,
+                                               const int32_t *__restrict__ jexp, _Float16 *__restrict__ Bt) {
+    const int NG = PLM_FWD_NG(d.Q), SPU = 4 * NG;
+    const int u = blockIdx.x / (2 * NG), ci = blockIdx.x % (2 * NG), b16l = blockIdx.y, b16 = d.b16_lo + b16l;
+    const float sc = ldexpf(1.f, *jexp);
+    const float *__restrict__ xj = x + d.nh_pad_l;
+    _Float16 *tile_hi = Bt + ((size_t)b16l * d.nksteps + (size_t)u * SPU + 2 * ci) * (size_t)(2 * d.Q * 512);
+    _Float16 *tile_lo = tile_hi + (size_t)(2 * d.Q * 512);
+    for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
+        const int a = idx >> 6, lane = idx & 63, gb = lane >> 4, r = lane & 15;
+        const int i = b16 * 16 + r;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            half8 hi, lo;
+#pragma unroll
+            for (int e8 = 0; e8 < 8; e8++) {
+                const int ga = 2 * half + (gb >> 1), pp = 2 * (gb & 1) + (e8 >> 2), e = e8 & 3;
+                const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl % NG;
+                const int b = 4 * sg + e + 1, j = 32 * u + 8 * ga + s8;     // state 0 has no slot (reference state)
+                float v = 0.f;
+                if (b < d.Q && i < d.L && j < d.L && i != j) {
+                    v = load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, b);
+                    if (!d.gap_mode) v -= load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
+                    v *= sc;
+                }
+                const _Float16 h = (_Float16)v;
+                hi[e8] = h;
+                lo[e8] = (_Float16)(v - (float)h);
+            }
+            *(half8 *)(tile_hi + (size_t)(half * d.Q + a) * 512 + lane * 8) = hi;
+            *(half8 *)(tile_lo + (size_t)(half * d.Q + a) * 512 + lane * 8) = lo;
+        }
+    }
+}
+#else
 __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restrict__ x,
                                                const float *__restrict__ xhalo,
                                                const int32_t *__restrict__ jexp, _Float16 *__restrict__ Bt) {
@@ -537,11 +600,16 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
         *(half8 *)(tile + (size_t)(d.Q + a) * 512 + lane * 8) = lo;
     }
 }
+#endif
 hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhalo, const int32_t *jexp, void *Bt,
                              hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_expand, dim3(d.nksteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
+    hipLaunchKernelGGL(k_expand, dim3(PLM_SPARSE_FWD ? d.nksteps / 2 : d.nksteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
                        (_Float16 *)Bt);
+#if PLM_SPARSE_FWD
+    hipLaunchKernelGGL(k_fwd_ref, dim3(d.b16_hi - d.b16_lo, 16, d.Q), dim3(64), 0, st, d, x, xhalo,
+                       (float *)((char *)Bt + (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024));
+#endif
     return hipGetLastError();
 }
 
@@ -580,8 +648,8 @@ template <int Q> struct FwdRing {
     static constexpr int R = (Q % 3 == 0) ? 3 : (Q % 4 == 0) ? 4 : Q;
 };
 template <int Q, int A>
-__device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb, u32 lbn,
-                                          half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
+__device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, int i0, int i1, u32 lb,
+                                          u32 lbn, half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
                                           const DmaPlan &dma) {
     constexpr int R = FwdRing<Q>::R, MID = (Q - 2) / 2, NP = (2 * Q + 7) / 8;
     if constexpr ((PLM_ABLATE & 4) != 0) {
@@ -596,6 +664,18 @@ __device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, c
     }
     constexpr int newer = PLM_PIPE ? 4 : (A + 2 < Q) ? 4 : (A + 1 < Q) ? 2 : 0;
     if constexpr ((PLM_ABLATE & 4) == 0) lds_wait<newer>(bh[A % R], bl[A % R]);
+#if PLM_SPARSE_FWD
+    // the two LDS reads of the fragment are the two halves of one 16-half dense B operand; a0 / a1 are compressed
+    // one-hot fragments (8 halves + 2-bit positions i0 / i1): one instruction per row fragment covers 64 dense K slots
+    const half16 bb = __builtin_shufflevector(bh[A % R], bl[A % R], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    acc[0][A] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(a0, bb, acc[0][A], i0, 0, 0);
+    if constexpr (PLM_PIPE && A == MID) {
+        vm_wait<0>();
+        barrier_raw();
+    }
+    dma_at<Q, A, NP, PLM_DMA_STAGGER_FWD>(dma);
+    acc[1][A] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(a1, bb, acc[1][A], i1, 0, 0);
+#else
     acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh[A % R], acc[0][A], 0, 0, 0);
     acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[A % R], acc[1][A], 0, 0, 0);
     if constexpr (PLM_PIPE && A == MID) {
@@ -605,10 +685,11 @@ __device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, c
     dma_at<Q, A, NP, PLM_DMA_STAGGER_FWD>(dma);  // PLM_PIPE: tile t+2 -> the buffer of tile t-1; else tile t+1 -> the other buffer
     acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[A % R], acc[0][A], 0, 0, 0);
     acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[A % R], acc[1][A], 0, 0, 0);
+#endif
 }
 template <int Q, int... A>
-__device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, u32 lb, u32 lbn,
-                                          half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
+__device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, int i0, int i1, u32 lb,
+                                          u32 lbn, half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
                                           const DmaPlan &dma, std::integer_sequence<int, A...>) {
     if constexpr (!PLM_PIPE) {
         bh[0] = lds_read_b128<0>(lb);
@@ -616,7 +697,7 @@ __device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, c
         bh[1] = lds_read_b128<1024>(lb);
         bl[1] = lds_read_b128<(Q + 1) * 1024>(lb);
     }
-    (fwd_state<Q, A>(acc, a0, a1, lb, lbn, bh, bl, dma), ...);
+    (fwd_state<Q, A>(acc, a0, a1, i0, i1, lb, lbn, bh, bl, dma), ...);
 }
 
 template <int Q, int MODE>
@@ -646,8 +727,16 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
         acc[0][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#if PLM_SPARSE_FWD
+    // steps of a 32-site block: 2 NG instruction slices x 2 planes; gap mode needs no special case (k_expand leaves
+    // the slots of state 0 zero)
+    constexpr int NG = PLM_FWD_NG(Q), SPU = 4 * NG, gap = 0;
+    const int nsteps = d.nu * SPU;
+#else
     // gap mode: the K steps of state 0 are skipped altogether (gapped neighbours contribute nothing)
+    constexpr int SPU = Q;
     const int gap = d.gap_mode, Qe = Q - gap, nsteps = d.nu * Qe;
+#endif
 #if PLM_PROBE
     unsigned long long pr_wait = 0;
     const unsigned long long pr_t0 = PROBE_NOW();
@@ -656,10 +745,10 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     int un = 0, bn = gap;
     for (int k = 0; k < NBUF - 1; k++) {
         if (k < nsteps) {
-            const DmaPlan first{bt + (size_t)(un * Q + bn) * TILE, smem + k * TILE, wave_s, 2 * Q, (u32)lane * 16, false};
+            const DmaPlan first{bt + (size_t)(un * SPU + bn) * TILE, smem + k * TILE, wave_s, 2 * Q, (u32)lane * 16, false};
             dma_issue_all<NP>(first);
         }
-        if (++bn == Q) { bn = gap; ++un; }
+        if (++bn == SPU) { bn = gap; ++un; }
     }
     u64 na0 = *(const u64 *)(A.msa_rm + arow0), na1 = *(const u64 *)(A.msa_rm + arow1);   // bytes of the NEXT u
     half8 bh[R], bl[R];
@@ -683,7 +772,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             load_b64_inplace(na0, A.msa_rm, arow0 + 32 * (u + 1));
             load_b64_inplace(na1, A.msa_rm, arow1 + 32 * (u + 1));
         }
-        for (int b = gap; b < Q; ++b, ++t) {
+        for (int b = gap; b < SPU; ++b, ++t) {
             if constexpr (!PLM_PIPE) {
 #if PLM_PROBE
                 const unsigned long long pa = PROBE_NOW();
@@ -698,23 +787,45 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             }
             const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
             const int tgt = PLM_PIPE ? ((nxt + 1 == NBUF) ? 0 : nxt + 1) : nxt;   // buffer of step t + NBUF - 1
-            const DmaPlan dma{bt + (size_t)(un * Q + bn) * TILE, smem + tgt * TILE, wave_s,
+            const DmaPlan dma{bt + (size_t)(un * SPU + bn) * TILE, smem + tgt * TILE, wave_s,
                               (t + NBUF - 1 < nsteps) ? 2 * Q : 0, (u32)lane * 16, wave_s >= 4};
             const u32 lb = lds_addr(smem + cur * TILE + lane * 16), lbn = lds_addr(smem + nxt * TILE + lane * 16);
+#if PLM_SPARSE_FWD
+            // compressed one-hot fragments of instruction slice ci = b / 2 (the two planes of a slice share them):
+            // pair p = (site s8, state group sg) of the lane's 8 sites; value 1 in the pair's first slot when the
+            // site's state lies in the group, its 2-bit position = state % 4; the pair's second slot stays 0
+            half8 a0, a1;
+            int i0 = 0, i1 = 0;
+            {
+                const int ci = b >> 1;
+#pragma unroll
+                for (int pp = 0; pp < 4; pp++) {
+                    const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl - s8 * NG;
+                    const u32 x0 = (u32)(xa0 >> (8 * s8)) & 0xffu, x1 = (u32)(xa1 >> (8 * s8)) & 0xffu;
+                    // state x > 0 sits in slot (x - 1); x = 0 (the reference state) wraps to a group that does not exist
+                    ((u32 *)&a0)[pp] = (((x0 - 1u) >> 2) == (u32)sg) ? 0x3C00u : 0u;
+                    ((u32 *)&a1)[pp] = (((x1 - 1u) >> 2) == (u32)sg) ? 0x3C00u : 0u;
+                    i0 |= (int)(((x0 - 1u) & 3u) << (4 * pp));
+                    i1 |= (int)(((x1 - 1u) & 3u) << (4 * pp));
+                }
+            }
+#elif !(PLM_ABLATE & 8)
+            const int i0 = 0, i1 = 0;
             const u32 bb = (u32)b * 0x01010101u;
-#if !(PLM_ABLATE & 8)
             const half8 a0 = onehot8((u32)xa0, (u32)(xa0 >> 32), bb);
             const half8 a1 = onehot8((u32)xa1, (u32)(xa1 >> 32), bb);
 #else
+            const int i0 = 0, i1 = 0;
+            const u32 bb = (u32)b * 0x01010101u;
             half8 a0, a1;
             ((u32 *)&a0)[0] = (u32)xa0; ((u32 *)&a0)[1] = (u32)(xa0 >> 32); ((u32 *)&a0)[2] = bb; ((u32 *)&a0)[3] = (u32)xa1;
             ((u32 *)&a1)[0] = (u32)xa1; ((u32 *)&a1)[1] = (u32)(xa1 >> 32); ((u32 *)&a1)[2] = bb; ((u32 *)&a1)[3] = (u32)xa0;
 #endif
             // software pipeline: the B fragments of state a+2 are in flight while state a computes
             // (without it hipcc waits lgkmcnt(0) before every group of 4 MFMAs: LDS latency x21)
-            fwd_kstep<Q>(acc, a0, a1, lb, lbn, bh, bl, dma, std::make_integer_sequence<int, Q>{});
+            fwd_kstep<Q>(acc, a0, a1, i0, i1, lb, lbn, bh, bl, dma, std::make_integer_sequence<int, Q>{});
             cur = nxt;
-            if (++bn == Q) { bn = gap; ++un; }
+            if (++bn == SPU) { bn = gap; ++un; }
         }
     }
     if constexpr (PLM_PIPE) {   // the last step read two fragments past the end: let them land before the
@@ -731,16 +842,25 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     }
 #endif
 
+    // reference-state constants of the lane's site (sparse formulation; see plm_internal.h), zero otherwise
+#if PLM_SPARSE_FWD
+    const float *cref = (const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE) + ((size_t)b16l * 16 + r) * Q;
+#define PLM_CREF(a) cref[a]
+#else
+#define PLM_CREF(a) 0.f
+#endif
     if constexpr (MODE == FWD_STORE) {
         const float sc = ldexpf(1.f, -(*A.jexp));
         float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + wave) * 2 * Q * 64 + lane;
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int a = 0; a < Q; a++) {
+            const float c = PLM_CREF(a);
 #pragma unroll
-            for (int a = 0; a < Q; a++) {
+            for (int m = 0; m < 2; m++) {
                 const f32x4 v = acc[m][a];
-                hj[(size_t)(m * Q + a) * 64] = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+                hj[(size_t)(m * Q + a) * 64] = make_float4(fmaf(v[0], sc, c), fmaf(v[1], sc, c), fmaf(v[2], sc, c), fmaf(v[3], sc, c));
             }
+        }
         return;
     }
     {
@@ -759,13 +879,14 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 for (int reg = 0; reg < 4; reg++) {
                     const int s = s_wave + 16 * m + 4 * g + reg;
                     const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
-                    float ej = 0.f, eh = 0.f;
+                    float ej = 0.f, eh = 0.f, ec = 0.f;
 #pragma unroll
                     for (int a = 0; a < Q; a++) {
                         ej = (a == xi) ? acc[m][a][reg] : ej;
                         eh = (a == xi) ? hv[a] : eh;
+                        ec = (a == xi) ? PLM_CREF(a) : ec;
                     }
-                    ej *= sc;
+                    ej = fmaf(ej, sc, ec);
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) {   // sum over the 16 sites of the block (lanes r)
                         ej += __shfl_xor(ej, o, 64);
@@ -784,7 +905,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                         float *o = A.out + ((size_t)s * d.L + i) * d.Qc;   // the API's array: the problem's alphabet
 #pragma unroll
                         for (int a = 0; a < Q; a++)
-                            if (a < d.Qc) o[a] = acc[m][a][reg] * sc;
+                            if (a < d.Qc) o[a] = fmaf(acc[m][a][reg], sc, PLM_CREF(a));
                     }
                 }
             }
