@@ -4,9 +4,10 @@
 // process that evcouplings/couplings/tools.py:266 launches:
 //   k_reweight   N x N Hamming identity counts on the packed int8 alignment (VALU, integer)
 //   k_expand     parameters -> forward B operand (f16 hi/lo MFMA fragments)
-//   k_fwd        one-hot(MSA) x J on MFMA -> the coupling part of every conditional (HJ), stored for k_hpass; two
-//                more epilogues turn the same GEMM into statistical energies / potentials of sequences under a
-//                fitted model (row N2)
+//   k_fwd        one-hot(MSA) x J on the 2:4 sparse MFMA (K ordered (site, state): 4 states of one site per group
+//                of 4 slots, state 0 as reference state) -> the coupling part of every conditional (HJ), stored for
+//                k_hpass; two more epilogues turn the same GEMM into statistical energies / potentials of sequences
+//                under a fitted model (row N2).  PLM_SPARSE_FWD=0 builds the dense formulation of rounds 1-2.
 //   k_bwd        one-hot(MSA)^T x residuals on MFMA -> asymmetric gradient slab
 //   k_assemble   slab + slab^T + L2 term -> gradient, regulariser partial sums
 //   k_hpass      per-site softmax over HJ + fields -> residuals (the backward operand), -log P, and the gradient /
@@ -22,7 +23,8 @@
 // The alignment is int8 in HBM; one-hot MFMA A fragments are expanded from 8 packed bytes
 // in registers (never materialised in memory); the dense operand (couplings / residuals)
 // is split into two f16 planes (22-bit significand, power-of-two pre-scaled) and
-// accumulated in f32 by v_mfma_f32_16x16x32_f16.  Written for wave64 / gfx950 only.
+// accumulated in f32 by v_mfma_f32_16x16x32_f16 (backward) / v_smfmac_f32_16x16x64_f16 (forward).  Written for
+// wave64 / gfx950 only.
 #include "../../include/plm_hip.h"
 #include "plm_internal.h"
 #include <math.h>
