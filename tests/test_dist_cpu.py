@@ -139,3 +139,41 @@ def test_sharded_state_exchange_volumes_are_consistent():
         cross = nb * (nb + 1) // 2 - sum(k * (k + 1) // 2 + k * sum(own[i + 1:]) - k * sum(own[i + 1:])
                                          for i, k in enumerate(own))
         assert cross == sum(own[r] * own[rp] for r in range(n) for rp in range(r + 1, n))
+
+
+def _id_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from evcouplings_amd import plm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the id itself needs a GPU (ncclGetUniqueId); what is tested here is that rank 0's bytes reach every rank
+        plm.rccl_unique_id = lambda: bytes([17 + rank]) * plm.RCCL_ID_BYTES
+        q.put((rank, pdist.share_rccl_id()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_id_travels_from_rank_zero_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(got[r] == bytes([17]) * 128 for r in range(3))
+
+
+def test_native_rccl_switch(monkeypatch):
+    monkeypatch.delenv("PLM_NATIVE_RCCL", raising=False)
+    assert not pdist.native_rccl_requested()
+    monkeypatch.setenv("PLM_NATIVE_RCCL", "0")
+    assert not pdist.native_rccl_requested()
+    monkeypatch.setenv("PLM_NATIVE_RCCL", "1")
+    assert pdist.native_rccl_requested()
