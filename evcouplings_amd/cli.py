@@ -10,6 +10,12 @@ An unmodified EVcouplings can use the GPU solver by pointing ``tools.plmc`` at t
 launches it and regex-parses stderr (tools.py:20-108, 286).  This shim accepts exactly that
 argv, writes the two files and prints the log lines the parser needs on stderr.  Exit code
 0 on success, 1 on failure (with the reason on stderr).
+
+`-n CPUS` is plmc's thread count: accepted and ignored.  Options plmc does not have (an unmodified pipeline sets the
+environment variables instead): `--solver vp|joint` (PLM_HIP_SOLVER: "joint" = L-BFGS over fields and couplings
+together as libLBFGS-based plmc runs it; "vp" = variable projection, the default), `--gpus N|max` (PLM_HIP_GPUS: GPUs of
+this node to shard the fit over), `--epsilon E` (stop rule |g|/max(1,|x|) < E, default 1e-3),
+`--conventions BITS` (PLM_HIP_CONVENTIONS).
 """
 import sys
 
@@ -17,7 +23,8 @@ USAGE = __doc__
 
 _WITH_VALUE = {"-c": "couplings_file", "-o": "param_file", "-f": "focus_seq", "-m": "iterations",
                "-a": "alphabet", "-t": "theta_div", "-s": "scale", "-lh": "lambda_h", "-le": "lambda_J",
-               "-lg": "lambda_g", "-n": "cpu"}
+               "-lg": "lambda_g", "-n": "cpu", "--solver": "solver", "--gpus": "gpus", "--epsilon": "epsilon",
+               "--conventions": "conventions"}
 
 
 def parse_argv(argv):
@@ -48,7 +55,9 @@ def parse_argv(argv):
     if "couplings_file" not in opts:
         raise ValueError("-c <couplings file> is required")
     opts["alignment"] = positional[0]
-    for key in ("scale", "lambda_h", "lambda_J", "lambda_g", "theta_div"):
+    if "conventions" in opts:
+        opts["conventions"] = int(opts["conventions"], 0)
+    for key in ("scale", "lambda_h", "lambda_J", "lambda_g", "theta_div", "epsilon"):
         if key in opts:
             opts[key] = float(opts[key])
     if "iterations" in opts and opts["iterations"].lower() != "max":
@@ -76,7 +85,8 @@ def main(argv=None):
             focus_seq=opts.get("focus_seq"), alphabet=opts.get("alphabet"), theta=theta,
             scale=opts.get("scale"), ignore_gaps=opts["ignore_gaps"], iterations=opts.get("iterations"),
             lambda_h=opts.get("lambda_h"), lambda_J=opts.get("lambda_J"), lambda_g=opts.get("lambda_g"),
-            cpu=opts.get("cpu"))
+            cpu=opts.get("cpu"), solver=opts.get("solver"), gpus=opts.get("gpus"), epsilon=opts.get("epsilon"),
+            conventions=opts.get("conventions"))
     except Exception as exc:
         sys.stderr.write("plmc_hip: %s: %s\n" % (type(exc).__name__, exc))
         return 1

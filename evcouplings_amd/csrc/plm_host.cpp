@@ -333,11 +333,17 @@ int ctx_eval_enqueue(plm_ctx *c) {
 // and returns dF/dJ = df/dJ at (h*(J), J) (envelope theorem).  x's field part is overwritten with h*(J); the
 // field part of g is zero.  scal[SL_GH2 = 5] = squared gradient norm of the field subproblems at the returned point.
 bool vp_enabled(const plm_ctx *c) {
-    return !(c->prob.flags & PLM_FLAG_JOINT_LBFGS) && (c->d.nshards == 1 || c->d.sharded);
+    // lambda_h = 0: the per-site Hessians are singular along the softmax gauge direction (the Newton solver has no
+    // pivoting) -- such a problem runs the joint path
+    return !(c->prob.flags & PLM_FLAG_JOINT_LBFGS) && (c->d.nshards == 1 || c->d.sharded) && c->prob.lambda_h > 0;
 }
 int vp_alloc(plm_ctx *c) {
     if (c->hj) return PLM_OK;
-    const size_t nsites = (size_t)std::max(1, (c->d.b16_hi - c->d.b16_lo) * 16);
+    // per-site buffers are indexed by i - h_site0 over the LOCAL FIELD PART: the shard's own sites in sharded-state
+    // mode, but all L sites in the replicated multi-shard mode (own_lo = 0, own_hi = nb16), where the shard's own
+    // column blocks are only a slice of them (h64 is filled and read for every site by forward_at_x)
+    const size_t nsites = (size_t)std::max(std::max(1, (c->d.b16_hi - c->d.b16_lo) * 16),
+                                           std::min(c->d.L, c->d.own_hi * 16) - c->d.h_site0);
     PLM_TRY(dalloc((char **)&c->hj, plm_hj_bytes(c->d)));
     PLM_TRY(dalloc((char **)&c->hpart, plm_hpart_bytes(c->d)));
     PLM_TRY(dalloc((char **)&c->gpart, plm_gpart_bytes(c->d)));
@@ -435,7 +441,8 @@ int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
         const double gh2 = c->h_scal[5];
         *gh2_out = gh2;
         rounds = round;
-        if (getenv("PLM_DEBUG_VP"))
+        static const bool debug_vp = getenv("PLM_DEBUG_VP") != nullptr;   // read once per process
+        if (debug_vp)
             fprintf(stderr, "[plm vp] eval %d round %d: newton=%d hess_age=%d |g_h|=%.3e tol=%.3e\n", c->n_evals, round,
                     newton, c->vp_hess_age, std::sqrt(gh2), std::sqrt(tol2));
         // done: converged, or not finite (the line search deals with that), or no longer improving (f32 floor)
@@ -1113,7 +1120,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     c->eval_valid = false;
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
-    if (std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx)) > eps) {
+    double last_cond = std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx));   // |g|/max(1,|x|) at the last accepted point
+    if (last_cond > eps) {
         // first step: unit displacement along the plain gradient; the D^-1-scaled direction is Newton-like for the
         // diagonal part of the Hessian, so it starts from min(1, that)
         auto first_step = [&]() { return precond ? std::min(1.0, 1.0 / std::sqrt(gDg)) : 1.0 / std::sqrt(gg); };
@@ -1261,7 +1269,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             if (cb)
                 cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
                    std::sqrt(std::max(0.0, xx - hh)), user);
-            if (gnorm / std::max(1.0, xnorm) <= eps) { status = PLM_STATUS_CONVERGED; break; }
+            last_cond = gnorm / std::max(1.0, xnorm);
+            if (last_cond <= eps) { status = PLM_STATUS_CONVERGED; break; }
             if (max_iter > 0 && k >= max_iter) { status = PLM_STATUS_MAXITER; break; }
             if (SY[e * m + e] > 0) {   // curvature pair accepted (always true under the Wolfe conditions)
                 stored = nst;
@@ -1286,8 +1295,14 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         res->fx = fx;
         res->n_eff = (float)c->n_eff;
         res->seconds_optimize = now_s() - t0;
+        // a fit that did not meet the stop rule says how far it got: the reference records this string as
+        // `optimization_status` (couplings/tools.py:99), the only place a pipeline user sees it
         if (status == PLM_STATUS_LINESEARCH)
-            snprintf(res->status_msg, sizeof res->status_msg, "%s [code %d]", status_text(status), ls_reason);
+            snprintf(res->status_msg, sizeof res->status_msg, "%s [code %d]; |g|/max(1,|x|) = %.3e", status_text(status),
+                     ls_reason, last_cond);
+        else if (status == PLM_STATUS_MAXITER)
+            snprintf(res->status_msg, sizeof res->status_msg, "%s; |g|/max(1,|x|) = %.3e (epsilon %.1e)",
+                     status_text(status), last_cond, eps);
         else
             snprintf(res->status_msg, sizeof res->status_msg, "%s", status_text(status));
     }
@@ -1654,6 +1669,9 @@ int plm_alignment_stats(const int8_t *msa, int32_t n, int32_t L, int32_t gap_sta
     if (gap_state < 0 || gap_state > 126) return fail(PLM_EINVAL, "gap state outside 0..126");
     for (size_t k = 0; k < (size_t)n * L; k++)
         if (msa[k] < 0) return fail(PLM_EINVAL, "msa[%zu] is negative", k);     // the packed compare needs bytes < 0x80
+    if (query)
+        for (int k = 0; k < L; k++)
+            if (query[k] < 0) return fail(PLM_EINVAL, "query[%d] is negative (states must be 0..127)", k);
     PLM_TRY(check_device(device));
     hipStream_t st = (hipStream_t)stream;
     int8_t *dm = nullptr, *dq = nullptr;

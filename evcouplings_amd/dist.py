@@ -215,24 +215,29 @@ def fit_distributed(msa, q=21, group=None, sharded_state=True, transport=None, *
                    **kwargs)
 
 
-def resolve_gpu_count(cpu=None):
-    """How many GPUs a run_plmc-style call should use.  plmc's `cpu` option (threads, tools.py:257-259; int or
-    "max") is read as the number of GPUs, capped by what is visible; the environment variable PLM_HIP_GPUS overrides
-    it (PLM_HIP_GPUS=1 pins the single-GPU path whatever the pipeline configuration says)."""
-    import os
+def resolve_gpu_count(cpu=None, gpus=None):
+    """How many GPUs a run_plmc-style call uses.  Multi-GPU is opt-in: `gpus` (explicit keyword), else the environment
+    variable PLM_HIP_GPUS -- an integer, "max" (every visible GPU) or "cpu" (read plmc's `cpu` option, threads for
+    plmc -n, tools.py:257-259, as the number of GPUs) -- else 1.  A pipeline-wide `cpu: N` therefore never starts GPU
+    ranks by itself.  The count is capped by the visible devices."""
     from evcouplings_amd import plm
-    env = os.environ.get("PLM_HIP_GPUS")
-    want = env if env not in (None, "") else cpu
+    env = os.environ.get("PLM_HIP_GPUS", "")
+    want = gpus if gpus is not None else (env if env != "" else None)
+    if isinstance(want, str) and want.lower() == "cpu":
+        want = cpu
     if want is None:
         return 1
-    have = max(1, plm.device_count())
     if isinstance(want, str) and want.lower() == "max":
-        return have if env in (None, "") else have
+        return max(1, plm.device_count())
     n = max(1, int(want))
-    # an explicit PLM_HIP_GPUS may exceed the visible devices only for the gloo flow test (ranks share GPUs)
-    if env not in (None, "") and os.environ.get("PLM_DIST_BACKEND", "nccl") != "nccl":
+    # the gloo flow test folds ranks onto the visible GPUs: the count may exceed them there
+    if os.environ.get("PLM_DIST_BACKEND", "nccl") != "nccl":
         return n
-    return min(n, have)
+    return min(n, max(1, plm.device_count()))
+
+
+class LaunchError(RuntimeError):
+    """The multi-GPU child job ended without a result."""
 
 
 def launch_fit(msa, n_gpus, q=21, timeout=None, **kwargs):
@@ -249,9 +254,6 @@ def launch_fit(msa, n_gpus, q=21, timeout=None, **kwargs):
     import tempfile
     kwargs = {k: v for k, v in kwargs.items() if k != "callback"}
     kwargs["q"] = int(q)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     with tempfile.TemporaryDirectory(prefix="plm_dist_") as tmp:
         src, dst = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
         np.savez(src, msa=np.ascontiguousarray(msa, dtype=np.int8), kwargs=json.dumps(kwargs))
@@ -259,11 +261,24 @@ def launch_fit(msa, n_gpus, q=21, timeout=None, **kwargs):
         env = dict(os.environ)
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "evcouplings_amd.dist_worker", src, dst]
-        run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        run = None
+        for attempt in range(3):
+            # a free port is found by binding and releasing it; another process can take it in between, so a
+            # rendezvous that dies with "address already in use" is retried on a fresh port
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "evcouplings_amd.dist_worker", src,
+                   dst]
+            try:
+                run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+            except (OSError, subprocess.TimeoutExpired) as exc:
+                raise LaunchError("multi-GPU fit could not run: %r" % (exc,))
+            if run.returncode == 0 or "ddress already in use" not in (run.stderr or ""):
+                break
         if run.returncode != 0 or not os.path.exists(dst):
-            raise RuntimeError("multi-GPU fit failed (exit %d):\n%s\n%s" % (run.returncode, run.stdout[-2000:],
+            raise LaunchError("multi-GPU fit failed (exit %d):\n%s\n%s" % (run.returncode, run.stdout[-2000:],
                                                                             run.stderr[-4000:]))
         z = np.load(dst)
         res = {k: z[k] for k in z.files if k not in ("table", "meta")}

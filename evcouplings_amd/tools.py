@@ -84,11 +84,32 @@ def _valid_file(path):
         return False
 
 
+SOLVERS = ("vp", "joint")
+
+
+def solver_from_env(solver=None):
+    """Which optimiser a run_plmc-style call uses: explicit value, else the environment variable PLM_HIP_SOLVER (for an
+    unmodified pipeline; same pattern as PLM_HIP_CONVENTIONS), else "vp".
+      "vp"     variable projection (default): fields solved by Newton for every trial couplings, L-BFGS over the
+               couplings -- reaches the optimum in ~20x fewer iterations;
+      "joint"  L-BFGS over fields and couplings together, the route libLBFGS-based plmc takes (PLM_FLAG_JOINT_LBFGS):
+               choose it when the iterate at a FIXED iteration count (the reference default is 100,
+               config/sample_config_monomer.txt:149) should be plmc-like rather than converged."""
+    if solver is None:
+        solver = os.environ.get("PLM_HIP_SOLVER", "") or "vp"
+    solver = str(solver).lower()
+    if solver not in SOLVERS:
+        raise ValueError("solver must be one of %s, got %r" % ("/".join(SOLVERS), solver))
+    return solver
+
+
 def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, alphabet=None, theta=None,
                    scale=None, ignore_gaps=False, iterations=None, lambda_h=None, lambda_J=None,
                    lambda_g=None, cpu=None, epsilon=None, lbfgs_m=6, device=0, distributed=False,
-                   callback=None, conventions=None):
-    """Does the work of run_plmc_hip and additionally returns the raw fit dict and the log text."""
+                   callback=None, conventions=None, solver=None, gpus=None):
+    """Does the work of run_plmc_hip and additionally returns the raw fit dict and the log text.
+    Extensions over run_plmc's parameters: `solver` ("vp" | "joint", default from PLM_HIP_SOLVER), `gpus` (number of
+    GPUs of this node to shard the fit over, default from PLM_HIP_GPUS, else 1), `epsilon`, `lbfgs_m`, `conventions`."""
     from evcouplings_amd import plm   # imports the HIP library: fails loudly if it is not built
 
     if not _valid_file(alignment):
@@ -110,13 +131,22 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
             raise ExternalToolError("iterations must be an integer or 'max', got {!r}".format(iterations))
         iterations = 0                       # until converged (tools.py:226-228 lets "max" through)
     iterations = int(iterations)
-    # `cpu` (threads for plmc -n, tools.py:257-259; int or "max") is read as the number of GPUs of this node to shard
-    # the fit over (capped by the visible devices; PLM_HIP_GPUS overrides it)
+    # `cpu` is plmc's OpenMP thread count (tools.py:257-259; int or "max"): validated, otherwise ignored -- a
+    # pipeline-wide `cpu: N` must not start N GPU ranks.  Multi-GPU is opt-in: `gpus=` here, or PLM_HIP_GPUS=N|max
+    # for an unmodified pipeline (PLM_HIP_GPUS=cpu reads the cpu option as the GPU count).
     from evcouplings_amd import dist as _dist
+    if cpu is not None and not (isinstance(cpu, str) and cpu.lower() == "max"):
+        try:
+            int(cpu)
+        except (TypeError, ValueError):
+            raise ExternalToolError("cpu must be an integer or 'max', got {!r}".format(cpu))
     try:
-        n_gpus = 1 if distributed else _dist.resolve_gpu_count(cpu)
-    except (TypeError, ValueError):
-        raise ExternalToolError("cpu must be an integer or 'max', got {!r}".format(cpu))
+        n_gpus = 1 if distributed else _dist.resolve_gpu_count(cpu, gpus)
+        solver = solver_from_env(solver)
+    except (TypeError, ValueError) as exc:
+        raise ExternalToolError(str(exc))
+    except Exception as exc:       # library missing / no device: the same error type every other solver failure has
+        raise ExternalToolError("HIP PLM solver failed: {}".format(exc))
 
     try:
         enc = alignment_io.encode_alignment(alignment, focus_seq=focus_seq, alphabet=alphabet)
@@ -127,14 +157,21 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
     fit_kwargs = dict(q=q, ignore_gaps=bool(ignore_gaps), theta_id=theta, scale=scale, lambda_h=lambda_h, lambda_j=lambda_J,
                       max_iter=iterations, epsilon=DEFAULTS["epsilon"] if epsilon is None else float(epsilon),
-                      lbfgs_m=lbfgs_m, callback=callback,
+                      lbfgs_m=lbfgs_m, callback=callback, joint=(solver == "joint"),
                       # PLM_CONV_* switches: explicit, or the environment variable PLM_HIP_CONVENTIONS
                       conventions=plm.conventions_from_env(conventions))
     try:
         if distributed:
             res = _dist.fit_distributed(enc.msa, **fit_kwargs)
         elif n_gpus > 1:
-            res = _dist.launch_fit(enc.msa, n_gpus, **fit_kwargs)     # N ranks under torch.distributed.run
+            try:
+                res = _dist.launch_fit(enc.msa, n_gpus, **fit_kwargs)     # N ranks under torch.distributed.run
+            except _dist.LaunchError as exc:
+                # the job never produced a result (torch / RCCL missing, a rank died): the single-GPU fit computes
+                # the same thing, only slower -- still the HIP path, never a CPU path
+                import warnings
+                warnings.warn("multi-GPU fit on %d GPUs failed, running on one GPU instead: %s" % (n_gpus, exc))
+                res = plm.fit(enc.msa, device=device, **fit_kwargs)
         else:
             res = plm.fit(enc.msa, device=device, **fit_kwargs)
     except Exception as exc:   # PlmError, ImportError (library missing), ...
@@ -176,14 +213,17 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
 def run_plmc_hip(alignment, couplings_file, param_file=None, focus_seq=None, alphabet=None, theta=None,
                  scale=None, ignore_gaps=False, iterations=None, lambda_h=None, lambda_J=None,
-                 lambda_g=None, cpu=None, binary=None):
+                 lambda_g=None, cpu=None, binary=None, solver=None, gpus=None):
     """
     Drop-in for ``run_plmc`` (evcouplings/couplings/tools.py:126-130): same parameters (``theta``
     is the identity threshold, e.g. 0.8 -- no 1-theta round trip, tools.py:236-239; ``binary``
-    is ignored), same ``PlmcResult``, ``ResourceError`` for missing inputs/outputs and
-    ``ExternalToolError`` for solver failures.
+    is ignored; ``cpu``, plmc's thread count, is validated and ignored), same ``PlmcResult``, ``ResourceError`` for
+    missing inputs/outputs and ``ExternalToolError`` for solver failures.  Two keyword extensions, both also
+    selectable from the environment of an unmodified pipeline: ``solver`` ("vp" | "joint"; PLM_HIP_SOLVER) and
+    ``gpus`` (GPUs of this node to shard the fit over; PLM_HIP_GPUS).
     """
     result, _, _ = infer_to_files(alignment, couplings_file, param_file, focus_seq=focus_seq, alphabet=alphabet,
                                   theta=theta, scale=scale, ignore_gaps=ignore_gaps, iterations=iterations,
-                                  lambda_h=lambda_h, lambda_J=lambda_J, lambda_g=lambda_g, cpu=cpu)
+                                  lambda_h=lambda_h, lambda_J=lambda_J, lambda_g=lambda_g, cpu=cpu, solver=solver,
+                                  gpus=gpus)
     return result

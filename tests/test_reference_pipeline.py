@@ -282,7 +282,17 @@ def test_align_stage_descriptions_through_the_drop_ins(ref, golden_dir, monkeypa
         keep, lc = alignment_accel.alignment_filters(z["mapped"], 0, int(z["min_seq"]), float(z["min_col"]))
         np.testing.assert_array_equal(keep, z["keep_seqs"])
         np.testing.assert_array_equal(lc, z["lc_cols"])
-        kept = ali.select(sequences=keep)
+        # the reference's own filter expressions (align/protocol.py:906-912, 941) through the installed Alignment.count
+        assert ref_ali.Alignment.count is alignment_accel.alignment_count
+        np.testing.assert_array_equal(ali.count("-", axis="seq"), z["seq_gap_frac"])
+        np.testing.assert_array_equal(ali.count("-", axis="pos"), z["col_gap_frac"])
+        assert ali.count("-", axis="pos", normalize=False).dtype == np.int64
+        keep2 = (1 - ali.count("-", axis="seq")) >= int(z["min_seq"]) / 100
+        np.testing.assert_array_equal(keep2, z["keep_seqs"])
+        kept = ali.select(sequences=keep2)
+        np.testing.assert_array_equal(kept.count(kept._match_gap, axis="pos") > 1 - float(z["min_col"]), z["lc_cols"])
+        with pytest.raises(ValueError):
+            ali.count("-", axis="rows")
         kept.set_weights(0.8)
         np.testing.assert_allclose(kept.weights, z["weights"], rtol=1e-12)
         freq = ref_prot.describe_frequencies(kept, 10, target_seq_index=0)
@@ -297,6 +307,7 @@ def test_align_stage_descriptions_through_the_drop_ins(ref, golden_dir, monkeypa
     finally:
         alignment_accel.uninstall(ref_ali)
     assert ref_ali.map_matrix.__module__.startswith("evcouplings.")      # restored
+    assert ref_ali.Alignment.count.__module__.startswith("evcouplings.")
 
 
 def _oracle_backed_plm(monkeypatch):
