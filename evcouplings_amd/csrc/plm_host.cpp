@@ -372,7 +372,7 @@ int vp_stage1(plm_ctx *c) {
     return PLM_OK;
 }
 // stage 2: `newton` Newton steps on the fields from their current values, then the residual pass at the result
-// (Rt, -log P partials) with the gradient norm of the field subproblems -> scal[5].  refresh: the first step
+// (Rt, -log P partials; only with write_rt) with the gradient norm of the field subproblems -> scal[5].  refresh: the first step
 // recomputes the per-site Hessians (a pass with more arithmetic), otherwise the cached inverses are reused.
 // reuse: hpart still holds the gradient sums of the residual pass at the current fields (a previous stage 2 that did
 // not meet the tolerance), so the first step needs no pass of its own.
@@ -381,7 +381,7 @@ int vp_stage1(plm_ctx *c) {
 // raised flag return at once, per-site convergence, the backward GEMM conditional on the flag) was built and
 // measured: no host round trips, but it needs more passes per evaluation (3.2 s vs 2.95 s for the headline fit).
 // The kernels keep the hooks (skip / run flags); this host logic does not use them.
-int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse) {
+int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse, bool write_rt) {
     const PlmDims &d = c->d;
     HIP_TRY(hipMemsetAsync(c->vp_flag, 0, sizeof(int), c->st));
     // slots 6, 7 (pass counter and verdict of k_vp_check) lie inside the all-reduced scalar range: a counter that is
@@ -397,7 +397,11 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse) {
         c->vp_hess_age = full ? 0 : c->vp_hess_age + 1;
     }
     c->vp_newton_total += newton;
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->Rt, c->fx_part, c->hpart, c->gpart, nullptr, c->st));
+    // the pass at the result: gradient sums for the convergence check (and for the next round's first step); with
+    // write_rt also the residual fragments and -log P partials -- 1.29 GB of writes that only the LAST round's pass
+    // needs to make (ctx_eval_vp decides which rounds write speculatively)
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, write_rt ? 1 : 0, 1, write_rt ? c->Rt : nullptr,
+                             write_rt ? c->fx_part : nullptr, c->hpart, c->gpart, nullptr, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
                               c->vp_flag, c->st));
     return PLM_OK;
@@ -429,27 +433,38 @@ int fetch_scalars(plm_ctx *c, int first, int count);
 // f32 floor); the check costs one extra host synchronisation per evaluation (sharded: one scalar all-reduce)
 int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
     PLM_TRY(vp_stage1(c));
-    double prev = INFINITY;
+    double prev = INFINITY, gh2 = INFINITY;
     int newton = *newton_io, rounds = 0;
+    bool rt_current = false;   // Rt / fx_part were written at the fields the solver stopped at
+    static const bool debug_vp = getenv("PLM_DEBUG_VP") != nullptr;   // read once per process
     for (int round = 0;; round++) {
         // Hessians: refreshed when none exist, periodically, and whenever a round with the cached ones fell short
         const bool refresh = c->vp_hess_age < 0 ||
                              (round == 0 ? (c->vp_hess_age >= 64 || c->vp_refresh_next) : c->vp_hess_age > 0);
-        PLM_TRY(vp_stage2(c, newton, refresh && newton > 0, round > 0));
+        // Only the last round's pass has to write the residual fragments.  Round 0 writes them speculatively (late in
+        // a fit it is the only round); a later round does so when the contraction seen so far says it will meet the
+        // tolerance (a Newton step with the sampled Hessians shrinks |g_h|^2 ~100-fold), else its pass is the cheaper
+        // statistics-only one and the fragments are written once, after the loop.
+        const double rate = (round > 1 && prev < INFINITY && gh2 < prev) ? std::max(1e-4, gh2 / prev) : 1e-4;
+        const bool write_rt = round == 0 || gh2 * rate <= tol2;
+        prev = gh2;
+        PLM_TRY(vp_stage2(c, newton, refresh && newton > 0, round > 0, write_rt));
         PLM_TRY(ctx_allreduce_scalars(c, 5, 1));
         PLM_TRY(fetch_scalars(c, 5, 1));
-        const double gh2 = c->h_scal[5];
+        gh2 = c->h_scal[5];
         *gh2_out = gh2;
         rounds = round;
-        static const bool debug_vp = getenv("PLM_DEBUG_VP") != nullptr;   // read once per process
+        rt_current = write_rt;
         if (debug_vp)
-            fprintf(stderr, "[plm vp] eval %d round %d: newton=%d hess_age=%d |g_h|=%.3e tol=%.3e\n", c->n_evals, round,
-                    newton, c->vp_hess_age, std::sqrt(gh2), std::sqrt(tol2));
+            fprintf(stderr, "[plm vp] eval %d round %d: newton=%d hess_age=%d |g_h|=%.3e tol=%.3e rt=%d\n", c->n_evals, round,
+                    newton, c->vp_hess_age, std::sqrt(gh2), std::sqrt(tol2), (int)write_rt);
         // done: converged, or not finite (the line search deals with that), or no longer improving (f32 floor)
         if (!(gh2 > tol2) || round >= 8 || (round > 1 && gh2 > 0.25 * prev)) break;
-        prev = gh2;
         newton = 2;
     }
+    if (!rt_current)   // the last round ended on a statistics-only pass: residual fragments and -log P at its fields
+        HIP_TRY(plm_launch_hpass(c->d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr,
+                                 c->st));
     // steps to try first at the next trial point: one more if this one needed extra rounds, one fewer (down to
     // none: the L-BFGS extrapolation of the fields is then good enough) if it met the tolerance with room to spare
     c->vp_refresh_next = rounds > 0;   // the cached Hessians were too stale for this step size: start fresh next time
@@ -1380,7 +1395,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         if (vp) {   // the fit's pipeline: forward GEMM -> HJ, 2 Newton steps on the fields, residual pass
             HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
             HIP_TRY(hipEventRecord(ev[2], c->st));
-            PLM_TRY(vp_stage2(c, 1, r == 0, false));   // one Newton step + the residual pass
+            PLM_TRY(vp_stage2(c, 1, r == 0, false, true));   // one Newton step + the residual pass
             HIP_TRY(hipEventRecord(ev[5], c->st));
         } else {
             PLM_TRY(forward_at_x(c));

@@ -916,147 +916,6 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     }
 }
 
-#if PLM_SPARSE_FWD
-// =========================================================================================
-// k_fwd4 (PLM_FWD_ROWS4=1, NOT YET RUN ON A GPU -- prepared for the next round): the
-// store-mode forward GEMM with the tile of a workgroup split the other way.  k_fwd gives each of its 8 waves 32
-// sequences x all Q states, so every wave reads the whole 42 KB tile of a K step from LDS (8 x 42 ds_read_b128 per
-// step) -- with the sparse MFMA that stream, not the matrix cores, bounds the kernel.  Here wave w owns the 64
-// sequences of group w & 3 and the states of half w >> 2 (ceil(Q/2) for half 0, floor(Q/2) for half 1): every B
-// fragment it reads feeds 4 row fragments, LDS reads per step halve, the MFMA work and the tile stream are the same.
-// (Round 1 measured this tiling on the dense kernel -- no gain there, the MFMA pipe was the limit -- and needed two
-// LDS exchanges for the softmax over states; the store-only epilogue needs none.)  Same HJ layout as k_fwd.
-// For odd Q half 1 has one state less: it still reads the surplus fragment pair (one KB past the tile: the launcher
-// adds it) and skips its MFMAs, a wave-uniform branch.
-// =========================================================================================
-#ifndef PLM_FWD_ROWS4
-#define PLM_FWD_ROWS4 0
-#endif
-template <int Q, int K>
-__device__ __forceinline__ void fwd4_state(f32x4 (&acc)[4][(Q + 1) / 2], const half8 (&af)[4], const int (&ai)[4], u32 lb,
-                                           half8 (&bh)[3], half8 (&bl)[3], const DmaPlan &dma, bool last_live) {
-    constexpr int NS0 = (Q + 1) / 2, NP = (2 * Q + 7) / 8;
-    if constexpr (K + 2 < NS0) {
-        bh[(K + 2) % 3] = lds_read_b128<(K + 2) * 1024>(lb);
-        bl[(K + 2) % 3] = lds_read_b128<(Q + K + 2) * 1024>(lb);
-    }
-    constexpr int newer = (K + 2 < NS0) ? 4 : (K + 1 < NS0) ? 2 : 0;
-    lds_wait<newer>(bh[K % 3], bl[K % 3]);
-    if (K < NS0 - 1 || (Q % 2 == 0) || last_live) {
-        const half16 bb = __builtin_shufflevector(bh[K % 3], bl[K % 3], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-        acc[0][K] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[0], bb, acc[0][K], ai[0], 0, 0);
-        acc[1][K] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[1], bb, acc[1][K], ai[1], 0, 0);
-        dma_at<NS0, K, NP, PLM_DMA_STAGGER_FWD>(dma);
-        acc[2][K] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[2], bb, acc[2][K], ai[2], 0, 0);
-        acc[3][K] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[3], bb, acc[3][K], ai[3], 0, 0);
-    } else {
-        dma_at<NS0, K, NP, PLM_DMA_STAGGER_FWD>(dma);
-    }
-}
-template <int Q, int... K>
-__device__ __forceinline__ void fwd4_kstep(f32x4 (&acc)[4][(Q + 1) / 2], const half8 (&af)[4], const int (&ai)[4], u32 lb,
-                                           const DmaPlan &dma, bool last_live, std::integer_sequence<int, K...>) {
-    half8 bh[3], bl[3];
-    bh[0] = lds_read_b128<0>(lb);
-    bl[0] = lds_read_b128<Q * 1024>(lb);
-    bh[1] = lds_read_b128<1024>(lb);
-    bl[1] = lds_read_b128<(Q + 1) * 1024>(lb);
-    (fwd4_state<Q, K>(acc, af, ai, lb, bh, bl, dma, last_live), ...);
-}
-template <int Q>
-__global__ __launch_bounds__(512) void k_fwd4(PlmDims d, FwdArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE = 2 * Q * 1024, NP = (2 * Q + 7) / 8, NS0 = (Q + 1) / 2, NS1 = Q / 2;
-    constexpr int NG = PLM_FWD_NG(Q), SPU = 4 * NG;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sgp = wave_s & 3, sh = wave_s >> 2;           // sequence group, state half
-    const int a_lo = sh ? NS0 : 0, ns = sh ? NS1 : NS0;
-    const int ntiles = d.nstiles * (d.b16_hi - d.b16_lo), per_xcd = (ntiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);    // XCD-aware order, as k_fwd
-    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
-    const int stile = tile % d.nstiles, b16l = tile / d.nstiles;
-    const int r = lane & 15, g = lane >> 4;
-    const int s_wave = stile * PLM_SEQ_TILE + sgp * 64;
-    const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE;
-    u32 arow[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) arow[m] = (u32)(s_wave + 16 * m + r) * (u32)d.Lp32 + 8 * g;
-    f32x4 acc[4][NS0];
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int k = 0; k < NS0; k++) acc[m][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nsteps = d.nu * SPU;
-    int un = 0, bn = 0;
-    {
-        const DmaPlan first{bt, smem, wave_s, 2 * Q, (u32)lane * 16, false};
-        dma_issue_all<NP>(first);
-        if (++bn == SPU) { bn = 0; ++un; }
-    }
-    u64 na[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) na[m] = *(const u64 *)(A.msa_rm + arow[m]);
-    int t = 0, cur = 0;
-    for (int u = 0; u < d.nu; ++u) {
-        u64 xa[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            vm_landed(na[m]);
-            xa[m] = na[m];
-        }
-        if (u + 1 < d.nu) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) load_b64_inplace(na[m], A.msa_rm, arow[m] + 32 * (u + 1));
-        }
-        for (int b = 0; b < SPU; ++b, ++t) {
-            vm_wait<0>();
-            __syncthreads();
-            const int nxt = cur ^ 1;
-            const DmaPlan dma{bt + (size_t)(un * SPU + bn) * TILE, smem + nxt * TILE, wave_s,
-                              (t + 1 < nsteps) ? 2 * Q : 0, (u32)lane * 16, wave_s >= 4};
-            const u32 lb = lds_addr(smem + cur * TILE + a_lo * 1024 + lane * 16);
-            half8 af[4];
-            int ai[4];
-            {
-                const int ci = b >> 1;
-#pragma unroll
-                for (int m = 0; m < 4; m++) ai[m] = 0;
-#pragma unroll
-                for (int pp = 0; pp < 4; pp++) {
-                    const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl - s8 * NG;
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const u32 xs = (u32)(xa[m] >> (8 * s8)) & 0xffu;
-                        ((u32 *)&af[m])[pp] = (((xs - 1u) >> 2) == (u32)sg) ? 0x3C00u : 0u;
-                        ai[m] |= (int)(((xs - 1u) & 3u) << (4 * pp));
-                    }
-                }
-            }
-            fwd4_kstep<Q>(acc, af, ai, lb, dma, ns == NS0, std::make_integer_sequence<int, NS0>{});
-            cur = nxt;
-            if (++bn == SPU) { bn = 0; ++un; }
-        }
-    }
-    // ---- store HJ in k_fwd's layout: [tile][8 sequence groups of 32][2 row fragments][Q][64 lanes] float4 ----
-    const float sc = ldexpf(1.f, -(*A.jexp));
-    const float *cref = (const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE) + ((size_t)b16l * 16 + r) * Q;
-#pragma unroll
-    for (int k = 0; k < NS0; k++) {
-        if (k < ns) {
-            const int a = a_lo + k;
-            const float c = cref[a];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const f32x4 v = acc[m][k];
-                float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + 2 * sgp + (m >> 1)) * 2 * Q * 64 + lane;
-                hj[(size_t)((m & 1) * Q + a) * 64] = make_float4(fmaf(v[0], sc, c), fmaf(v[1], sc, c), fmaf(v[2], sc, c), fmaf(v[3], sc, c));
-            }
-        }
-    }
-}
-#endif
-
 static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const int ntiles = d.nstiles * (d.b16_hi - d.b16_lo);
@@ -1074,23 +933,7 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
         }                                                                                              \
         hipLaunchKernelGGL((k_fwd<QQ, MM>), grid, block, lds, st, d, A);                               \
     }
-#if PLM_SPARSE_FWD && PLM_FWD_ROWS4
-#define FWD_STORE_LAUNCH(QQ)                                                                           \
-    {                                                                                                  \
-        const size_t lds4 = (size_t)2 * 2 * (QQ) * 1024 + 1024;   /* two buffers + the surplus fragment */ \
-        static bool attr4_dev[PLM_MAX_DEVICES] = {false};                                              \
-        bool &attr4 = attr4_dev[plm_current_device()];                                                 \
-        if (!attr4) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void *)k_fwd4<QQ>,                               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
-            if (e != hipSuccess) return e;                                                             \
-            attr4 = true;                                                                              \
-        }                                                                                              \
-        hipLaunchKernelGGL((k_fwd4<QQ>), grid, block, lds4, st, d, A);                                 \
-    }
-#else
 #define FWD_STORE_LAUNCH(QQ) FWD_LAUNCH(QQ, FWD_STORE)
-#endif
 #define FWD_CASE(QQ)                                                                                   \
     case QQ:                                                                                           \
         if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                             \

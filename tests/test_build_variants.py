@@ -1,6 +1,6 @@
-"""The compile-time alternatives of the kernel file must keep compiling for gfx950: the dense forward GEMM of rounds
-1-2 (-DPLM_SPARSE_FWD=0, the A/B partner of the sparse one) and the 4-row-fragment tiling prepared for the next
-round (-DPLM_FWD_ROWS4=1).  hipcc cross-compiles without a GPU."""
+"""The compile-time alternative of the kernel file must keep compiling for gfx950: the dense forward GEMM of rounds
+1-2 (-DPLM_SPARSE_FWD=0, the A/B partner of the sparse one).  hipcc cross-compiles without a GPU.  (The 4-row-fragment
+tiling k_fwd4 of round 2 was measured in round 3 -- 4.07-4.14 ms against 3.78-3.88 ms -- and removed.)"""
 import os
 import shutil
 import subprocess
@@ -12,7 +12,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-@pytest.mark.parametrize("flag", ["-DPLM_SPARSE_FWD=0", "-DPLM_FWD_ROWS4=1"])
+@pytest.mark.parametrize("flag", ["-DPLM_SPARSE_FWD=0"])
 def test_kernel_variant_compiles(flag, tmp_path):
     out = tmp_path / "k.o"
     run = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", flag, "-c",

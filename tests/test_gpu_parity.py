@@ -715,31 +715,142 @@ def test_resumed_optimisation_skips_the_known_start_point(plm):
     np.testing.assert_array_equal(a.get_x(), b.get_x())
 
 
-def test_run_plmc_hip_launches_ranks_for_cpu_option(plm, tmp_path, monkeypatch):
-    """BASELINE configs 4 / 5 through the boundary: `cpu=N` of run_plmc (tools.py:178-181, 257-259) = number of GPUs.
-    run_plmc_hip starts N ranks under torch.distributed.run (evcouplings_amd.dist_worker), sites and optimiser state
-    sharded; here two ranks share the one GPU of the box with gloo / host-staged collectives (PLM_DIST_BACKEND), the
-    files must match the single-GPU run's."""
+def test_run_plmc_hip_shards_over_gpus_only_when_asked(plm, tmp_path, monkeypatch):
+    """BASELINE configs 4 / 5 through the boundary.  Multi-GPU is opt-in (`gpus=` / PLM_HIP_GPUS): run_plmc's `cpu` is
+    plmc's thread count and must not start ranks by itself.  With PLM_HIP_GPUS=2 the drop-in starts 2 ranks under
+    torch.distributed.run (evcouplings_amd.dist_worker), sites and optimiser state sharded; here the two ranks share
+    the one GPU of the box with gloo / host-staged collectives (PLM_DIST_BACKEND).  Both runs converge (iterations
+    "max", epsilon 1e-4); the files must agree within BASELINE's 1e-4."""
     from evcouplings_amd import tools, model_io, dist
     from evcouplings_amd.synthetic import msa_to_a2m
     N, L = 500, 40
     msa, _ = synthetic_msa(N, L, seed=23)
     ali = msa_to_a2m(msa, str(tmp_path / "in.a2m"))
-    kw = dict(focus_seq="SYN/1-40", theta=0.8, iterations=40, lambda_h=0.01, lambda_J=plm.default_lambda_j(L, Q))
-    one = tools.run_plmc_hip(ali, str(tmp_path / "a_ECs.txt"), str(tmp_path / "a.model"), cpu=1, **kw)
-    assert dist.resolve_gpu_count(4) == 1 and dist.resolve_gpu_count("max") == 1      # capped by the visible devices
-    monkeypatch.setenv("PLM_HIP_GPUS", "2")
+    kw = dict(focus_seq="SYN/1-40", theta=0.8, iterations="max", epsilon=1e-4, lambda_h=0.01,
+              lambda_J=plm.default_lambda_j(L, Q))
+    monkeypatch.delenv("PLM_HIP_GPUS", raising=False)
+    assert dist.resolve_gpu_count(4) == 1 and dist.resolve_gpu_count("max") == 1      # cpu alone never shards
+    assert dist.resolve_gpu_count(4, gpus=4) == 1 and dist.resolve_gpu_count(None, gpus="max") == 1   # capped: one GPU here
+    one, res1, _ = tools.infer_to_files(ali, str(tmp_path / "a_ECs.txt"), str(tmp_path / "a.model"), cpu=4, **kw)
     monkeypatch.setenv("PLM_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("PLM_HIP_GPUS", "cpu")
+    assert dist.resolve_gpu_count(2) == 2 and dist.resolve_gpu_count(None) == 1       # "cpu": read the cpu option
+    monkeypatch.setenv("PLM_HIP_GPUS", "2")
     assert dist.resolve_gpu_count(None) == 2
-    two = tools.run_plmc_hip(ali, str(tmp_path / "b_ECs.txt"), str(tmp_path / "b.model"), cpu=1, **kw)
+    two, res2, _ = tools.infer_to_files(ali, str(tmp_path / "b_ECs.txt"), str(tmp_path / "b.model"), cpu=1, **kw)
+    assert res1["status"] == 0 and res2["status"] == 0, (res1["status_msg"], res2["status_msg"])
+    assert one.optimization_status == two.optimization_status
     assert two.num_valid_seqs == one.num_valid_seqs and two.effective_samples == one.effective_samples
-    assert len(two.iteration_table) == len(one.iteration_table) or two.optimization_status == one.optimization_status
+    assert abs(len(two.iteration_table) - len(one.iteration_table)) <= max(3, len(one.iteration_table) // 10)
     a, b = model_io.read_model_file(str(tmp_path / "a.model")), model_io.read_model_file(str(tmp_path / "b.model"))
-    np.testing.assert_allclose(b["jij"], a["jij"], atol=2e-4)
-    np.testing.assert_allclose(b["hi"], a["hi"], atol=5e-3)
+    np.testing.assert_allclose(b["jij"], a["jij"], atol=1e-4)
+    np.testing.assert_allclose(b["hi"], a["hi"], atol=2e-3)
     ea = np.loadtxt(str(tmp_path / "a_ECs.txt"), usecols=5)
     eb = np.loadtxt(str(tmp_path / "b_ECs.txt"), usecols=5)
-    np.testing.assert_allclose(eb, ea, atol=2e-4)
+    np.testing.assert_allclose(eb, ea, atol=1e-4)
+
+
+def test_multi_gpu_launch_failure_falls_back_to_one_gpu(plm, tmp_path, monkeypatch):
+    """A multi-GPU job that dies before producing a result (here: the launcher is made to fail) must not fail the
+    stage: the single-GPU HIP fit runs instead, with a warning."""
+    from evcouplings_amd import tools, dist
+    from evcouplings_amd.synthetic import msa_to_a2m
+    msa, _ = synthetic_msa(300, 24, seed=3)
+    ali = msa_to_a2m(msa, str(tmp_path / "in.a2m"))
+
+    def broken(*a, **k):
+        raise dist.LaunchError("no ranks")
+    monkeypatch.setattr(dist, "launch_fit", broken)
+    monkeypatch.setattr(dist, "resolve_gpu_count", lambda cpu=None, gpus=None: 2)
+    with pytest.warns(UserWarning, match="running on one GPU"):
+        r = tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), str(tmp_path / "m.model"), focus_seq="SYN/1-24", iterations=5)
+    assert os.path.getsize(r.couplings_file) > 0 and "|g|/max(1,|x|)" in r.optimization_status
+
+
+# ---------------------------------------------------------------- plmc's own route: joint L-BFGS (row a7)
+def test_joint_lbfgs_follows_the_oracle_trajectory(plm, oracle64):
+    """The joint path (PLM_FLAG_JOINT_LBFGS; solver="joint" at the boundary) is the algorithm libLBFGS-based plmc runs:
+    L-BFGS (m = 6) over fields and couplings together with a More'-Thuente search.  The oracle's optimiser is the same
+    algorithm in float64 -- the only plmc-shaped comparison available without the binary: equal iteration counts must
+    give equal objective values.  Compared per iteration over the first 30 iterations (later the f32-class evaluation
+    and the f64 one pick different trial steps and the trajectories drift apart; both still decrease)."""
+    N, L = 2000, 48
+    msa, _ = synthetic_msa(N, L, seed=12)
+    lj = plm.default_lambda_j(L, Q)
+    ref = oracle64.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=30, epsilon=1e-12, want_fij=False)
+    res = plm.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=30, epsilon=1e-12, joint=True, want_fij=False)
+    assert res["iters"] == ref["iters"] == 30 and res["status"] == 1
+    fx, fxo = np.array([r[3] for r in res["table"]]), np.array([r[3] for r in ref["table"]])
+    rel = np.abs(fx - fxo) / np.abs(fxo)
+    print("joint trajectory: max rel fx difference %.3g (iteration %d); evaluations %d vs %d" % (
+        rel.max(), int(rel.argmax()) + 1, res["n_evals"], ref["nevals"]))
+    assert rel.max() <= 1e-5, rel
+    # the other columns of the iteration table: -log-likelihood, |h|, |e| (plmc prints them; parse_plmc_log keeps them)
+    for col, tol in ((4, 1e-5), (5, 1e-4), (6, 1e-3)):
+        a, b = np.array([r[col] for r in res["table"]]), np.array([r[col] for r in ref["table"]])
+        assert (np.abs(a - b) <= tol * np.maximum(1e-12, np.abs(b))).all(), (col, np.abs(a - b).max())
+    assert res["n_evals"] == ref["nevals"]                     # same line-search decisions
+
+
+def test_joint_lbfgs_converges_to_the_oracle_optimum(plm, oracle64):
+    """... and run to convergence it must land on the oracle's optimum with status 'converged' (strict convexity makes
+    the optimum unique; the default variable-projection solver is held to the same bar above)."""
+    N, L = 600, 24
+    msa, _ = synthetic_msa(N, L, seed=31)
+    lj = plm.default_lambda_j(L, Q)
+    ref = oracle64.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=5000, epsilon=1e-7)
+    res = plm.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=5000, epsilon=2e-5, joint=True)
+    assert res["status"] == 0, res["status_msg"]
+    assert res["fx"] == pytest.approx(ref["fx"], rel=1e-6)
+    assert np.abs(res["cn"] - ref["cn"]).max() < 1e-4
+    np.testing.assert_allclose(res["jij"], ref["jij"], atol=1e-4)
+    vp = plm.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=3000, epsilon=2e-6)
+    assert np.abs(res["cn"] - vp["cn"]).max() < 1e-4           # both solvers of the library: one optimum
+
+
+def test_solver_selection_reaches_the_joint_path_through_the_boundary(plm, tmp_path, monkeypatch):
+    """solver="joint" / PLM_HIP_SOLVER=joint on run_plmc_hip, --solver on the CLI shim: at the reference's default 100
+    iterations the two solvers stop at different points (neither converged), so the choice must be visible."""
+    from evcouplings_amd import tools, cli
+    from evcouplings_amd.synthetic import msa_to_a2m
+    N, L = 800, 32
+    msa, _ = synthetic_msa(N, L, seed=9)
+    ali = msa_to_a2m(msa, str(tmp_path / "in.a2m"))
+    lj = plm.default_lambda_j(L, Q)
+    kw = dict(focus_seq="SYN/1-32", theta=0.8, iterations=15, lambda_h=0.01, lambda_J=lj)
+    direct = plm.fit(msa, Q, lambda_h=0.01, lambda_j=lj, max_iter=15, joint=True, want_fij=False)
+    _, byarg, _ = tools.infer_to_files(ali, str(tmp_path / "a.txt"), None, solver="joint", **kw)
+    monkeypatch.setenv("PLM_HIP_SOLVER", "joint")
+    _, byenv, _ = tools.infer_to_files(ali, str(tmp_path / "b.txt"), None, **kw)
+    monkeypatch.delenv("PLM_HIP_SOLVER")
+    _, vp, _ = tools.infer_to_files(ali, str(tmp_path / "c.txt"), None, **kw)
+    np.testing.assert_array_equal(byarg["cn"], direct["cn"])
+    np.testing.assert_array_equal(byenv["cn"], direct["cn"])
+    assert byarg["fx"] > vp["fx"] and np.abs(vp["cn"] - direct["cn"]).max() > 1e-3    # VP is further along after 15
+    assert "|g|/max(1,|x|) = " in byarg["status_msg"]
+    rc = cli.main(["-c", str(tmp_path / "d.txt"), "-f", "SYN", "-m", "15", "-lh", "0.01", "-le", repr(lj), "-t", "0.2",
+                   "--solver", "joint", ali])
+    assert rc == 0
+    np.testing.assert_allclose(np.loadtxt(str(tmp_path / "d.txt"), usecols=5), np.loadtxt(str(tmp_path / "a.txt"), usecols=5),
+                               atol=1e-6)
+    with pytest.raises(tools.ExternalToolError):
+        tools.run_plmc_hip(ali, str(tmp_path / "x.txt"), solver="newton", **kw)
+
+
+def test_replicated_multi_shard_evaluation_at_config_scale_sites(plm, oracle64):
+    """Replicated multi-shard mode (exchange callback / LoopbackShards) with L = 300 on 8 shards: the per-site buffers
+    of the field pass cover all L sites there (the local field part), not only the shard's own 2-3 column blocks --
+    ADVICE r2: they were sized for the own blocks and the pass wrote / read ~50 KB past an 8 KB buffer."""
+    from evcouplings_amd.dist import LoopbackShards
+    N, L = 400, 300
+    msa, _ = synthetic_msa(N, L, seed=78)
+    w = (1.0 / oracle64.reweight(msa, 0.8)).astype(np.float32)
+    x = (0.05 * np.random.default_rng(6).normal(size=plm.n_params(L, Q))).astype(np.float32)
+    lj = plm.default_lambda_j(L, Q)
+    fx1, nll1, g1 = plm.evaluate(msa, w, Q, 0.01, lj, x)
+    fx, nll, g = LoopbackShards(msa, w, Q, 0.01, lj, 8).evaluate(x)
+    assert fx == pytest.approx(fx1, rel=1e-6)
+    np.testing.assert_allclose(g, g1, atol=1e-5 * np.abs(g1).max(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("conv", [0, 32, 64, 128, 256, 64 | 256, 128 | 256, 512, 32 | 64 | 256 | 512])

@@ -8,8 +8,11 @@ The oracle (oracle/plm_oracle.c, float64, OpenMP) is the checker: one objective+
     (L=300, N=50 000);
   * an optimality certificate for the fit: the ORACLE's gradient at the point the GPU fit stopped satisfies the
     stop rule (the fit does not merely believe it converged), and pushing the GPU fit 10x further does not move CN;
-  * config 2 "EC scores within 1e-4 of the CPU solver": the GPU's CN against the CN of the point an independent
-    float64 optimiser (scipy L-BFGS-B on the oracle's objective) reaches from there.
+  * config 2 "EC scores within 1e-4 of the CPU solver": the GPU's CN at the SHIPPED stop rule (epsilon = 1e-3) against
+    the CN of the point an independent float64 optimiser (scipy L-BFGS-B on the oracle's objective) reaches from there;
+  * BASELINE.json configs 3 (N = 100 000), 4 (L = 500) and 5 (L = 600, two chains): one f64-oracle evaluation far from
+    the optimum and one at the GPU's stop point each (same thresholds), the optimality certificate for config 3, and for
+    config 5 the whole file round trip (A2M -> run_plmc_hip -> .model / _ECs.txt -> reader -> scores).
 """
 import os
 
@@ -20,7 +23,15 @@ from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED
 
 pytestmark = pytest.mark.gpu
 Q = 21
-CONFIGS = {"config2": (20000, 200, BASE_SEED + 2), "headline": (50000, 300, BASE_SEED + 1)}
+CONFIGS = {"config2": (20000, 200, BASE_SEED + 2), "headline": (50000, 300, BASE_SEED + 1),
+           "config3": (100000, 300, BASE_SEED + 3), "config4": (50000, 500, BASE_SEED + 4),
+           "config5": (30000, 600, BASE_SEED + 5)}
+# configurations that get the full treatment (two fits); the larger ones get the shipped fit only -- their vectors are
+# 220-320 MB each and an oracle evaluation costs 10-20 s of the box's host cores
+FULL = ("config2", "headline", "config3")
+# config 3 (N = 100 000): the f32-class evaluation's rounding noise is ~1.5x the headline's in |g|/|x| units
+# (DESIGN.md section 5), the "much tighter" fit stops a little earlier
+TIGHT_OF = {"config3": 6e-4}
 # the "much tighter than the stop rule" fit: |g|/|x| < 4e-4.  At N = 50 000 the rounding noise of the f32-class
 # gradient is ~1e-4 in these units and the fit crawls below 3e-4: about as far as the
 # headline can be pushed.
@@ -70,10 +81,12 @@ def fits(plm):
             ctx.set_options(max_iter=3000, epsilon=1e-3)
             r = ctx.optimize()
             out["fit_1e-3"] = dict(r, x=ctx.get_x(), cn=ctx.scores()[1])
-            ctx.set_options(max_iter=1000, epsilon=TIGHT)
-            r = ctx.optimize()
-            out["fit_tight"] = dict(r, x=ctx.get_x(), cn=ctx.scores()[1])
-        cache[name] = out
+            if name in FULL:
+                ctx.set_options(max_iter=1000, epsilon=TIGHT_OF.get(name, TIGHT))
+                r = ctx.optimize()
+                out["fit_tight"] = dict(r, x=ctx.get_x(), cn=ctx.scores()[1])
+        if name in FULL:          # configs 4 / 5 are visited by one test each: not kept (their vectors are 220-320 MB)
+            cache[name] = out
         return out
     return get
 
@@ -82,9 +95,10 @@ def _oracle_eval(oracle64, f, x):
     return oracle64.eval(f["msa"], f["w"].astype(np.float64), Q, 0.01, f["lambda_j"], x.astype(np.float64))
 
 
-@pytest.mark.parametrize("name", ["config2", "headline"])
+@pytest.mark.parametrize("name", ["config2", "headline", "config3", "config4", "config5"])
 def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, fits, name):
     f = fits(name)
+    assert f["fit_1e-3"]["status"] == 0, f["fit_1e-3"]["status_msg"]          # every BASELINE configuration converges
     # far from the optimum: relative criteria (gradient entries are large)
     fx, nll, g = plm.evaluate(f["msa"], f["w"], Q, 0.01, f["lambda_j"], f["x_far"])
     fxo, nllo, go = _oracle_eval(oracle64, f, f["x_far"])
@@ -97,22 +111,32 @@ def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, fits, name):
     fxo, nllo, go = _oracle_eval(oracle64, f, x)
     assert abs(fx - fxo) <= 2e-6 * abs(fxo)
     err = np.linalg.norm(g - go) / max(1.0, np.linalg.norm(x))
+    cond64 = np.linalg.norm(go) / max(1.0, np.linalg.norm(x))
+    print("%s: |g_hip - g_f64|/|x| = %.3g at the stop point, oracle cond %.3g, %d iterations / %d evaluations" % (
+        name, err, cond64, f["fit_1e-3"]["iters"], f["fit_1e-3"]["n_evals"]))
     assert err <= 6e-4, err                      # eps = 1e-3 is the stop rule; measured 4.0e-4 at the headline
     assert np.abs(g - go).max() <= 2e-5 * gmax_far
+    # optimality as the ORACLE sees it (configs 2 / headline / 3 repeat this with more checks below)
+    assert cond64 < 1.6e-3, cond64
+    f["cond64_1e-3"] = cond64
 
 
-@pytest.mark.parametrize("name", ["config2", "headline"])
+@pytest.mark.parametrize("name", ["config2", "headline", "config3"])
 def test_fit_optimality_certificate(oracle64, fits, name):
     f = fits(name)
     a, b = f["fit_1e-3"], f["fit_tight"]
+    tight = TIGHT_OF.get(name, TIGHT)
     assert a["status"] == 0, a["status_msg"]                          # converged by its own rule
     assert a["table"][-1][2] < 1e-3
     # the oracle agrees: its float64 gradient at the GPU's final point satisfies the rule up to the evaluation error
-    _, _, go = _oracle_eval(oracle64, f, a["x"])
-    cond64 = np.linalg.norm(go) / max(1.0, np.linalg.norm(a["x"]))
+    # (computed by the evaluation test above when it ran on this configuration first)
+    cond64 = f.get("cond64_1e-3")
+    if cond64 is None:
+        _, _, go = _oracle_eval(oracle64, f, a["x"])
+        cond64 = np.linalg.norm(go) / max(1.0, np.linalg.norm(a["x"]))
     assert cond64 < 1.6e-3, cond64
-    # 2.5 times tighter moves no EC score by more than 1e-4 (BASELINE.json's tolerance on EC scores)
-    assert b["status"] == 0 and b["table"][-1][2] < TIGHT, (b["status_msg"], b["table"][-1][2])
+    # 1.7 - 2.5 times tighter moves no EC score by more than 1e-4 (BASELINE.json's tolerance on EC scores)
+    assert b["status"] == 0 and b["table"][-1][2] < tight, (b["status_msg"], b["table"][-1][2])
     assert np.abs(a["cn"] - b["cn"]).max() < 1e-4
     _, _, gob = _oracle_eval(oracle64, f, b["x"])
     assert np.linalg.norm(gob) / max(1.0, np.linalg.norm(b["x"])) < cond64
@@ -120,11 +144,13 @@ def test_fit_optimality_certificate(oracle64, fits, name):
 
 def test_config2_cn_within_1e4_of_an_independent_f64_optimiser(plm, oracle64, fits):
     """BASELINE.json config 2: 'EC scores vs CPU plmc within 1e-4'.  plmc is unobtainable; the CPU
-    side here is scipy's L-BFGS-B minimising the ORACLE's float64 objective, started from the GPU's answer and
-    given 25 evaluations: it must not find anything better that moves a CN score by 1e-4."""
+    side here is scipy's L-BFGS-B minimising the ORACLE's float64 objective, started from the answer the drop-in SHIPS
+    (stop rule epsilon = 1e-3, not the tighter fit) and given 25 evaluations: whatever it still gains must not move a CN
+    score by 1e-4."""
     import scipy.optimize as so
     f = fits("config2")
-    x0 = f["fit_tight"]["x"].astype(np.float64)
+    shipped = f["fit_1e-3"]
+    x0 = shipped["x"].astype(np.float64)
     w64 = f["w"].astype(np.float64)
 
     def fun(x):
@@ -135,4 +161,40 @@ def test_config2_cn_within_1e4_of_an_independent_f64_optimiser(plm, oracle64, fi
     assert res.fun <= fun(x0)[0] * (1 + 1e-12)
     L = f["L"]
     _, cn_cpu = oracle64.scores(res.x[L * Q:], L, Q)
+    print("config2: scipy f64 from the shipped point: f %.6f -> %.6f, max |dCN| %.3g" % (
+        fun(x0)[0], res.fun, np.abs(cn_cpu - shipped["cn"]).max()))
+    assert np.abs(cn_cpu - shipped["cn"]).max() < 1e-4
     assert np.abs(cn_cpu - f["fit_tight"]["cn"]).max() < 1e-4
+
+
+def test_config5_two_chain_file_round_trip(plm, tmp_path):
+    """BASELINE.json config 5: EVcomplex-style concatenated alignment, L = 600 = 350 + 250, N = 30 000 -- 'inter-chain EC
+    scoring, CouplingsModel round-trip'.  A2M file -> the run_plmc drop-in (fit to the stop rule) -> _ECs.txt and the
+    634 MB plmc_v2 .model -> read back -> scores recomputed from the file's couplings must be the EC file's, and the
+    planted inter-chain couplings must lead the inter-chain ranking (what the reference's complex protocol extracts,
+    couplings/protocol.py:521-560)."""
+    from evcouplings_amd import model_io, tools
+    from evcouplings_amd.synthetic import msa_to_a2m
+    N, L, seed = CONFIGS["config5"]
+    L1 = 350
+    msa, planted = synthetic_msa(N, L, seed=seed)
+    ali = msa_to_a2m(msa, str(tmp_path / "c5.a2m"))
+    ec_file, model_file = str(tmp_path / "c5_ECs.txt"), str(tmp_path / "c5.model")
+    r = tools.run_plmc_hip(ali, ec_file, model_file, focus_seq="SYN/1-600", theta=0.8, iterations="max", lambda_h=0.01,
+                           lambda_J=plm.default_lambda_j(L, Q))
+    assert r.optimization_status.startswith("converged"), r.optimization_status
+    assert r.num_valid_sites == L and r.num_valid_seqs == N
+    assert os.path.getsize(model_file) == 40 + Q + 4 * N + 5 * L + 8 * L * Q + 4 * L * (L - 1) * Q * Q   # SURVEY App. A
+    m = model_io.read_model_file(model_file)
+    assert m["L"] == L and m["q"] == Q and m["jij"].shape == (L * (L - 1) // 2, Q, Q)
+    _, cn = plm.scores(m["jij"], L, Q)
+    ecs = np.loadtxt(ec_file, usecols=(0, 2, 5))
+    iu, ju = np.triu_indices(L, 1)
+    np.testing.assert_array_equal(ecs[:, 0].astype(int), iu + 1)
+    np.testing.assert_array_equal(ecs[:, 1].astype(int), ju + 1)
+    np.testing.assert_allclose(ecs[:, 2], cn[iu, ju], atol=2e-6)            # 6 decimals in the text file
+    inter = (iu < L1) & (ju >= L1)
+    planted_inter = {(i, j) for (i, j) in planted if i < L1 <= j}
+    order = np.argsort(-cn[iu, ju][inter])
+    top = set(zip(iu[inter][order[:len(planted_inter)]].tolist(), ju[inter][order[:len(planted_inter)]].tolist()))
+    assert len(planted_inter) >= 20 and len(top & planted_inter) >= 0.9 * len(planted_inter), (len(top & planted_inter), len(planted_inter))
