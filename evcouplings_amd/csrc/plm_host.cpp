@@ -104,6 +104,14 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.Lp32 = d.nu * 32;
     d.nksteps = d.nu * PLM_FWD_SPU(d.Q);
     d.nssteps = d.Np / 32;
+    d.nst128 = d.Np / PLM_BWD_KSTEP;
+    // digit planes of the backward GEMM: 24-bit residuals by default, 32-bit for fits that must converge below 1e-4
+    // (the quantisation noise of three planes is ~5e-5 |x| at the headline); PLM_BWD_PLANES = 3 | 4 overrides
+    d.nplanes = (p.epsilon > 0 && p.epsilon < 1e-4) ? 4 : 3;
+    if (const char *e = getenv("PLM_BWD_PLANES")) d.nplanes = atoi(e) == 4 ? 4 : 3;
+    const float qmax = d.nplanes == 4 ? PLM_R_QMAX4 : PLM_R_QMAX3;
+    d.rscale = qmax;                    // for unit weights; plm_ctx_set_weights sets the pair for the weights in use
+    d.gscale = 1.0f / (qmax * (float)PLM_BWD_ONEHOT_VALUE);
     d.nstiles = d.Np / PLM_SEQ_TILE;
     plm_pick_tile(d.Q, &d.FM, &d.FN);
     d.nmf = d.nb16 * d.Q + d.FM;
@@ -118,23 +126,28 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
     d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
     {
-        // split-K factor of the backward GEMM: at least ~6 rounds of workgroups on the 256 CUs (1536 blocks;
-        // fewer balances badly -- measured on configs 2 and 4), and among those the factor with the cheapest
-        // tail: the launch runs in ceil(tiles * ks / 256) rounds of 1/ks of the K range each, and every extra
-        // partial slab costs k_assemble two more reads of it (config 5: ks 1 -> 2 takes k_bwd from 14.2 to 12.5 ms).
-        // Cost in units of one full-K round (a K step is ~1.4 us, HBM ~4 TB/s effective):
-        const int tiles = d.nrow_tiles * d.ncol_tiles, ks_max = std::max(1, std::min(16, d.nssteps / 8));
-        const int ks_min = std::min(ks_max, (1536 + tiles - 1) / tiles);
-        const double beta = (2.0 * (double)d.nmf * d.nnfl * 1024.0 / 4e12) / ((double)d.nssteps * 1.4e-6);
+        // K split of the backward GEMM.  A launch has tiles * nplanes * ks workgroups (one digit plane per workgroup),
+        // each over 1/ks of the K steps; with integer accumulation the split changes no result, only the balance: the
+        // launch runs in ceil(tiles * 3 * ks / 256) rounds of 1/ks of a full-K workgroup each (XCD granularity makes
+        // it slightly worse), and every extra set of partial slabs costs k_assemble two more reads of it.
+        // Cost in units of one full-K workgroup (a 128-sequence K step is ~1.3 us; the partial slabs reach k_assemble
+        // largely through L2 / the 256 MB Infinity Cache -- measured at the headline: ks 1 -> 2 adds 0.11 ms to
+        // k_assemble for 0.98 GB more reads and takes 0.20 ms off k_bwd -- hence the 12 TB/s):
+        const int tiles = d.nrow_tiles * d.ncol_tiles, ks_max = std::max(1, std::min(16, d.nst128 / 8));
+        // int32 accumulators: |sum| <= 128 (one-hot value) * 127 (digit) * (sequences of the K range) must stay below 2^31
+        const int ks_min = std::min(ks_max, std::max(1, (int)(((int64_t)d.Np * 127 * 128) >> 31) + 1));
+        const double beta = (2.0 * d.nplanes * (double)d.nmf * d.nnfl * 1024.0 / 12e12) / ((double)d.nst128 * 1.3e-6);
         int best = ks_min;
         double best_cost = 1e300;
         for (int ks = ks_min; ks <= ks_max; ks++) {
-            const double cost = (double)((tiles * ks + 255) / 256) / ks + beta * ks;
+            const int groups_per_xcd = (d.ncol_tiles * d.nplanes * ks + 7) / 8;     // busiest XCD
+            const double cost = (double)((groups_per_xcd * d.nrow_tiles + 31) / 32) / ks + beta * ks;
             if (cost < best_cost * 0.98) { best_cost = cost; best = ks; }
         }
         d.ksplit = best;
-        // measurement knob (tests/probes/noise_probe.py): force the split-K factor of the backward GEMM
-        if (const char *e = getenv("PLM_KSPLIT")) d.ksplit = std::max(1, std::min(ks_max, atoi(e)));
+        // measurement knob: force the K split of the backward GEMM (results are identical for every value)
+        if (const char *e = getenv("PLM_KSPLIT")) d.ksplit = std::max(ks_min, std::min(ks_max, atoi(e)));
+        (void)tiles;
     }
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
@@ -177,7 +190,7 @@ struct plm_ctx {
     float *w = nullptr;
     int32_t *counts = nullptr;
     void *Bt = nullptr, *Rt = nullptr;
-    float *G = nullptr;        // split-K partial slabs (local)
+    int32_t *G = nullptr;      // digit-plane / K-range partial slabs of the backward GEMM (local, exact integer sums)
     float *gather = nullptr;   // exchange buffer [nshards][slab] (replicated multi-shard mode only)
     plm_collective_cb collective = nullptr;   // sharded-state mode: collectives through the host ...
     void *collective_user = nullptr;
@@ -269,7 +282,7 @@ int forward_at_x(plm_ctx *c) {
     PLM_TRY(vp_alloc(c));
     HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr, c->st));
     return PLM_OK;
 }
 
@@ -301,7 +314,7 @@ int ctx_eval_enqueue(plm_ctx *c) {
     HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
     PLM_TRY(forward_at_x(c));
     HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
-    const float *Gsrc = c->G;
+    const void *Gsrc = c->G;
     int ks_count = d.ksplit, n_shard_nll = 0;
     const double *shard_nll = nullptr;
     if (d.nshards > 1) {
@@ -314,7 +327,7 @@ int ctx_eval_enqueue(plm_ctx *c) {
         if (c->exchange(c->gather, slab, d.nshards, d.shard, c->exchange_user) != 0)
             return fail(PLM_ECALLBACK, "exchange callback failed");
         Gsrc = c->gather;
-        ks_count = 1;
+        ks_count = 0;            // float slabs, planes and K ranges already combined by k_slab_reduce
         n_shard_nll = d.nshards;
         shard_nll = (const double *)((char *)c->gather + slab - 256);
     }
@@ -390,7 +403,7 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse, bool write_rt) {
     for (int it = 0; it < newton; it++) {
         const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
         if (full || !(it == 0 && reuse))
-            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, nullptr, nullptr, c->hpart,
+            HIP_TRY(plm_launch_hpass(d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, nullptr, nullptr, c->hpart,
                                      c->gpart, nullptr, c->st));
         HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
                                   c->vp_flag, c->st));
@@ -400,7 +413,7 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse, bool write_rt) {
     // the pass at the result: gradient sums for the convergence check (and for the next round's first step); with
     // write_rt also the residual fragments and -log P partials -- 1.29 GB of writes that only the LAST round's pass
     // needs to make (ctx_eval_vp decides which rounds write speculatively)
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, write_rt ? 1 : 0, 1, write_rt ? c->Rt : nullptr,
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, write_rt ? 1 : 0, 1, write_rt ? c->Rt : nullptr,
                              write_rt ? c->fx_part : nullptr, c->hpart, c->gpart, nullptr, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
                               c->vp_flag, c->st));
@@ -463,7 +476,7 @@ int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
         newton = 2;
     }
     if (!rt_current)   // the last round ended on a statistics-only pass: residual fragments and -log P at its fields
-        HIP_TRY(plm_launch_hpass(c->d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr,
+        HIP_TRY(plm_launch_hpass(c->d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr,
                                  c->st));
     // steps to try first at the next trial point: one more if this one needed extra rounds, one fewer (down to
     // none: the L-BFGS extrapolation of the fields is then good enough) if it met the tolerance with room to spare
@@ -817,6 +830,11 @@ int plm_ctx_set_weights(plm_ctx_t *c, const float *weights_host) {
     c->n_eff = neff;
     c->have_weights = true;
     c->eval_valid = false;
+    // residual quantisation of the backward GEMM: |r_s(i,a)| <= w_s, so the largest weight maps to the largest
+    // 24-bit magnitude whose three signed digits fit int8
+    const float qmax = c->d.nplanes == 4 ? PLM_R_QMAX4 : PLM_R_QMAX3;
+    c->d.rscale = qmax / wmax;
+    c->d.gscale = wmax / (qmax * (float)PLM_BWD_ONEHOT_VALUE);   // the one-hot operand of k_bwd carries -128
     return PLM_OK;
 }
 
@@ -979,21 +997,30 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
 // entry of the Gram matrix of {s_j, y_j, g}, refreshed by ONE pass over the history per
 // iteration (k_multidot), and the direction is ONE fused linear combination (k_multiaxpy).
 // Two host synchronisations per iteration: after the line-search evaluation and after the pass.
-int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res) {
-    if (!c) return fail(PLM_EINVAL, "NULL ctx");
-    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
-    HIP_TRY(hipSetDevice(c->device));
+// One phase of an optimisation: L-BFGS from the current point until |g| / max(1, |x|) <= eps or the iteration budget is
+// spent.  k_off / t0: iterations already done and the start time of the whole optimisation (a second phase continues
+// the numbering of the iteration callback and the clock).
+static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res, const double eps, const int k_off,
+                          const double t0) {
     const PlmDims &d = c->d;
     const int64_t n = d.n_local;
     const int m = std::min(20, c->prob.lbfgs_m > 0 ? c->prob.lbfgs_m : 6);
     const int max_iter = c->prob.max_iter;
-    const double eps = c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3;
     const int max_ls = 20;
     const double ftol = 1e-4, gtol = 0.9, xtol = 1e-7, stpmin = 1e-20, stpmax = 1e20;
-    // f is an f64 sum of f32 terms: once an iteration's decrease drowns in that rounding noise the
-    // sufficient-decrease test is replaced by "f did not rise beyond noise" + the curvature
-    // condition (approximate Wolfe, Hager & Zhang 2005); same rule as the f32 oracle build
-    const double epsf = 1e-6;
+    // f is an f64 sum of ~N L f32 terms: its rounding noise is ~1e-10 |f| (measured: 2e-3 at f = 2.8e7, N = 100 000),
+    // while the gradient -- exact integer sums of 24-bit residuals since round 3 -- is good to a few 1e-4 of |x|.  Near
+    // the optimum of a large problem the decrease of an iteration (stp |g.d| / 2) falls below that noise before the stop
+    // rule is met; a More'-Thuente search fed with such values interpolates on noise (seen at config 3: trials that
+    // wander between two step lengths until the bracket collapses, accepted steps that raise f).  Two devices:
+    //  * approximate Wolfe (Hager & Zhang 2005), as in the f32 oracle build: a trial whose f did not rise beyond
+    //    epsf |f0| passes the sufficient-decrease test;
+    //  * where |f(trial) - f(0)| is inside flat_rel |f(0)| AND the evaluated value contradicts what the derivatives
+    //    imply, f(0) + stp (g0.d + g.d) / 2 (trapezoid: exact for a quadratic), by more than half of that implied change,
+    //    the search works with the implied value -- then the sufficient-decrease test is H&Z's derivative form
+    //    g.d <= (2 ftol - 1) g0.d and the cubic steps see consistent data.  Small problems never get there (their f is
+    //    good to ~1e-10 |f| too, and that is far below their decreases).
+    const double epsf = 1e-6, flat_rel = 4e-9;
     PLM_TRY(ctx_alloc_lbfgs(c, m));
     float *S = c->hist, *Y = c->hist + (size_t)m * n;
     // H0 = gamma * D^-1 with D the Hessian diagonal of the independent-site model at the start point (closed form
@@ -1026,8 +1053,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     std::vector<double> SY(m * m, 0.0), YDY(m * m, 0.0), Sg(m, 0.0), YDg(m, 0.0);
     double gg = 0, gDg = 0, xx = 0, hh = 0;
     std::vector<double> alpha(m), cs(m), cy(m);
-    const double t0 = now_s();
-    c->n_evals = 0;
+    if (k_off == 0) c->n_evals = 0;
     // device scalar slots; in sharded-state mode each fetch is preceded by a sum over the shards of
     // exactly the slots that were just written ([FX..DG] after an evaluation, [XX..MD+..] after the pass)
     enum { SL_FX = 0, SL_NLL = 1, SL_DG = 2, SL_XX = 3, SL_HH = 4, SL_GH2 = 5, SL_MD = 8 };
@@ -1211,26 +1237,31 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     continue;
                 }
                 const double ftest1 = finit + stp * dgtest;
+                // the value the search works with: the evaluated one, or inside the noise band the derivative-implied one
+                const double f_implied = finit + 0.5 * stp * (dginit + dg);
+                const bool noisy = std::fabs(fx - finit) <= flat_rel * std::fabs(finit) &&
+                                   std::fabs(fx - f_implied) > 0.5 * std::fabs(f_implied - finit) + 1e-12 * std::fabs(finit);
+                const double fl = noisy ? f_implied : fx;
                 if (count < 64) { trace[count][0] = stp; trace[count][1] = fx - finit; trace[count][2] = dg; }
                 count++;
                 if (brackt && (stp <= stmin || stmax <= stp || uinfo)) { lsrc = -1; break; }
-                if (stp == stpmax && fx <= ftest1 && dg <= dgtest) { lsrc = -2; break; }
-                if (stp == stpmin && (ftest1 < fx || dgtest <= dg)) { lsrc = -3; break; }
+                if (stp == stpmax && fl <= ftest1 && dg <= dgtest) { lsrc = -2; break; }
+                if (stp == stpmin && (ftest1 < fl || dgtest <= dg)) { lsrc = -3; break; }
                 if (brackt && stmax - stmin <= xtol * stmax) { lsrc = -4; break; }
                 if (count >= max_ls) { lsrc = -5; break; }
-                if ((fx <= ftest1 || fx <= finit + epsf * std::fabs(finit)) && std::fabs(dg) <= gtol * (-dginit)) {
+                if ((fl <= ftest1 || (!noisy && fx <= finit + epsf * std::fabs(finit))) && std::fabs(dg) <= gtol * (-dginit)) {
                     lsrc = 1;
                     break;
                 }
-                if (stage1 && fx <= ftest1 && std::min(ftol, gtol) * dginit <= dg) stage1 = 0;
-                if (stage1 && ftest1 < fx && fx <= fxx) {
-                    double fm = fx - stp * dgtest, fxm = fxx - stx * dgtest, fym = fy - sty * dgtest;
+                if (stage1 && fl <= ftest1 && std::min(ftol, gtol) * dginit <= dg) stage1 = 0;
+                if (stage1 && ftest1 < fl && fl <= fxx) {
+                    double fm = fl - stp * dgtest, fxm = fxx - stx * dgtest, fym = fy - sty * dgtest;
                     double dgm = dg - dgtest, dgxm = dgx - dgtest, dgym = dgy - dgtest;
                     uinfo = mt_update(&stx, &fxm, &dgxm, &sty, &fym, &dgym, &stp, fm, dgm, stmin, stmax, &brackt);
                     fxx = fxm + stx * dgtest; fy = fym + sty * dgtest;
                     dgx = dgxm + dgtest; dgy = dgym + dgtest;
                 } else {
-                    uinfo = mt_update(&stx, &fxx, &dgx, &sty, &fy, &dgy, &stp, fx, dg, stmin, stmax, &brackt);
+                    uinfo = mt_update(&stx, &fxx, &dgx, &sty, &fy, &dgy, &stp, fl, dg, stmin, stmax, &brackt);
                 }
                 if (brackt) {
                     if (0.66 * prev_width <= std::fabs(sty - stx)) stp = stx + 0.5 * (sty - stx);
@@ -1282,11 +1313,11 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             gh2 = gh2_trial;
             const double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg + gh2);
             if (cb)
-                cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
+                cb(k + k_off, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
                    std::sqrt(std::max(0.0, xx - hh)), user);
             last_cond = gnorm / std::max(1.0, xnorm);
             if (last_cond <= eps) { status = PLM_STATUS_CONVERGED; break; }
-            if (max_iter > 0 && k >= max_iter) { status = PLM_STATUS_MAXITER; break; }
+            if (max_iter > 0 && k + k_off >= max_iter) { status = PLM_STATUS_MAXITER; break; }
             if (SY[e * m + e] > 0) {   // curvature pair accepted (always true under the Wolfe conditions)
                 stored = nst;
                 end = (end + 1) % m;
@@ -1304,7 +1335,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     c->last_nll = nll;
     c->last_gh2 = gh2;
     if (res) {
-        res->iters_done = k;
+        res->iters_done = k + k_off;
         res->n_evals = c->n_evals;
         res->status = status;
         res->fx = fx;
@@ -1322,6 +1353,13 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             snprintf(res->status_msg, sizeof res->status_msg, "%s", status_text(status));
     }
     return PLM_OK;
+}
+
+int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
+    HIP_TRY(hipSetDevice(c->device));
+    return optimize_phase(c, cb, user, res, c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3, 0, now_s());
 }
 
 int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {

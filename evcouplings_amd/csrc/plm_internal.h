@@ -12,10 +12,15 @@
 //   Bt      f16  [b16][kstep][2][q][64][8]   one-hot GEMM B operand of the forward pass:
 //                                  expanded couplings split hi/lo, stored as ready-made MFMA
 //                                  B fragments (lane-linear 16 B per lane)
-//   Rt      f16  [sstep][nf][2][64][8]       residuals w_s (P_si(a) - [x_si=a]) * 2^14 split
-//                                  hi/lo, stored as MFMA B fragments of the backward pass
-//   G       f32  [shard][ksplit][mf][nfl][64][4]   asymmetric gradient slab, one 16x16
-//                                  MFMA accumulator tile per (row fragment, col fragment)
+//   Rt      i8   [3 planes][step128][nf][2][64][16]   residuals w_s (P_si(a) - [x_si=a]) in 24-bit fixed point
+//                                  (R = rint(r * rscale), |R| <= 8 355 711), split into three SIGNED base-256 digits
+//                                  (R = d0 + 256 d1 + 65536 d2, each digit in [-128, 127]); plane p holds digit p as
+//                                  ready-made B fragments of v_mfma_i32_16x16x64_i8: per 128-sequence K step and column
+//                                  fragment two 1 KB fragments (sequences 0-63 / 64-127), lane (G = lane / 16, site =
+//                                  lane % 16) holding the 16 consecutive sequences 16 G .. 16 G + 15
+//   G       i32  [3 planes][ksplit][mf][nfl][64][4]   asymmetric gradient slab per digit plane and K range: EXACT
+//                                  integer sums (one 16x16 MFMA accumulator tile per (row fragment, col fragment));
+//                                  consumers combine g = gscale * sum_k (G0 + 256 G1 + 65536 G2)
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -23,7 +28,19 @@
 
 #define PLM_PAD_STATE 127
 #define PLM_SEQ_TILE 256      // sequences per forward workgroup (8 waves x 32)
-#define PLM_R_EXP 14          // residuals are stored scaled by 2^14 (|r| <= scale <= 1)
+#define PLM_R_EXP 14          // forward operand: couplings are stored scaled by 2^(14 - exponent of max|J|)
+// Backward GEMM on the int8 matrix cores: residuals in 24-bit fixed point, three signed base-256 digit
+// planes, ONE plane per workgroup (the plane index takes the place of most of the split-K factor), int32 accumulators.
+// The largest magnitude whose digits all fit int8 is 127 * (65536 + 256 + 1) = 8 355 711; the scale maps the largest
+// weight a little below it, so that the float rounding of w * rscale * (P - delta) (|P - delta| <= 1) cannot cross it.
+// Three planes (24 bits) are the default: their quantisation noise in the gradient, ~2^-24 w_max sqrt(2 L^2 q N / 12) in
+// norm, is ~5e-5 |x| at the headline, far inside the stop rule 1e-3.  A fit asked to converge below 1e-4 (tests that
+// compare optima at tight tolerance) runs FOUR planes (32 bits: every bit of the f32 residuals) at 4/3 of the cost.
+#define PLM_BWD_MAXPLANES 4
+#define PLM_R_QMAX3 8355000.0f          // < 127 * (65536 + 256 + 1)
+#define PLM_R_QMAX4 2138000000.0f       // < 127 * (16777216 + 65536 + 256 + 1) = 2 139 062 143
+#define PLM_BWD_KSTEP 128     // sequences per K step of k_bwd (two v_mfma_i32_16x16x64_i8 sub-steps)
+#define PLM_BWD_ONEHOT_VALUE (-128)   // the one-hot operand of k_bwd holds -128 for a match (two VALU ops per 4 sites)
 
 // Forward GEMM on the 2:4 sparse MFMA (v_smfmac_f32_16x16x64_f16): the K index is ordered (site, state) with the
 // alphabet padded to a multiple of 4, so that every group of 4 dense K slots holds 4 states of ONE site -- at most
@@ -50,7 +67,11 @@ struct PlmDims {
     int nu;        // 32-site K blocks covering L
     int Lp32;      // nu * 32
     int nksteps;   // nu * PLM_FWD_SPU(Q)   forward K steps (tiles of 2 Q KB)
-    int nssteps;   // Np / 32     backward K steps (32 sequences)
+    int nssteps;   // Np / 32     (32-sequence groups: the wave granularity of the forward-side kernels)
+    int nst128;    // Np / 128    backward K steps (PLM_BWD_KSTEP sequences)
+    int nplanes;   // digit planes of the residuals: 3 (24-bit fixed point) or 4 (32-bit)
+    float rscale;  // residual quantisation: R = rint(r * rscale), rscale = PLM_R_QMAX{3,4} / max_s w_s (set with the weights)
+    float gscale;  // 1 / rscale: turns the integer gradient sums back into residual units
     int nstiles;   // Np / PLM_SEQ_TILE
     int FM, FN;    // backward wave tile in fragments
     int nmf;       // row fragments of the backward GEMM: nb16*Q + FM (last FM = "ones" block)
@@ -121,9 +142,11 @@ hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, cons
 // one pass over HJ with the fields of x: per-workgroup per-site sums for the field solver (stats 1: gradient sums
 // into gpart (f64), 2: also Hessian sums -- exact diagonal, sampled off-diagonal -- into hpart (f32)) and, with write_rt, the residual fragments (Rt) and -log P partials
 // (fx_part) of the solver's forward epilogue.  skip (device int, may be NULL): non-zero = do nothing.
-hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const double *h64,
-                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, double *gpart,
-                            const int *skip, hipStream_t st);
+// Bt: the forward operand whose GEMM produced hj (its tail holds the reference-state constants the stored potentials
+// leave out, added here in f64 with the fields)
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const void *Bt, const int8_t *msa_rm, const float *w,
+                            const double *h64, int write_rt, int stats, void *Rt, double *fx_part, float *hpart,
+                            double *gpart, const int *skip, hipStream_t st);
 // Per-site gradient norms of the last pass (their sum -> g2_out[0]); update = 1: sites above their share of tol2 take a
 // Newton step on the field part of x (full = that pass carried Hessian sums: inverse recomputed and cached in hinv
 // [sites][Q][Q]; else the cached inverse).  *flag (device, required) is raised when no site is above its share and
@@ -145,17 +168,20 @@ size_t plm_hj_bytes(const PlmDims &d);
 size_t plm_hpart_bytes(const PlmDims &d);   // Hessian sums (f32)
 size_t plm_gpart_bytes(const PlmDims &d);   // gradient sums (f64)
 // run (device int, may be NULL): the kernel returns at once while *run == 0
-hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G, const int *run,
+hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, int32_t *G, const int *run,
                                hipStream_t st);
-hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab, hipStream_t st);
-// g = 2^-R_EXP * (G + G^T) + 2 lambda x ; mode 1: marginals (out = G / neff, no symmetrisation)
-hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *ghalo,
+// replicated multi-shard mode: planes and K ranges combined into this shard's float slab (residual units / gscale)
+hipError_t plm_launch_slab_reduce(const PlmDims &d, const int32_t *G, float *slab, hipStream_t st);
+// g = gscale * (G + G^T) + 2 lambda x ; mode 1: marginals (out = G / neff, no symmetrisation).  G: the int32 plane /
+// K-range partials of k_bwd (ks_count = d.ksplit), or with ks_count = 0 a float slab already combined (the gathered
+// slabs of the replicated multi-shard mode)
+hipError_t plm_launch_assemble(const PlmDims &d, const void *G, int ks_count, const float *ghalo,
                                const float *x, float *g, float lambda_h, float lambda_j, double *reg_part,
                                int mode, float inv_neff, hipStream_t st);
 // sharded-state exchange staging: blocks of Q*Q*256 floats
 #define PLM_BLOCK_FLOATS(d) ((size_t)(d).Q * (d).Q * 256)
 hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, hipStream_t st);
-hipError_t plm_launch_pack_g(const PlmDims &d, const float *G, float *sendbuf, hipStream_t st);
+hipError_t plm_launch_pack_g(const PlmDims &d, const int32_t *G, float *sendbuf, hipStream_t st);
 hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_t nb, uint32_t *maxbits,
                               int32_t *jexp, hipStream_t st);
 hipError_t plm_launch_finish_fx(const PlmDims &d, const double *fx_part, int n_fx_part,
@@ -177,7 +203,7 @@ hipError_t plm_launch_align_stats(const int8_t *msa, int n, int L, int gap_state
                                   int32_t *col_gaps, int32_t *ident, hipStream_t st);
 size_t plm_bt_bytes(const PlmDims &d);
 size_t plm_rt_bytes(const PlmDims &d);
-size_t plm_g_bytes(const PlmDims &d);      // [ksplit][nmf][nnfl][256] floats
+size_t plm_g_bytes(const PlmDims &d);      // [nplanes][ksplit][nmf][nnfl][256] int32
 size_t plm_slab_bytes(const PlmDims &d);   // [nmf][nnfl][256] floats + 256 B tail (shard nll)
 int plm_reg_parts(const PlmDims &d);       // number of double partials assemble writes
 bool plm_q_supported(int q);     // 2..21

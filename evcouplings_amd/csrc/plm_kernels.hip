@@ -35,6 +35,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
 // PLM_PIPE selects how the streamed B tiles of k_fwd / k_bwd are synchronised.
@@ -147,6 +148,43 @@ template <int N> __device__ __forceinline__ void lds_wait(half8 &a, half8 &b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
+// the same for the int8 fragments of the backward GEMM (one 16-byte fragment slot per read)
+template <int OFF> __device__ __forceinline__ i32x4 lds_read_b128_i(u32 addr) {
+    i32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N> __device__ __forceinline__ void lds_wait_i(i32x4 &a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+
+// ---- residuals in fixed point, signed base-256 digits (backward GEMM on the int8 matrix cores) -------------------
+// Three digits: R in [-8355711, 8355711], R + 0x808080 lies in [0, 2^24) and its bytes are the digits + 128
+// (R = sum_k (u_k - 128) 256^k  <=>  sum_k u_k 256^k = R + 128 (1 + 256 + 65536)); xor 0x80 per byte turns u_k into the
+// two's-complement digit d_k = u_k - 128.  Four digits: the same with 0x80808080 in 32-bit wrap-around arithmetic
+// (|R| <= 2 139 062 143).  Returns the digits in bytes 0-2 (0-3).
+__device__ __forceinline__ u32 digits_of(float v, bool four) {
+    const u32 bias = four ? 0x80808080u : 0x00808080u;
+    const int R = (int)__builtin_rintf(v);       // ties to even: unbiased (|v| <= PLM_R_QMAX by construction)
+    return ((u32)R + bias) ^ bias;
+}
+// bytes p of four digit words -> the plane words [x0.p, x1.p, x2.p, x3.p] (v_perm_b32: selector byte 0-3 picks a byte
+// of the SECOND source, 4-7 of the first)
+__device__ __forceinline__ void planes_of4(u32 x0, u32 x1, u32 x2, u32 x3, u32 (&pl)[PLM_BWD_MAXPLANES]) {
+    const u32 t01 = __builtin_amdgcn_perm(x1, x0, 0x05010400u);   // x0.b0 x1.b0 x0.b1 x1.b1
+    const u32 t23 = __builtin_amdgcn_perm(x3, x2, 0x05010400u);
+    const u32 u01 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);   // x0.b2 x1.b2 x0.b3 x1.b3
+    const u32 u23 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+    pl[0] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+    pl[1] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+    pl[2] = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+    pl[3] = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+}
+// byte address of the 16-byte fragment slot of (plane, 64-sequence group s64, column fragment nf, lane slot) in Rt
+__device__ __forceinline__ size_t rt_slot(const PlmDims &d, int plane, int s64, int nf, int slot) {
+    return ((((size_t)plane * d.nst128 + (s64 >> 1)) * d.nnfl + nf) * 2 + (s64 & 1)) * 1024 + (size_t)slot * 16;
+}
+
 // ---- LDS-DMA staging of the next tile -----------------------------------------------------------
 // A tile is copied global -> LDS in 1 KB pieces (one global_load_lds per wave-instruction); wave w copies
 // pieces w, w+8, ...  (the wave number is passed through readfirstlane so the piece tests are scalar
@@ -160,6 +198,11 @@ struct DmaPlan {
     int limit;         // number of pieces to copy (0 = nothing to stage)
     u32 lane_off;      // lane * 16: the only per-lane part of the address
     bool late;         // this wave issues in the second slot of the step (PLM_DMA_STAGGER_*)
+    // k_bwd: one more piece per wave, the alignment bytes of its row group for one half of the next K step (gathered:
+    // every lane has its own global address, the LDS side is lane-linear like every piece)
+    const char *a_src = nullptr;   // wave-uniform base (nullptr: no such piece)
+    u32 a_off = 0;                 // per-lane byte offset
+    char *a_dst = nullptr;         // LDS destination (wave-uniform)
 };
 template <int NP> __device__ __forceinline__ void dma_issue_all(const DmaPlan &P) {
 #pragma unroll
@@ -168,6 +211,7 @@ template <int NP> __device__ __forceinline__ void dma_issue_all(const DmaPlan &P
         if (p < P.limit)
             __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024 + P.lane_off), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
     }
+    if (P.a_src) __builtin_amdgcn_global_load_lds(GLB_PTR(P.a_src + P.a_off), LDS_PTR(P.a_dst), 16, 0, 0);
 }
 // the two issue slots of a step with NF fragments: S0 for the early waves, S1 for the late ones
 template <int NF, int A, int NP, int STG> __device__ __forceinline__ void dma_at(const DmaPlan &P) {
@@ -215,10 +259,19 @@ void plm_pick_tile(int q, int *fm, int *fn) {
 // forward operand: the K-step tiles of every local column block, then (sparse formulation) the reference-state
 // constants C[local site][Q] as floats
 size_t plm_bt_bytes(const PlmDims &d) {
-    return (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024 + (size_t)d.blk_per_shard * 16 * d.Q * sizeof(float);
+    return (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024 +
+           (size_t)d.blk_per_shard * 16 * d.Q * (sizeof(float) + sizeof(double));
 }
-size_t plm_rt_bytes(const PlmDims &d) { return (size_t)d.nssteps * d.nnfl * 2 * 1024; }
-size_t plm_g_bytes(const PlmDims &d) { return (size_t)d.ksplit * d.nmf * d.nnfl * 1024; }
+// the reference-state constants behind the tiles: C[local site][Q] as floats (energy / potential epilogues of k_fwd),
+// then the same in f64 (the fit: k_hpass adds them together with the fields, as a hi + lo pair)
+static inline const float *bt_cref32(const PlmDims &d, const void *Bt) {
+    return (const float *)((const char *)Bt + (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024);
+}
+static inline const double *bt_cref64(const PlmDims &d, const void *Bt) {
+    return (const double *)(bt_cref32(d, Bt) + (size_t)d.blk_per_shard * 16 * d.Q);
+}
+size_t plm_rt_bytes(const PlmDims &d) { return (size_t)d.nplanes * d.nst128 * d.nnfl * 2 * 1024; }
+size_t plm_g_bytes(const PlmDims &d) { return (size_t)d.nplanes * d.ksplit * d.nmf * d.nnfl * 1024; }
 size_t plm_slab_bytes(const PlmDims &d) { return (size_t)d.nmf * d.nnfl * 1024 + 256; }
 int plm_reg_parts(const PlmDims &d) { return (int)(d.np_own * d.Q) + (int)((d.nh_pad_l + 255) / 256); }
 
@@ -417,32 +470,39 @@ hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thres
 // one-hot residual builder for the marginals:  R[s,(i,a)] = w_s [x_si = a]  in Rt layout
 // =========================================================================================
 __global__ __launch_bounds__(256) void k_onehot_rt(PlmDims d, const int8_t *__restrict__ msa_rm,
-                                                  const float *__restrict__ w, _Float16 *__restrict__ Rt,
-                                                  float rscale) {
-    const int sstep = blockIdx.x, b16l = blockIdx.y, b16 = d.b16_lo + b16l;
+                                                  const float *__restrict__ w, char *__restrict__ Rt) {
+    // one workgroup per (64-sequence group, site block): for every state a fragment of 64 lanes x 16 sequences
+    const int s64 = blockIdx.x, b16l = blockIdx.y, b16 = d.b16_lo + b16l;
     for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
         const int a = idx >> 6, lane = idx & 63, kg = lane >> 4, ii = lane & 15;
         const int i = b16 * 16 + ii;
-        half8 hi, lo;
+        u32 pw[PLM_BWD_MAXPLANES][4];
+        const bool four = d.nplanes == 4;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int s = sstep * 32 + kg * 8 + perm8(e);
-            float v = 0.f;
-            if (i < d.L && b16 < d.nb16 && msa_rm[(size_t)s * d.Lp32 + i] == a) v = w[s] * rscale;
-            const _Float16 h = (_Float16)v;
-            hi[e] = h;
-            lo[e] = (_Float16)(v - (float)h);
+        for (int q4 = 0; q4 < 4; q4++) {
+            u32 x[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int s = s64 * 64 + kg * 16 + q4 * 4 + e;
+                float v = 0.f;
+                if (i < d.L && b16 < d.nb16 && msa_rm[(size_t)s * d.Lp32 + i] == a) v = w[s] * d.rscale;
+                x[e] = digits_of(v, four);
+            }
+            u32 pl[PLM_BWD_MAXPLANES];
+            planes_of4(x[0], x[1], x[2], x[3], pl);
+#pragma unroll
+            for (int p = 0; p < PLM_BWD_MAXPLANES; p++) pw[p][q4] = pl[p];
         }
-        const size_t base = (((size_t)sstep * d.nnfl + (size_t)b16l * d.Q + a) * 2) * 512 + (size_t)lane * 8;
-        *(half8 *)(Rt + base) = hi;
-        *(half8 *)(Rt + base + 512) = lo;
+#pragma unroll
+        for (int p = 0; p < PLM_BWD_MAXPLANES; p++)
+            if (p < d.nplanes)
+                *(uint4 *)(Rt + rt_slot(d, p, s64, b16l * d.Q + a, lane)) = make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]);
     }
 }
 hipError_t plm_launch_onehot_rt(const PlmDims &d, const int8_t *msa_rm, const float *w, void *Rt,
                                 hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;   // a trailing shard may own no site block
-    hipLaunchKernelGGL(k_onehot_rt, dim3(d.nssteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, msa_rm, w,
-                       (_Float16 *)Rt, ldexpf(1.f, PLM_R_EXP));
+    hipLaunchKernelGGL(k_onehot_rt, dim3(2 * d.nst128, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, msa_rm, w, (char *)Rt);
     return hipGetLastError();
 }
 
@@ -528,7 +588,7 @@ __device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__
 // k_fwd_ref: the constant the differences leave out, C[i][a] = sum_{j != i} J_ij(a, 0) (zero in gap mode, where state 0
 // is not a model state), unscaled, behind the tiles.
 __global__ __launch_bounds__(64) void k_fwd_ref(PlmDims d, const float *__restrict__ x, const float *__restrict__ xhalo,
-                                               float *__restrict__ cref) {
+                                               float *__restrict__ cref, double *__restrict__ cref64) {
     const int b16l = blockIdx.x, b16 = d.b16_lo + b16l, r = blockIdx.y, a = blockIdx.z, t = threadIdx.x;
     const int i = b16 * 16 + r;
     const float *__restrict__ xj = x + d.nh_pad_l;
@@ -537,14 +597,17 @@ __global__ __launch_bounds__(64) void k_fwd_ref(PlmDims d, const float *__restri
         for (int j = t; j < d.L; j += 64)
             if (j != i) s += (double)load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (t == 0) cref[((size_t)b16l * 16 + r) * d.Q + a] = (float)s;
+    if (t == 0) {
+        cref[((size_t)b16l * 16 + r) * d.Q + a] = (float)s;
+        cref64[((size_t)b16l * 16 + r) * d.Q + a] = s;
+    }
 }
 __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restrict__ x,
                                                const float *__restrict__ xhalo,
                                                const int32_t *__restrict__ jexp, _Float16 *__restrict__ Bt) {
     const int NG = PLM_FWD_NG(d.Q), SPU = 4 * NG;
     const int u = blockIdx.x / (2 * NG), ci = blockIdx.x % (2 * NG), b16l = blockIdx.y, b16 = d.b16_lo + b16l;
-    const float sc = ldexpf(1.f, *jexp);
+    const double sc = ldexp(1.0, *jexp);
     const float *__restrict__ xj = x + d.nh_pad_l;
     _Float16 *tile_hi = Bt + ((size_t)b16l * d.nksteps + (size_t)u * SPU + 2 * ci) * (size_t)(2 * d.Q * 512);
     _Float16 *tile_lo = tile_hi + (size_t)(2 * d.Q * 512);
@@ -559,15 +622,17 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
                 const int ga = 2 * half + (gb >> 1), pp = 2 * (gb & 1) + (e8 >> 2), e = e8 & 3;
                 const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl % NG;
                 const int b = 4 * sg + e + 1, j = 32 * u + 8 * ga + s8;     // state 0 has no slot (reference state)
-                float v = 0.f;
+                // the difference to the reference state, exact in f64 (two f32 values), scaled by a power of two and split
+                // hi = f16(v), lo = f16(v - hi): 23 significant bits of the DIFFERENCE (an f32 subtraction would round first)
+                double v = 0.0;
                 if (b < d.Q && i < d.L && j < d.L && i != j) {
-                    v = load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, b);
-                    if (!d.gap_mode) v -= load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
+                    v = (double)load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, b);
+                    if (!d.gap_mode) v -= (double)load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
                     v *= sc;
                 }
                 const _Float16 h = (_Float16)v;
                 hi[e8] = h;
-                lo[e8] = (_Float16)(v - (float)h);
+                lo[e8] = (_Float16)(v - (double)h);
             }
             *(half8 *)(tile_hi + (size_t)(half * d.Q + a) * 512 + lane * 8) = hi;
             *(half8 *)(tile_lo + (size_t)(half * d.Q + a) * 512 + lane * 8) = lo;
@@ -610,7 +675,7 @@ hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhal
                        (_Float16 *)Bt);
 #if PLM_SPARSE_FWD
     hipLaunchKernelGGL(k_fwd_ref, dim3(d.b16_hi - d.b16_lo, 16, d.Q), dim3(64), 0, st, d, x, xhalo,
-                       (float *)((char *)Bt + (size_t)d.blk_per_shard * d.nksteps * 2 * d.Q * 1024));
+                       (float *)bt_cref32(d, Bt), (double *)bt_cref64(d, Bt));
 #endif
     return hipGetLastError();
 }
@@ -855,12 +920,14 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
         const float sc = ldexpf(1.f, -(*A.jexp));
         float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + wave) * 2 * Q * 64 + lane;
 #pragma unroll
+        // the reference-state constant C_i(a) is NOT added here: rounded into these f32 values it would shift the
+        // potentials of every sequence of a (site, state) by the same ~1e-7 |C| -- a coherent error that the gradient
+        // sums add up N-fold (tests/probes/fwd_bias_probe.py).  k_hpass adds it in f64 together with the field.
         for (int a = 0; a < Q; a++) {
-            const float c = PLM_CREF(a);
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const f32x4 v = acc[m][a];
-                hj[(size_t)(m * Q + a) * 64] = make_float4(fmaf(v[0], sc, c), fmaf(v[1], sc, c), fmaf(v[2], sc, c), fmaf(v[3], sc, c));
+                hj[(size_t)(m * Q + a) * 64] = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
             }
         }
         return;
@@ -994,13 +1061,35 @@ __device__ __forceinline__ float sum_over_g(float v) {
     auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// exp(x) for the softmax.  __expf is v_exp_f32(x * 1.44269502f): the float nearest to log2(e) is 1.33e-8 (relative) too
+// small, which evaluates every softmax at a temperature 1.33e-8 off -- for x = H - max = -8 every probability comes out
+// 1e-7 too LARGE, the same way in every sequence: a coherent error that the gradient sums add up N-fold.  It was the
+// systematic part of |g_hip - g_f64| at scale (4.7e-4 |x| at the headline, growing with N L; round 2 attributed it to
+// the MFMA accumulation).  Adding the low part of the constant to the PRODUCT does not help: x * LO is below half an ulp
+// of x * HI and rounds away every time.  It is applied to the RESULT instead: exp(x) = 2^(x HI) * 2^(x LO) =
+// r + r * (x * LO ln 2).  What is left is the random rounding of x * HI, which averages out over the sequences.
+// (x = -inf, a masked state, is clamped to a finite value whose exponential is still exactly 0: 0 * inf would be NaN.)
+__device__ __forceinline__ float exp_unbiased(float x) {
+    const float LOG2E_HI = 1.44269502162933349609375f;       // 0x3fb8aa3b, the float nearest to log2(e)
+    const float LO_LN2 = 1.3349758e-8f;                      // (log2(e) - LOG2E_HI) * ln 2
+    x = fmaxf(x, -200.f);
+    const float r = __builtin_amdgcn_exp2f(x * LOG2E_HI);
+    return __builtin_fmaf(r, x * LO_LN2, r);
+}
+// log(z) = log2(z) * ln 2 with the same care (the f32 ln 2 is 2.1e-9 too large; irrelevant for the gradient, kept exact
+// for the objective's sake)
+__device__ __forceinline__ float log_unbiased(float z) {
+    const float l2 = __builtin_amdgcn_logf(z);
+    return __builtin_fmaf(l2, -1.904654323148236e-9f, l2 * 0.693147182464599609375f);   // ln 2 = HI + LO
+}
 __global__ void k_sum_partials(const double *__restrict__ p, int n, double *out);
 struct HpassArgs {
     const float4 *hj;
     const int8_t *msa_rm;
     const float *w;
     const double *h;      // fields of the local sites in f64 (the solver's copy: see k_hsolve)
-    _Float16 *Rt;
+    const double *c;      // reference-state constants of the forward GEMM, [local site][Q] f64 (NULL: none)
+    char *Rt;
     double *fx_part;
     float *hpart;         // [workgroup][16 sites][NH]  Hessian sums, NH = Q (Q + 1) / 2 (STATS == 2 only)
     double *gpart;        // [workgroup][16 sites][Q]   gradient sums, f64: their f32 accumulation was the noise floor
@@ -1028,16 +1117,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     const int gap = d.gap_mode;
     const int i = b16 * 16 + r;
     const bool site_ok = i < d.L;
-    // the fields as hi + lo f32 pairs of their f64 values.  A field rounded to f32 shifts H of EVERY sequence by the
-    // same ~1e-7, a systematic error of the gradient sums that put a floor of ~1e-2 under |g_h| at N = 50 000; with
-    // the low part added separately the rounding of (HJ + lo) + hi differs from sequence to sequence and averages out
-    float hv[Q], hl[Q];
-#pragma unroll
-    for (int a = 0; a < Q; a++) {
-        const double h64 = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.0;
-        hv[a] = (float)h64;
-        hl[a] = (float)(h64 - (double)hv[a]);
-    }
+    // (the fields are read inside the loop over the two halves: see there)
     float fxl = 0.f;
     // statistics areas, one per wave: gradient sums [site][Q] in f64, then Hessian sums [site][NH] in f32.  Lanes add
     // with fire-and-forget LDS adds (the 4 lanes of a site collide on one address inside one instruction: resolved in
@@ -1058,6 +1138,20 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     asm volatile("" : "+s"(m_end));   // opaque trip count: the loop must not be unrolled (register pressure)
 #pragma nounroll
     for (int m = 0; m < m_end; m++) {
+        // the fields (+ the reference-state constants of the forward GEMM) as hi + lo f32 pairs of their f64 values.  A
+        // field rounded to f32 shifts H of EVERY sequence by the same ~1e-7, a systematic error of the gradient sums that
+        // put a floor of ~1e-2 under |g_h| at N = 50 000; with the low part added separately the rounding of
+        // (HJ + lo) + hi differs from sequence to sequence and averages out.  Read once per half (42 registers that
+        // would otherwise stay live through the residual epilogue of the first half; the second read hits L2).
+        float hv[Q], hl[Q];
+        u32 hoff = (u32)(site_ok ? i - d.h_site0 : 0) * Q, coff = (u32)(b16l * 16 + r) * Q;
+        asm volatile("" : "+v"(hoff), "+v"(coff));   // opaque per iteration: the loads must not be hoisted out of the loop
+#pragma unroll
+        for (int a = 0; a < Q; a++) {
+            const double h64 = site_ok ? A.h[hoff + a] + (A.c ? A.c[coff + a] : 0.0) : 0.0;
+            hv[a] = (float)h64;
+            hl[a] = (float)(h64 - (double)hv[a]);
+        }
         f32x4 acc[Q];
 #pragma unroll
         for (int a = 0; a < Q; a++) {
@@ -1084,12 +1178,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             for (int a = 0; a < Q; a++) {
                 const float H = acc[a][reg] - mx;
                 hx = (a == xi) ? H : hx;
-                const float ev = __expf(H);
+                const float ev = exp_unbiased(H);
                 acc[a][reg] = ev;
                 Z += ev;
             }
             const float invZ = 1.f / Z;
-            if (WRITE_RT && ws > 0.f) fxl -= ws * (hx - __logf(Z));
+            if (WRITE_RT && ws > 0.f) fxl -= ws * (hx - log_unbiased(Z));
 #pragma unroll
             for (int a = 0; a < Q; a++) acc[a][reg] *= invZ;     // P
             wk[reg] = ws;
@@ -1129,37 +1223,62 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             }
         }
         if constexpr (WRITE_RT) {
-            // ---- residuals -> Rt as backward-pass B fragments (hi / lo f16 planes), as in k_fwd ------------
-            const int sstep = s_wave >> 5;
-            char *rt_u = (char *)(A.Rt + ((size_t)sstep * d.nnfl + (size_t)b16l * Q) * 1024);   // wave-uniform
-            // byte offset of the lane's 16-byte slot: fragment lane (2m + g/2, r); odd g -> the lo plane (+1 KB)
-            const u32 slot16 = (u32)((2 * m + (g >> 1)) * 16 + r) * 16 + (u32)(g & 1) * 1024;
+            // ---- residuals -> Rt: 24-bit fixed point, three signed digit planes, B fragments of the int8 backward
+            // GEMM.  A fragment covers 64 sequences (two waves of this tile): this wave's half m is lane group
+            // Gq = 2 (wave & 1) + m of it, and the lane's 4 sequences (4 g .. 4 g + 3 of the half) are dword g of the
+            // 16-byte slot of lane (Gq, site r).
+            __builtin_amdgcn_sched_barrier(0);   // nothing of the epilogue is to be hoisted into the statistics section
+            const int s64 = stile * 4 + (wave >> 1);
+            const int Gq = 2 * (wave & 1) + m;
+            // wave-uniform base of (plane 0, this K half-step, state 0 of the site block) + the stride between planes;
+            // per lane only a 32-bit offset: (state) * 2048 + slot * 16
+            char *rt_u = A.Rt + rt_slot(d, 0, s64, b16l * Q, 0);
+            const size_t rt_plane = (size_t)d.nst128 * d.nnfl * 2048;
+            const u32 slot16 = (u32)(Gq * 16 + r) * 16;
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 wk[reg] *= A.rscale;
                 asm volatile("" : "+v"(xk[reg]));
             }
-#pragma unroll
-            for (int a = 0; a < Q; a++) {
-                f32x4 v;
+            // digit words of state a for the lane's 4 sequences
+            const bool four = d.nplanes == 4;
+            auto planes_of_state = [&](int a, u32 (&pl)[PLM_BWD_MAXPLANES]) {
+                u32 x[4];
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++)
-                    v[reg] = wk[reg] * (acc[a][reg] - ((a == xk[reg]) ? 1.f : 0.f));
-                union { half4 h; u32 w[2]; } hi, lo;
-                hi.h[0] = (_Float16)v[0]; hi.h[1] = (_Float16)v[2]; hi.h[2] = (_Float16)v[1]; hi.h[3] = (_Float16)v[3];
-                lo.h[0] = (_Float16)(v[0] - (float)hi.h[0]); lo.h[1] = (_Float16)(v[2] - (float)hi.h[1]);
-                lo.h[2] = (_Float16)(v[1] - (float)hi.h[2]); lo.h[3] = (_Float16)(v[3] - (float)hi.h[3]);
-                // the 16-byte slot of a fragment lane = the 4 halves of sequence group g (even) + those of g + 1:
-                // swap rows so that even-g lanes hold the whole hi slot and odd-g lanes the whole lo slot, then
-                // ONE 16-byte store per lane (v_permlane16_swap: odd rows of the first <-> even rows of the second)
-                uint4 o;
-                {
-                    auto p0 = __builtin_amdgcn_permlane16_swap(hi.w[0], lo.w[0], false, false);
-                    auto p1 = __builtin_amdgcn_permlane16_swap(hi.w[1], lo.w[1], false, false);
-                    o = make_uint4(p0[0], p1[0], p0[1], p1[1]);
+                    x[reg] = digits_of(wk[reg] * (acc[a][reg] - ((a == xk[reg]) ? 1.f : 0.f)), four);
+                planes_of4(x[0], x[1], x[2], x[3], pl);
+            };
+            // four states at a time: a 4 x 4 transpose over the lane groups g (2 + 2 row swaps per plane) leaves lane
+            // group g with the whole 16-byte slot of state 4 q + g -> ONE 16-byte store per lane, plane and 4 states
+#pragma unroll
+            for (int q4 = 0; q4 + 4 <= Q; q4 += 4) {
+                u32 pl[4][PLM_BWD_MAXPLANES];
+#pragma unroll
+                for (int k = 0; k < 4; k++) planes_of_state(q4 + k, pl[k]);
+                const u32 off = (u32)(q4 + g) * 2048 + slot16;
+#pragma unroll
+                for (int p = 0; p < PLM_BWD_MAXPLANES; p++) {
+                    if (p >= d.nplanes) break;
+                    // X[k] = rows (k0 k1 k2 k3) over g.  permlane32_swap(X0, X2): upper half of X0 <-> lower half of X2
+                    auto s02 = __builtin_amdgcn_permlane32_swap(pl[0][p], pl[2][p], false, false);   // (00 01 20 21) (02 03 22 23)
+                    auto s13 = __builtin_amdgcn_permlane32_swap(pl[1][p], pl[3][p], false, false);   // (10 11 30 31) (12 13 32 33)
+                    // permlane16_swap(A, B): odd rows of A <-> even rows of B
+                    auto t0 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);        // (00 10 20 30) (01 11 21 31)
+                    auto t1 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);        // (02 12 22 32) (03 13 23 33)
+                    // row g now holds, for state q4 + g, the dwords of source rows 0, 1, 2, 3 = bytes 0-3, 4-7, 8-11, 12-15
+                    *(uint4 *)(rt_u + p * rt_plane + off) = make_uint4(t0[0], t0[1], t1[0], t1[1]);
                 }
-                *(uint4 *)(rt_u + (size_t)a * 2048 + slot16) = o;
-                __builtin_amdgcn_sched_barrier(0);   // one state at a time (hipcc otherwise hoists all 84 compares)
+                __builtin_amdgcn_sched_barrier(0);   // one group at a time (hipcc otherwise hoists every compare)
+            }
+            // the Q % 4 states left over: one dword per lane
+#pragma unroll
+            for (int a = Q - Q % 4; a < Q; a++) {
+                u32 pl[PLM_BWD_MAXPLANES];
+                planes_of_state(a, pl);
+#pragma unroll
+                for (int p = 0; p < PLM_BWD_MAXPLANES; p++)
+                    if (p < d.nplanes) *(u32 *)(rt_u + p * rt_plane + (u32)a * 2048 + slot16 + 4 * g) = pl[p];
             }
         }
     }
@@ -1188,13 +1307,14 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
         if (tid == 0) A.fx_part[blk] = tot;
     }
 }
-hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w, const double *h64,
-                            int write_rt, int stats, void *Rt, double *fx_part, float *hpart, double *gpart,
-                            const int *skip, hipStream_t st) {
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const void *Bt, const int8_t *msa_rm, const float *w,
+                            const double *h64, int write_rt, int stats, void *Rt, double *fx_part, float *hpart,
+                            double *gpart, const int *skip, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const int nb = d.b16_hi - d.b16_lo, ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
     const dim3 block(512);
-    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (_Float16 *)Rt, fx_part, hpart, gpart, ldexpf(1.f, PLM_R_EXP), skip, 0};
+    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (PLM_SPARSE_FWD && Bt) ? bt_cref64(d, Bt) : nullptr, (char *)Rt, fx_part,
+                hpart, gpart, d.rscale, skip, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
         const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
@@ -1443,185 +1563,180 @@ hipError_t plm_launch_energy_sum(const PlmDims &d, const float *part, double *ou
 }
 
 // =========================================================================================
-// K_bwd: asymmetric gradient slab  G[(j,b),(i,a)] = sum_s [x_sj = b] * r_s(i,a)
-//   (row a6 backward half).  GEMM over K = sequences; A = one-hot of the column-major
-//   alignment expanded in registers, B = residual fragments (Rt) streamed through LDS.
-//   workgroup = 8 waves as 4 (rows) x 2 (cols); wave tile FM x FN accumulator fragments.
-//   Split-K over sequence ranges; XCD-aware block order keeps the row tiles that share a
-//   residual panel on one XCD (block b runs on XCD b % 8).
+// K_bwd: asymmetric gradient slab  G[(j,b),(i,a)] = sum_s [x_sj = b] * R_s(i,a)   (row a6 backward half)
+//   on the int8 matrix cores, EXACT: the residuals arrive in 24-bit fixed point as three signed base-256 digit planes
+//   (k_hpass / k_onehot_rt), a workgroup contracts ONE plane over its K range with v_mfma_i32_16x16x64_i8 into int32
+//   accumulators, the consumers combine G0 + 256 G1 + 65536 G2.  GEMM over K = sequences; A = one-hot {0,1} bytes of
+//   the column-major alignment expanded in registers (16 sequences per lane and instruction), B = digit fragments
+//   (Rt) streamed through LDS.  Why this shape:
+//     * the int8 instruction does twice the K of the f16 one in the same cycles; three digit planes replace the
+//       f16 hi + lo planes of rounds 1-2: 3/4 of the matrix-core cycles, of the LDS reads and of the L2->LDS stream;
+//     * one plane per workgroup keeps the 7 x 7 fragment register tile whole (three accumulator sets would not fit)
+//       and takes the place of most of the split-K factor (3 x the workgroups of a launch for free);
+//     * integer accumulation has no rounding: the sum is independent of tiling, K split and order (bit-reproducible
+//       by construction) and the error of the gradient is the quantisation of the residuals alone (2^-24 of the
+//       largest weight per term, unbiased) -- the f32 accumulation of rounds 1-2 left a systematic offset that grew
+//       with N (4e-4 |x| at N = 50 000, 1e-3 |x| at N = 100 000).
+//   A K step is 128 sequences = two 64-sequence halves (two fragments per column fragment in the tile, at the byte
+//   offsets the f16 hi / lo planes used to have); workgroup = 8 waves as 4 (rows) x 2 (cols), wave tile FM x FN
+//   accumulator fragments; |sum| <= 128 * 127 * K < 2^31 for K ranges below 132 000 sequences (make_dims splits K
+//   accordingly).  XCD-aware block order: the
+//   row tiles that share a (column tile, plane, K range) panel of Rt run on one XCD (block b runs on XCD b % 8).
 // =========================================================================================
-// one K step (32 sequences) of the backward GEMM for one wave: the B fragments of column C+1 are
-// in flight while the 2*FM MFMAs of column C run.  Two fragment slots; with PLM_PIPE the read for column 0
-// of the NEXT step (LDS address lbn) is issued behind the last column, so when FN is odd the slot
-// parity PAR alternates from step to step (two instantiations of the step).
-template <int FM, int FN, int C, int PAR>
-__device__ __forceinline__ void bwd_col(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb, u32 lbn,
-                                        half8 (&bh)[2], half8 (&bl)[2], const DmaPlan &dma) {
-    constexpr int MID = (FN - 2) / 2, NP = (4 * FN + 7) / 8;
-    constexpr int me = (C + PAR) & 1, nx = (C + 1 + PAR) & 1;
-    if constexpr ((PLM_ABLATE & 4) != 0) {
-        if constexpr (C == 0) lds_wait<0>(bh[me], bl[me]);
-        bh[nx] = bh[me];
-        bl[nx] = bl[me];
-    } else if constexpr (C + 1 < FN) {
-        bh[nx] = lds_read_b128<(C + 1) * 2048>(lb);
-        bl[nx] = lds_read_b128<(C + 1) * 2048 + 1024>(lb);
-    } else if constexpr (PLM_PIPE) {
-        bh[nx] = lds_read_b128<0>(lbn);
-        bl[nx] = lds_read_b128<1024>(lbn);
-    }
-    if constexpr ((PLM_ABLATE & 4) == 0) lds_wait<(PLM_PIPE || C + 1 < FN) ? 2 : 0>(bh[me], bl[me]);
+// one-hot of 16 packed states (4 dwords) against state b (replicated into every byte of bb): 16 int8 values, -128
+// where the state matches and 0 elsewhere -- two VALU operations per dword (the expansion shares the issue port with
+// the MFMAs: with {0, 1} values, four operations per dword, the kernel ran 5.0 ms).  States are < 128, so
+// (x ^ b) + 0x7f sets bit 7 of a byte exactly when it DIFFERS from b, with no carries; v_bfi keeps the complement of
+// that bit.  The factor -128 is part of gscale; |sum| <= 128 * 127 * K < 2^31 for K ranges below 132 000 sequences.
+__device__ __forceinline__ i32x4 onehot16(const i32x4 &x, u32 bb, u32 k7f) {
+    // hipcc rewrites the plain C of this as xor / sub / and (three operations); spelled out: v_xad_u32 = (x ^ b) + 0x7f..
+    // (bb in an SGPR, the constant in a VGPR: one constant-bus operand per instruction), v_bfi_b32 = ~y & 0x80..
+    i32x4 r;
+    const u32 k80 = 0x80808080u;
 #pragma unroll
-    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bh[me], acc[f][C], 0, 0, 0);
-    if constexpr (PLM_PIPE && C == MID) {   // see fwd_state
-        vm_wait<0>();
-        barrier_raw();
+    for (int j = 0; j < 4; j++) {
+        u32 y, v;
+        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(y) : "v"((u32)x[j]), "s"(bb), "v"(k7f));
+        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(v) : "v"(y), "s"(k80));
+        r[j] = (int)v;
     }
-    dma_at<FN, C, NP, PLM_DMA_STAGGER_BWD>(dma);
-#pragma unroll
-    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bl[me], acc[f][C], 0, 0, 0);
+    return r;
 }
-template <int FM, int FN, int PAR, int... C>
-__device__ __forceinline__ void bwd_kstep(f32x4 (&acc)[FM][FN], const half8 (&af)[FM], u32 lb, u32 lbn,
-                                          half8 (&bh)[2], half8 (&bl)[2], const DmaPlan &dma,
-                                          std::integer_sequence<int, C...>) {
-    if constexpr (!PLM_PIPE) {
-        bh[PAR] = lds_read_b128<0>(lb);
-        bl[PAR] = lds_read_b128<1024>(lb);
+// fragment T of a K step (T = half * FN + column): the fragment T + 1 is in flight while the FM MFMAs of T run.
+template <int FM, int FN, int T>
+__device__ __forceinline__ void bwd_frag(i32x4 (&acc)[FM][FN], const i32x4 (&af)[FM], u32 lb, i32x4 (&bf)[2],
+                                         const DmaPlan &dma) {
+    constexpr int C = T % FN, NP = (4 * FN + 7) / 8;
+    constexpr int me = T & 1, nx = (T + 1) & 1;
+    if constexpr (T + 1 < 2 * FN) {
+        constexpr int C1 = (T + 1) % FN, H1 = (T + 1) / FN;
+        bf[nx] = lds_read_b128_i<C1 * 2048 + H1 * 1024>(lb);
+        lds_wait_i<1>(bf[me]);
+    } else {
+        lds_wait_i<0>(bf[me]);
     }
-    (bwd_col<FM, FN, C, PAR>(acc, af, lb, lbn, bh, bl, dma), ...);
+#pragma unroll
+    for (int f = 0; f < FM; f++) acc[f][C] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[f], bf[me], acc[f][C], 0, 0, 0);
+    dma_at<2 * FN, T, NP, PLM_DMA_STAGGER_BWD>(dma);
+}
+template <int FM, int FN, int H, int... C>
+__device__ __forceinline__ void bwd_half(i32x4 (&acc)[FM][FN], const i32x4 (&af)[FM], u32 lb, i32x4 (&bf)[2],
+                                         const DmaPlan &dma, std::integer_sequence<int, C...>) {
+    (bwd_frag<FM, FN, H * FN + C>(acc, af, lb, bf, dma), ...);
 }
 
 template <int Q, int FM, int FN>
 __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict__ msa_cm,
-                                            const char *__restrict__ Rt, float *__restrict__ G,
+                                            const char *__restrict__ Rt, int *__restrict__ G,
                                             const int *__restrict__ run) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // variable-projection fit: the launch is enqueued behind the field solver's chain and only does its work when
     // that chain has converged (device flag); otherwise the host finishes the fields and launches it again
     if (run && !*run) return;
-    constexpr int TILE = 2 * FN * 2 * 1024;  // 2*FN col fragments x 2 planes
-    constexpr int NBUF = PLM_NBUF, NP = (4 * FN + 7) / 8;
+    constexpr int TILE = 2 * FN * 2 * 1024;  // 2*FN column fragments x 2 halves of the K step
+    constexpr int NP = (4 * FN + 7) / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to be wave-uniform
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ngroups = d.ncol_tiles * d.ksplit;
+    const int wm = wave_s >> 1, wn = wave_s & 1;               // wave-uniform: the states of the row fragments go to SGPRs
+    u32 k7f = 0x7f7f7f7fu;
+    asm volatile("" : "+v"(k7f));                              // a VGPR constant (see onehot16)
+    const int ngroups = d.ncol_tiles * d.nplanes * d.ksplit;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int grp = (slot / d.nrow_tiles) * 8 + xcd;
     if (grp >= ngroups) return;
     const int row_tile = slot % d.nrow_tiles;
-    const int col_tile = grp % d.ncol_tiles, ks = grp / d.ncol_tiles;
-    const int per = (d.nssteps + d.ksplit - 1) / d.ksplit;
-    const int k0 = ks * per, k1 = min(d.nssteps, k0 + per);
+    const int col_tile = grp % d.ncol_tiles, pk = grp / d.ncol_tiles;
+    const int plane = pk % d.nplanes, ks = pk / d.nplanes;
+    const int per = (d.nst128 + d.ksplit - 1) / d.ksplit;
+    const int k0 = ks * per, k1 = min(d.nst128, k0 + per);
 
     const int mf0 = (row_tile * 4 + wm) * FM;
     const bool row_ok = mf0 < d.nmf;
     const int j16 = row_ok ? mf0 / Q : 0, b0 = row_ok ? mf0 % Q : 0;
     const int nfl0 = col_tile * 2 * FN;
     const int r = lane & 15, g = lane >> 4;
-    // A operand: byte offset of this lane's site row in msa_cm (< 2^31: (nb16 + 1) * 16 * Np bytes)
-    const u32 acol = (u32)(j16 * 16 + r) * (u32)d.Np + 8 * g;
+    // A operand: byte offset of this lane's 16 sequences of its site row in msa_cm (< 2^31: (nb16 + 1) * 16 * Np bytes)
+    const u32 acol = (u32)(j16 * 16 + r) * (u32)d.Np + 16 * g;
 
-    f32x4 acc[FM][FN];
+    i32x4 acc[FM][FN];
 #pragma unroll
     for (int f = 0; f < FM; f++)
 #pragma unroll
-        for (int c = 0; c < FN; c++) acc[f][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < FN; c++) acc[f][c] = (i32x4){0, 0, 0, 0};
 
 #if PLM_PROBE
     unsigned long long pr_wait = 0;
     const unsigned long long pr_t0 = PROBE_NOW();
 #endif
-    // tile of step ss: 2*FN column fragments x 2 planes, contiguous in Rt; fragments past nnfl are not copied
+    // tile of step ss: 2*FN column fragments x 2 halves, contiguous in the plane; fragments past nnfl are not copied.
+    // Behind it in each LDS buffer: the alignment bytes of the 4 row groups, [row group][half] x 1 KB (lane (g, r) =
+    // 16 sequences of site row r): wave (wm, wn) brings in (wm, half wn) with one gathered piece, both waves of the row
+    // group read both halves -- no per-lane prefetch registers, and the two column waves share one fetch.
+    constexpr int ABYTES = 4 * 2 * 1024, BUF = TILE + ABYTES;
     const int np_valid = min(4 * FN, 2 * (d.nnfl - nfl0));
-    const char *rt0 = Rt + (size_t)nfl0 * 2048;
+    const char *rt0 = Rt + ((size_t)plane * d.nst128 * d.nnfl + nfl0) * 2048;
     const size_t rt_step = (size_t)d.nnfl * 2048;
-    for (int k = 0; k < NBUF - 1; k++)
-        if (k0 + k < k1) {
-            const DmaPlan first{rt0 + (size_t)(k0 + k) * rt_step, smem + k * TILE, wave_s, np_valid, (u32)lane * 16, false};
-            dma_issue_all<NP>(first);
-        }
-    u64 nx = (k0 < k1) ? *(const u64 *)(msa_cm + acol + (size_t)32 * k0) : 0ull;   // bytes of the next step (in place)
-    half8 bh[2], bl[2];
+    const char *a_src = row_ok ? (const char *)msa_cm : nullptr;
+    const u32 a_off0 = acol + 64 * (u32)wn;
+    const int a_slot = TILE + ((wave_s >> 1) * 2 + (wave_s & 1)) * 1024;   // wave-uniform (it ends up in M0)
+    if (k0 < k1) {
+        const DmaPlan first{rt0 + (size_t)k0 * rt_step, smem, wave_s, np_valid, (u32)lane * 16, false,
+                            a_src, a_off0 + PLM_BWD_KSTEP * (u32)k0, smem + a_slot};
+        dma_issue_all<NP>(first);
+    }
+    i32x4 bf[2];
     const u32 lw = lds_addr(smem + (wn * FN) * 2048 + lane * 16);   // this wave's columns in buffer 0
+    const u32 la = lds_addr(smem + TILE + (wm * 2) * 1024 + lane * 16);   // this row group's alignment bytes, half 0
     // the same register serves as the per-lane part of the LDS-DMA source address: lw = lane * 16 + lw_base
     const u32 lw_base = __builtin_amdgcn_readfirstlane(lw - (u32)lane * 16);
-    if constexpr (PLM_PIPE) {
-        vm_wait<0>();
-        __syncthreads();
-        if (row_ok) {
-            bh[0] = lds_read_b128<0>(lw);
-            bl[0] = lds_read_b128<1024>(lw);
-        }
-    }
-    int cur = 0, ss = k0;
-    // one K step; PAR = slot that holds column 0 of this step
-    auto step = [&](auto par_tag) {
-        constexpr int PAR = decltype(par_tag)::value;
-        if constexpr (!PLM_PIPE) {
+    int cur = 0;
+    for (int ss = k0; ss < k1; ++ss) {
 #if PLM_PROBE
-            const unsigned long long pa = PROBE_NOW();
+        const unsigned long long pa = PROBE_NOW();
 #endif
-            if constexpr ((PLM_ABLATE & 1) == 0) {
-                vm_wait<0>();
-                __syncthreads();
-            }
-#if PLM_PROBE
-            pr_wait += PROBE_NOW() - pa;
-#endif
+        if constexpr ((PLM_ABLATE & 1) == 0) {
+            vm_wait<0>();
+            __syncthreads();
         }
-        const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
-        const int tgt = PLM_PIPE ? ((nxt + 1 == NBUF) ? 0 : nxt + 1) : nxt;   // buffer of step ss + NBUF - 1
-        const DmaPlan dma{rt0 + (size_t)(ss + NBUF - 1) * rt_step - lw_base, smem + tgt * TILE, wave_s,
-                          (ss + NBUF - 1 < k1) ? np_valid : 0, lw, wave_s >= 4};
+#if PLM_PROBE
+        pr_wait += PROBE_NOW() - pa;
+#endif
+        const int nxt = cur ^ 1;
+        const bool more = ss + 1 < k1;
+        const DmaPlan dma{rt0 + (size_t)(ss + 1) * rt_step - lw_base, smem + nxt * BUF, wave_s, more ? np_valid : 0, lw,
+                          wave_s >= 4, more ? a_src : nullptr, a_off0 + PLM_BWD_KSTEP * (u32)(ss + 1),
+                          smem + nxt * BUF + a_slot};
         if (row_ok) {
-            vm_landed(nx);
-            const u64 xa = nx;
-            if (ss + 1 < k1) load_b64_inplace(nx, msa_cm, acol + 32 * (u32)(ss + 1));
-            half8 af[FM];
+            const u32 lb = lw + cur * BUF, lab = la + cur * BUF;
+            i32x4 af[FM];
+            i32x4 xa = lds_read_b128_i<0>(lab);
+            bf[0] = lds_read_b128_i<0>(lb);
+            lds_wait_i<1>(xa);
 #pragma unroll
-            for (int f = 0; f < FM; f++) {
-#if !(PLM_ABLATE & 8)
-                af[f] = onehot8((u32)xa, (u32)(xa >> 32), (u32)(b0 + f) * 0x01010101u);
-#else
-                ((u32 *)&af[f])[0] = (u32)xa; ((u32 *)&af[f])[1] = (u32)(xa >> 32); ((u32 *)&af[f])[2] = b0 + f; ((u32 *)&af[f])[3] = (u32)xa;
-#endif
-            }
-            bwd_kstep<FM, FN, PAR>(acc, af, lw + cur * TILE, lw + nxt * TILE, bh, bl, dma,
-                                   std::make_integer_sequence<int, FN>{});
+            for (int f = 0; f < FM; f++) af[f] = onehot16(xa, (u32)(b0 + f) * 0x01010101u, k7f);
+            bwd_half<FM, FN, 0>(acc, af, lb, bf, dma, std::make_integer_sequence<int, FN>{});
+            __builtin_amdgcn_sched_barrier(0);   // the second half's fragments take over the registers of the first's
+            xa = lds_read_b128_i<1024>(lab);
+            lds_wait_i<0>(xa);
+#pragma unroll
+            for (int f = 0; f < FM; f++) af[f] = onehot16(xa, (u32)(b0 + f) * 0x01010101u, k7f);
+            bwd_half<FM, FN, 1>(acc, af, lb, bf, dma, std::make_integer_sequence<int, FN>{});
         } else {            // idle row waves still take part in the barrier and copy their share
-            if constexpr (PLM_PIPE) {
-                vm_wait<0>();
-                barrier_raw();
-            }
             dma_issue_all<NP>(dma);
         }
         cur = nxt;
-        ++ss;
-    };
-    while (ss < k1) {
-        step(std::integral_constant<int, 0>{});
-        if constexpr (PLM_PIPE && (FN & 1)) {
-            if (ss < k1) step(std::integral_constant<int, 1>{});
-        }
-    }
-    if constexpr (PLM_PIPE) {   // a fragment read past the last step may still be in flight
-        if (row_ok) {
-            lds_wait<0>(bh[0], bl[0]);
-            lds_wait<0>(bh[1], bl[1]);
-        }
     }
 #if PLM_PROBE
     const unsigned long long pr_t1 = PROBE_NOW();
 #endif
     if (!row_ok) return;
+    int *Gp = G + (size_t)(plane * d.ksplit + ks) * d.nmf * d.nnfl * 256;
 #pragma unroll
     for (int f = 0; f < FM; f++)
 #pragma unroll
         for (int c = 0; c < FN; c++) {
             const int nfl = nfl0 + wn * FN + c;
-            if (nfl < d.nnfl)
-                *(f32x4 *)(G + ((((size_t)ks * d.nmf + mf0 + f) * d.nnfl + nfl) * 64 + lane) * 4) = acc[f][c];
+            if (nfl < d.nnfl) *(i32x4 *)(Gp + (((size_t)(mf0 + f) * d.nnfl + nfl) * 64 + lane) * 4) = acc[f][c];
         }
 #if PLM_PROBE
     if (lane == 0) {
@@ -1632,13 +1747,13 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
 #endif
 }
 
-hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, float *G, const int *run,
+hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, int32_t *G, const int *run,
                                hipStream_t st) {
-    const int ngroups = d.ncol_tiles * d.ksplit;
+    const int ngroups = d.ncol_tiles * d.nplanes * d.ksplit;
     const dim3 grid(8 * ((ngroups + 7) / 8) * d.nrow_tiles), block(512);
 #define BWD_CASE(QQ, M, N)                                                                             \
     case QQ: {                                                                                         \
-        const size_t lds = (size_t)PLM_NBUF * (2 * N * 2 * 1024);                                      \
+        const size_t lds = (size_t)2 * (2 * N * 2 * 1024 + 4 * 2 * 1024);   /* two buffers: digit tile + alignment bytes */ \
         static bool attr_done_dev[PLM_MAX_DEVICES] = {false};   /* the attribute is per device */     \
         bool &attr_done = attr_done_dev[plm_current_device()];                                         \
         if (!attr_done) {                                                                              \
@@ -1647,7 +1762,7 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
             if (e != hipSuccess) return e;                                                             \
             attr_done = true;                                                                          \
         }                                                                                              \
-        hipLaunchKernelGGL((k_bwd<QQ, M, N>), grid, block, lds, st, d, msa_cm, (const char *)Rt, G, run);   \
+        hipLaunchKernelGGL((k_bwd<QQ, M, N>), grid, block, lds, st, d, msa_cm, (const char *)Rt, (int *)G, run);   \
     } break;
     switch (d.Q) {
         BWD_CASE(21, 7, 7)
@@ -1661,22 +1776,36 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
     return hipGetLastError();
 }
 
-// sum the split-K partials into this shard's slab of the exchange buffer
-__global__ __launch_bounds__(256) void k_slab_reduce(const float4 *__restrict__ G, float4 *__restrict__ slab,
-                                                    int64_t n4, int ksplit) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 s = G[i];
-        for (int k = 1; k < ksplit; k++) {
-            const float4 t = G[i + (int64_t)k * n4];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-        slab[i] = s;
+// exact value of one slab element from k_bwd's int32 partials: K ranges summed per digit plane in 64 bits, planes
+// combined in f64 (< 2^53: exact), rounded ONCE to f32.  off = element offset inside one partial slab.
+__device__ __forceinline__ float g_combine(const int *__restrict__ G, size_t off, int ks_count, size_t kstride,
+                                           int nplanes) {
+    const size_t pstride = (size_t)ks_count * kstride;
+    double v = 0.0, wgt = 1.0;
+    for (int p = 0; p < nplanes; p++) {
+        long long sp = 0;     // a single K range stays below 2^31, their sum need not
+        for (int k = 0; k < ks_count; k++) sp += G[off + p * pstride + k * kstride];
+        v += wgt * (double)sp;
+        wgt *= 256.0;
     }
+    return (float)v;
 }
-hipError_t plm_launch_slab_reduce(const PlmDims &d, const float *G, float *slab, hipStream_t st) {
-    const int64_t n4 = (int64_t)d.nmf * d.nnfl * 64;
-    hipLaunchKernelGGL(k_slab_reduce, dim3(2048), dim3(256), 0, st, (const float4 *)G, (float4 *)slab, n4,
-                       d.ksplit);
+// slab element either way: int32 partials (ks_count >= 1) or an already combined float slab (ks_count = 0: the gathered
+// slabs of the replicated multi-shard mode)
+__device__ __forceinline__ float g_value(const void *__restrict__ G, size_t off, int ks_count, size_t kstride,
+                                         int nplanes) {
+    return ks_count > 0 ? g_combine((const int *)G, off, ks_count, kstride, nplanes) : ((const float *)G)[off];
+}
+
+// combine the digit planes and K ranges into this shard's float slab of the exchange buffer
+__global__ __launch_bounds__(256) void k_slab_reduce(const int *__restrict__ G, float *__restrict__ slab, int64_t n,
+                                                    int ksplit, int nplanes) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        slab[i] = g_combine(G, (size_t)i, ksplit, (size_t)n, nplanes);
+}
+hipError_t plm_launch_slab_reduce(const PlmDims &d, const int32_t *G, float *slab, hipStream_t st) {
+    const int64_t n = (int64_t)d.nmf * d.nnfl * 256;
+    hipLaunchKernelGGL(k_slab_reduce, dim3(2048), dim3(256), 0, st, (const int *)G, slab, n, d.ksplit, d.nplanes);
     return hipGetLastError();
 }
 
@@ -1694,7 +1823,7 @@ __device__ __forceinline__ size_t g_frag(const PlmDims &d, int ks_count, size_t 
     const int nfl = (block16 - plm_shard_lo(d, sh)) * d.Q + state;
     return (size_t)sh * slab_stride + ((size_t)mf * d.nnfl + nfl) * 256;
 }
-__global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__restrict__ G, int ks_count,
+__global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restrict__ G, int ks_count,
                                                  size_t slab_stride, const float *__restrict__ ghalo,
                                                  const float *__restrict__ x,
                                                  float *__restrict__ gout, float lambda_j,
@@ -1720,8 +1849,7 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__rest
     double reg = 0;
     for (int b = 0; b < d.Q; b++) {
         const size_t o1 = g_frag(d, ks_count, slab_stride, I, a, J * d.Q + b) + t1;
-        float v = 0.f;
-        for (int k = 0; k < ks_count; k++) v += G[o1 + k * kstride];
+        const float v = g_value(G, o1, ks_count, kstride, d.nplanes);
         float out;
         if (mode == 0) {
             float v2 = 0.f;
@@ -1729,7 +1857,7 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__rest
                 v2 = ghalo[hoff + (size_t)b * 256];
             } else {
                 const size_t o2 = g_frag(d, ks_count, slab_stride, J, b, I * d.Q + a) + t2;
-                for (int k = 0; k < ks_count; k++) v2 += G[o2 + k * kstride];
+                v2 = g_value(G, o2, ks_count, kstride, d.nplanes);
             }
             const float xv = x[xoff + (size_t)b * 256];
             const bool live = valid && !(d.gap_mode && (a == 0 || b == 0)) && a < d.Qc && b < d.Qc;
@@ -1746,7 +1874,7 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const float *__rest
     }
 }
 // field part: column sums of the residuals arrive through the "ones" row fragment
-__global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__restrict__ G, int ks_count,
+__global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const void *__restrict__ G, int ks_count,
                                                    size_t slab_stride, const float *__restrict__ x,
                                                    float *__restrict__ gout, float lambda_h,
                                                    double *__restrict__ reg_part, int mode, float scale) {
@@ -1760,8 +1888,7 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
         if (idx < (int64_t)(site_end - d.h_site0) * d.Q) {
             const int i = d.h_site0 + (int)(idx / d.Q), a = (int)(idx % d.Q);
             const size_t o = g_frag(d, ks_count, slab_stride, i >> 4, a, d.nb16 * d.Q) + (size_t)(i & 15) * 4;
-            float v = 0.f;
-            for (int k = 0; k < ks_count; k++) v += G[o + k * kstride];
+            const float v = g_value(G, o, ks_count, kstride, d.nplanes);
             if (mode != 1) {
                 const float xv = x[idx];
                 if (!(d.gap_mode && a == 0) && a < d.Qc) {
@@ -1781,12 +1908,13 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const float *__re
         if (threadIdx.x == 0) reg_part[d.np_own * d.Q + blockIdx.x] = (double)lambda_h * t;
     }
 }
-hipError_t plm_launch_assemble(const PlmDims &d, const float *G, int ks_count, const float *ghalo, const float *x,
+hipError_t plm_launch_assemble(const PlmDims &d, const void *G, int ks_count, const float *ghalo, const float *x,
                                float *g, float lambda_h, float lambda_j, double *reg_part, int mode, float inv_neff,
                                hipStream_t st) {
-    // replicated multi-shard mode reads the gathered slabs (one per shard); otherwise G is this shard's own
-    const size_t slab_stride = d.sharded ? 0 : plm_slab_bytes(d) / 4;
-    const float scale = ldexpf(1.f, -PLM_R_EXP) * (mode == 1 ? inv_neff : 1.f);
+    // replicated multi-shard mode reads the gathered float slabs (one per shard, ks_count = 0); otherwise G holds this
+    // shard's own int32 plane / K-range partials
+    const size_t slab_stride = (d.sharded || ks_count > 0) ? 0 : plm_slab_bytes(d) / 4;
+    const float scale = d.gscale * (mode == 1 ? inv_neff : 1.f);
     if (d.np_own > 0)
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride,
                            ghalo, x, g, lambda_j, reg_part, mode == 2 ? 0 : mode, scale);
@@ -2156,7 +2284,7 @@ hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, h
                        (float4 *)sendbuf);
     return hipGetLastError();
 }
-__global__ __launch_bounds__(256) void k_pack_g(PlmDims d, const float *__restrict__ G, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_pack_g(PlmDims d, const int *__restrict__ G, float *__restrict__ out) {
     // one block per (own column block J, lower block I, state a); thread t = fragment element
     const int a = blockIdx.y;
     const int jl = blockIdx.x / d.own_lo, I = blockIdx.x % d.own_lo;            // J = own_lo + jl
@@ -2168,14 +2296,12 @@ __global__ __launch_bounds__(256) void k_pack_g(PlmDims d, const float *__restri
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
     for (int b = 0; b < d.Q; b++) {
         const size_t o = ((size_t)(I * d.Q + a) * d.nnfl + (size_t)jl * d.Q + b) * 256 + threadIdx.x;
-        float v = 0.f;
-        for (int k = 0; k < d.ksplit; k++) v += G[o + k * kstride];
-        out[dst + (size_t)b * 256] = v;
+        out[dst + (size_t)b * 256] = g_combine(G, o, d.ksplit, kstride, d.nplanes);
     }
 }
-hipError_t plm_launch_pack_g(const PlmDims &d, const float *G, float *sendbuf, hipStream_t st) {
+hipError_t plm_launch_pack_g(const PlmDims &d, const int32_t *G, float *sendbuf, hipStream_t st) {
     if (d.nblk_own <= 0 || d.own_lo <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_g, dim3(d.nblk_own * d.own_lo, d.Q), dim3(256), 0, st, d, G, sendbuf);
+    hipLaunchKernelGGL(k_pack_g, dim3(d.nblk_own * d.own_lo, d.Q), dim3(256), 0, st, d, (const int *)G, sendbuf);
     return hipGetLastError();
 }
 

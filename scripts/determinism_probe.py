@@ -9,7 +9,7 @@ from evcouplings_amd.synthetic import synthetic_msa
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 for (N, L) in ((50000, 300), (20000, 200)):
     msa, _ = synthetic_msa(N, L, seed=7)
-    ctx = plm.PlmContext(msa, q=21, max_iter=15, epsilon=1e-12)
+    ctx = plm.PlmContext(msa, q=21, max_iter=15, epsilon=1e-3)
     ctx.reweight(); ctx.marginals(pairs=False); ctx.set_x(None)
     ctx.optimize()
     x = ctx.get_x()

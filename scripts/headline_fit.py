@@ -8,7 +8,7 @@ from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED
 N = int(os.environ.get("PLM_N", 50000)); L = int(os.environ.get("PLM_L", 300)); m = int(os.environ.get("PLM_M", 6))
 msa, _ = synthetic_msa(N, L, seed=BASE_SEED + 1)
 t = time.time()
-res = plm.fit(msa, 21, max_iter=int(os.environ.get("PLM_MAXIT", 6000)), epsilon=float(os.environ.get("PLM_EPS", 1e-3)), lbfgs_m=m, want_fij=False)
+res = plm.fit(msa, 21, max_iter=int(os.environ.get("PLM_MAXIT", 1500)), epsilon=float(os.environ.get("PLM_EPS", 1e-3)), lbfgs_m=m, want_fij=False)
 print("m=%d: iters=%d evals=%d status=%d (%s) %.2fs" % (m, res["iters"], res["n_evals"], res["status"], res["status_msg"], time.time() - t))
 tab = res["table"]
 cn_prev = None

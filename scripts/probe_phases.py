@@ -8,7 +8,7 @@ from evcouplings_amd import plm, _lib
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED
 N = int(os.environ.get("PLM_N", 50000)); L = int(os.environ.get("PLM_L", 300))
 msa, _ = synthetic_msa(N, L, seed=BASE_SEED + 1)
-ctx = plm.PlmContext(msa, q=21, max_iter=2, epsilon=1e-12)
+ctx = plm.PlmContext(msa, q=21, max_iter=2, epsilon=1e-3)
 ctx.set_weights(np.full(N, 0.9, np.float32)); ctx.marginals(pairs=False); ctx.set_x(None)
 ctx.optimize()
 lib = _lib.load()
