@@ -10,7 +10,15 @@ in the build container (tests/refstubs.py makes the package importable without n
   * the two coverage filters of modify_alignment       :900-914, 935-943
 
 on tests/golden/hip_fit_L24.a2m with a few sequences turned into fragments and two columns made gappy, so that both
-filters bite.  Output: tests/golden/align_stats.npz.  Usage: python tests/golden/make_golden_align.py
+filters bite.  Output: tests/golden/align_stats.npz.
+
+Real data: the one alignment the reference ships, notebooks/example/example_aln.a2m (53 cadherin
+sequences x 423 columns, 3 insert columns in lowercase / '.', real gap runs), is copied to tests/golden/example_aln.a2m
+(a test fixture) and run through the reference's own Alignment class the way the couplings stage sees it: match columns
+of the first sequence (couplings/mean_field.py:103-109), sequence weights at 80 % identity, single-site and pair
+frequencies, the describe_frequencies table.  Output: tests/golden/example_aln.npz.
+
+Usage: python tests/golden/make_golden_align.py
 """
 import os
 import sys
@@ -75,5 +83,37 @@ def main():
     print("wrote align_stats.npz:", {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def real_data():
+    import shutil
+    import evcouplings.align.alignment as ra
+    import evcouplings.align.protocol as rp
+    from oracle.oracle import Oracle
+    src = os.path.join(refstubs.REFERENCE, "notebooks", "example", "example_aln.a2m")
+    dst = os.path.join(HERE, "example_aln.a2m")
+    shutil.copyfile(src, dst)
+    with open(dst) as f:
+        ali = ra.Alignment.from_file(f, "fasta")
+    focus = ali.matrix[0]
+    keep_cols = np.array([c.isupper() for c in focus])             # uppercase = match state, not a gap, not an insert
+    sel = ali.select(columns=keep_cols)
+    mapped = ra.map_matrix(sel.matrix, sel.alphabet_map)
+    counts = Oracle("f64").reweight(mapped.astype(np.int8), 0.8)    # stand-in for num_cluster_members (App. D-9)
+    ra.num_cluster_members = lambda matrix, thr: Oracle("f64").reweight(np.asarray(matrix).astype(np.int8), thr).astype(float)
+    sel.set_weights(0.8)
+    fi = sel.frequencies
+    fij = sel.pair_frequencies                                      # dense L x L x q x q
+    L = sel.L
+    iu, ju = np.triu_indices(L, 1)
+    freq = rp.describe_frequencies(sel, 1, target_seq_index=0)
+    out = dict(ids=np.array(list(ali.ids)), keep_cols=keep_cols, mapped=mapped.astype(np.int8), counts=counts.astype(np.int32),
+               weights=sel.weights, fi=fi, fij_pairs=fij[iu, ju].astype(np.float32), n_eff=float(sel.weights.sum()),
+               freq_columns=np.array(list(freq.columns)), freq_values=freq.drop(columns=["A_i"]).to_numpy(dtype=float),
+               freq_target=np.array(list(freq["A_i"])), seq_gap_frac=sel.count("-", axis="seq"),
+               col_gap_frac=sel.count("-", axis="pos"), ident_to_target=sel.identities_to(sel[0]))
+    np.savez_compressed(os.path.join(HERE, "example_aln.npz"), **out)
+    print("wrote example_aln.npz: N=%d L=%d (of %d columns), N_eff %.2f" % (sel.N, L, ali.L, out["n_eff"]))
+
+
 if __name__ == "__main__":
     main()
+    real_data()

@@ -837,6 +837,72 @@ def test_solver_selection_reaches_the_joint_path_through_the_boundary(plm, tmp_p
         tools.run_plmc_hip(ali, str(tmp_path / "x.txt"), solver="newton", **kw)
 
 
+def test_real_alignment_end_to_end(plm, oracle64, golden_dir, tmp_path):
+    """Real data: the reference's example alignment (53 x 423 with insert columns and gap runs)
+    through encoder -> reweighting -> marginals -> frequency table on the GPU against what the reference's Alignment
+    class computed (tests/golden/example_aln.npz), an evaluation against the oracle, and the whole run_plmc drop-in."""
+    from evcouplings_amd import alignment_accel, alignment_io, model_io, tools
+    z = np.load(os.path.join(golden_dir, "example_aln.npz"))
+    a2m = os.path.join(golden_dir, "example_aln.a2m")
+    enc = alignment_io.encode_alignment(a2m, focus_seq="Q641K6_MOUSE")
+    np.testing.assert_array_equal(enc.msa, z["mapped"])
+    counts = plm.reweight(enc.msa, 0.8)
+    np.testing.assert_array_equal(counts, z["counts"])                                  # bit-exact
+    np.testing.assert_array_equal(alignment_accel.num_cluster_members(enc.msa, 0.8), z["counts"].astype(float))
+    fi, fij = plm.marginals(enc.msa, z["weights"].astype(np.float32), Q)
+    np.testing.assert_allclose(fi, z["fi"], atol=2e-6)
+    np.testing.assert_allclose(fij, z["fij_pairs"], atol=2e-6)
+    # the describe_frequencies table of the reference: conservation aside, its symbol columns are f_i
+    cols = list(z["freq_columns"])
+    np.testing.assert_allclose(alignment_accel.frequencies(enc.msa, z["weights"], Q), z["freq_values"][:, cols.index("-") - 1:],
+                               atol=2e-6)
+    seq_gaps, col_gaps, ident = plm.alignment_stats(enc.msa, 0, query=enc.msa[0])
+    np.testing.assert_array_equal(seq_gaps / 420, z["seq_gap_frac"])
+    np.testing.assert_array_equal(col_gaps / 53, z["col_gap_frac"])
+    np.testing.assert_array_equal(ident / 420, z["ident_to_target"])
+    # objective and gradient at a random point: L = 420 sites, 38.8 M parameters, 53 sequences
+    L = 420
+    lj = plm.default_lambda_j(L, Q)
+    x = (0.03 * np.random.default_rng(2).normal(size=plm.n_params(L, Q))).astype(np.float32)
+    w = z["weights"].astype(np.float32)
+    fx, nll, g = plm.evaluate(enc.msa, w, Q, 0.01, lj, x)
+    fxo, nllo, go = oracle64.eval(enc.msa, w.astype(np.float64), Q, 0.01, lj, x.astype(np.float64))
+    assert abs(fx - fxo) <= 2e-6 * abs(fxo) and np.abs(g - go).max() <= 3e-5 * np.abs(go).max()
+    # the drop-in on the file as the pipeline would hand it over (focus id without its range, tools.py:219)
+    r = tools.run_plmc_hip(a2m, str(tmp_path / "cad_ECs.txt"), str(tmp_path / "cad.model"), focus_seq="Q641K6_MOUSE/1-423",
+                           theta=0.8, iterations=40, lambda_h=0.01, lambda_J=lj)
+    assert (r.num_valid_seqs, r.num_total_seqs, r.num_valid_sites, r.num_total_sites) == (53, 53, 420, 423)
+    assert r.focus_seq_index == 1 and r.region_start == 1 and r.effective_samples == float("%.1f" % z["n_eff"])
+    m = model_io.read_model_file(str(tmp_path / "cad.model"))
+    np.testing.assert_array_equal(m["index_list"], 1 + np.flatnonzero(z["keep_cols"]))
+    np.testing.assert_allclose(m["fi"], z["fi"], atol=2e-6)
+    ecs = np.loadtxt(str(tmp_path / "cad_ECs.txt"), usecols=(0, 2))
+    assert set(np.unique(ecs).astype(int)) == set((1 + np.flatnonzero(z["keep_cols"])).tolist())
+
+
+def test_pin_kit_sweeps_the_conventions_against_a_plmc_like_binary(plm, tmp_path):
+    """scripts/pin_against_plmc.py end to end with bin/plmc_hip standing in for plmc (same command line, same files): the
+    sweep must single out the conventions the 'binary' ran with (the defaults) and report agreement inside 1e-4 for
+    the converged solver; the golden files it leaves behind are what tests/ would pin against on a host with plmc."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pin_against_plmc", os.path.join(root, "scripts", "pin_against_plmc.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    rep = pin.main(["--plmc", os.path.join(root, "bin", "plmc_hip"), "--small", "--iterations", "max", "--modes", "plain",
+                    "--out", str(tmp_path / "g"), "--work", str(tmp_path / "w")])
+    (r,) = rep
+    assert os.path.getsize(str(tmp_path / "g" / r["golden"])) > 0
+    best = r["best"]
+    assert best["max_abs_dCN"] < 1e-4 and best["conventions"] in (0, 32), best      # 32 = f32 threshold: same counts at 0.8
+    by = {(row["solver"], row["conventions"]): row["max_abs_dCN"] for row in r["table"]}
+    assert by[("vp", 0)] < 2e-5                       # the same solver on both sides
+    assert by[("joint", 0)] < 1e-4                    # plmc's algorithm, run to the same stop rule: the same optimum
+    assert by[("vp", 512)] > 1e-3                     # a convention that changes the scores is told apart
+    assert json.load(open(str(tmp_path / "g" / "plmc_small.json")))["best"]["solver"] in ("vp", "joint")
+
+
 def test_replicated_multi_shard_evaluation_at_config_scale_sites(plm, oracle64):
     """Replicated multi-shard mode (exchange callback / LoopbackShards) with L = 300 on 8 shards: the per-site buffers
     of the field pass cover all L sites there (the local field part), not only the shard's own 2-3 column blocks --

@@ -156,3 +156,117 @@ def test_run_plmc_hip_error_conventions(tmp_path):
         # no GPU here: the solver must fail loudly (as ExternalToolError), never fall back to a CPU path
         with pytest.raises(tools.ExternalToolError):
             tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), str(tmp_path / "m.model"), focus_seq="SYN/1-12")
+
+
+def test_cli_extensions_and_solver_selection(monkeypatch):
+    """Options plmc does not have: --solver / --gpus / --epsilon / --conventions on the shim, PLM_HIP_SOLVER for an
+    unmodified pipeline (same pattern as PLM_HIP_CONVENTIONS)."""
+    o = cli.parse_argv(["-c", "e", "--solver", "joint", "--gpus", "2", "--epsilon", "1e-4", "--conventions", "0x140", "a"])
+    assert o["solver"] == "joint" and o["gpus"] == "2" and o["epsilon"] == 1e-4 and o["conventions"] == 320
+    monkeypatch.delenv("PLM_HIP_SOLVER", raising=False)
+    assert tools.solver_from_env() == "vp" and tools.solver_from_env("JOINT") == "joint"
+    monkeypatch.setenv("PLM_HIP_SOLVER", "joint")
+    assert tools.solver_from_env() == "joint" and tools.solver_from_env("vp") == "vp"
+    with pytest.raises(ValueError):
+        tools.solver_from_env("newton")
+
+
+def test_gpu_count_is_opt_in(monkeypatch):
+    """run_plmc's `cpu` is plmc's thread count: it never starts GPU ranks by itself.  `gpus=` or
+    PLM_HIP_GPUS do; "cpu" as the variable's value reads the cpu option."""
+    from evcouplings_amd import dist, plm
+    monkeypatch.setattr(plm, "device_count", lambda: 8)
+    monkeypatch.delenv("PLM_HIP_GPUS", raising=False)
+    monkeypatch.delenv("PLM_DIST_BACKEND", raising=False)
+    assert dist.resolve_gpu_count(16) == 1 and dist.resolve_gpu_count("max") == 1 and dist.resolve_gpu_count(None) == 1
+    assert dist.resolve_gpu_count(16, gpus=4) == 4 and dist.resolve_gpu_count(None, gpus="max") == 8
+    assert dist.resolve_gpu_count(None, gpus=64) == 8                      # capped by the visible devices
+    monkeypatch.setenv("PLM_HIP_GPUS", "2")
+    assert dist.resolve_gpu_count(16) == 2 and dist.resolve_gpu_count(16, gpus=1) == 1
+    monkeypatch.setenv("PLM_HIP_GPUS", "cpu")
+    assert dist.resolve_gpu_count(4) == 4 and dist.resolve_gpu_count(None) == 1 and dist.resolve_gpu_count("max") == 8
+    monkeypatch.setenv("PLM_HIP_GPUS", "many")
+    with pytest.raises(ValueError):
+        dist.resolve_gpu_count(1)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run.
+    PLM_BENCH_LAUNCH_ONLY makes every rank join a gloo group and rank 0 report: no GPU needed."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PLM_BENCH_LAUNCH_ONLY="1")
+    env.pop("WORLD_SIZE", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = [ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"launch_only": True, "n_gpus": 2, "steps": 3, "warmup": 1}
+
+
+def test_pin_kit_against_a_stand_in_plmc(tmp_path):
+    """scripts/pin_against_plmc.py with tests/fake_plmc.py (the CPU oracle behind plmc's command line) as the binary:
+    the A2M export, the argv in run_plmc's order, the golden files and their record.  The HIP side of the script (the
+    sweep over the convention switches) runs in the GPU suite."""
+    import importlib.util
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pin_against_plmc", os.path.join(root, "scripts", "pin_against_plmc.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    fake = os.path.join(root, "tests", "fake_plmc.py")
+    rep = pin.main(["--plmc", fake, "--small", "--no-hip", "--iterations", "60", "--out", str(tmp_path / "g"),
+                    "--work", str(tmp_path / "w"), "--cpu", "2"])
+    assert [r["golden"] for r in rep] == ["plmc_small_ECs.txt", "plmc_small_g_ECs.txt"]
+    for r in rep:
+        ecs = pin.read_cn(str(tmp_path / "g" / r["golden"]))
+        L = r["L"]
+        assert len(ecs) == L * (L - 1) // 2 and all(np.isfinite(v) for v in ecs.values())
+        rec = json.load(open(str(tmp_path / "g" / ("plmc_small%s.json" % ("_g" if r["ignore_gaps"] else "")))))
+        argv = rec["argv"]
+        # the order run_plmc assembles (evcouplings/couplings/tools.py:202-262)
+        keys = [a for a in argv if a.startswith("-") and not a[1:2].isdigit()]
+        want = ["-c", "-o", "-f"] + (["-g"] if r["ignore_gaps"] else []) + ["-m", "-t", "-s", "-lh", "-le", "-lg", "-n"]
+        assert keys == want, keys
+        assert argv[argv.index("-f") + 1] == "SYN" and argv[-1].endswith("small.a2m")
+        assert argv[argv.index("-t") + 1] == str(1.0 - 0.8)                       # the 1 - theta round trip, as upstream
+        assert "valid sequences out of" in rec["plmc_stderr_tail"]
+    # with and without -g the stand-in solved different models
+    a, b = pin.read_cn(str(tmp_path / "g" / "plmc_small_ECs.txt")), pin.read_cn(str(tmp_path / "g" / "plmc_small_g_ECs.txt"))
+    assert max(abs(a[k] - b[k]) for k in a) > 1e-3
+
+
+def test_map_matrix_drop_in_handles_empty_cells():
+    """np.vectorize hands the alphabet map '' for an empty cell of a U1 / S1 matrix; the lookup-table drop-in does too."""
+    from collections import defaultdict
+    from evcouplings_amd import alignment_accel
+    amap = defaultdict(lambda: 0, {c: k for k, c in enumerate("-ACDE")})
+    amap[""] = 7
+    m = np.array([["A", "", "C"], ["-", "E", ""]], dtype="U1")
+    np.testing.assert_array_equal(alignment_accel.map_matrix(m, amap), np.vectorize(amap.__getitem__)(m))
+    with pytest.raises(ValueError):
+        alignment_accel._int8_states(np.array([[0, 200]]), "matrix")
+
+
+def test_real_alignment_through_the_host_layer_matches_the_reference(golden_dir, oracle64):
+    """The one alignment the reference ships (notebooks/example/example_aln.a2m: 53 cadherin sequences, 423 columns, three
+    of them inserts -- lowercase in the first sequence, '.' elsewhere --, real gap runs) through the A2M reader and
+    the oracle, against what the reference's own Alignment class made of it (tests/golden/make_golden_align.py)."""
+    z = np.load(os.path.join(golden_dir, "example_aln.npz"))
+    enc = alignment_io.encode_alignment(os.path.join(golden_dir, "example_aln.a2m"), focus_seq="Q641K6_MOUSE")
+    assert enc.msa.shape == (53, 420) and enc.n_total_sites == 423 and enc.n_valid_seqs == enc.n_total_seqs == 53
+    np.testing.assert_array_equal(enc.msa, z["mapped"])                       # same columns kept, same encoding
+    # index_list numbers the focus residues: the three insert positions leave gaps in the numbering
+    kept_positions = 1 + np.flatnonzero(z["keep_cols"])
+    np.testing.assert_array_equal(enc.index_list, kept_positions)
+    assert enc.target_seq == "".join(z["freq_target"].tolist())
+    counts = oracle64.reweight(enc.msa, 0.8)
+    np.testing.assert_array_equal(counts, z["counts"])
+    w = 1.0 / counts
+    np.testing.assert_allclose(w, z["weights"], rtol=1e-14)
+    fi, fij = oracle64.marginals(enc.msa, w, 21)
+    np.testing.assert_allclose(fi, z["fi"], atol=1e-13)
+    np.testing.assert_allclose(fij, z["fij_pairs"], atol=2e-7)                # stored as float32
