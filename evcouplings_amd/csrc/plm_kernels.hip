@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
                                                const int32_t *__restrict__ jexp, _Float16 *__restrict__ Bt) {
     const int NG = PLM_FWD_NG(d.Q), SPU = 4 * NG;
     const int u = blockIdx.x / (2 * NG), ci = blockIdx.x % (2 * NG), b16l = blockIdx.y, b16 = d.b16_lo + b16l;
-    const double sc = ldexp(1.0, *jexp);
+    const float sc = ldexpf(1.f, *jexp);
     const float *__restrict__ xj = x + d.nh_pad_l;
     _Float16 *tile_hi = Bt + ((size_t)b16l * d.nksteps + (size_t)u * SPU + 2 * ci) * (size_t)(2 * d.Q * 512);
     _Float16 *tile_lo = tile_hi + (size_t)(2 * d.Q * 512);
@@ -622,17 +622,18 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
                 const int ga = 2 * half + (gb >> 1), pp = 2 * (gb & 1) + (e8 >> 2), e = e8 & 3;
                 const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl % NG;
                 const int b = 4 * sg + e + 1, j = 32 * u + 8 * ga + s8;     // state 0 has no slot (reference state)
-                // the difference to the reference state, exact in f64 (two f32 values), scaled by a power of two and split
-                // hi = f16(v), lo = f16(v - hi): 23 significant bits of the DIFFERENCE (an f32 subtraction would round first)
-                double v = 0.0;
+                // the difference to the reference state, scaled by a power of two and split hi = f16(v), lo = f16(v - hi):
+                // 23 significant bits of the DIFFERENCE.  (Forming it in f64 first was measured: +0.09 ms, no effect on the
+                // evaluation error -- that is the f32 accumulation of the GEMM, not this operand.)
+                float v = 0.f;
                 if (b < d.Q && i < d.L && j < d.L && i != j) {
-                    v = (double)load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, b);
-                    if (!d.gap_mode) v -= (double)load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
+                    v = load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, b);
+                    if (!d.gap_mode) v -= load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
                     v *= sc;
                 }
                 const _Float16 h = (_Float16)v;
                 hi[e8] = h;
-                lo[e8] = (_Float16)(v - (double)h);
+                lo[e8] = (_Float16)(v - (float)h);
             }
             *(half8 *)(tile_hi + (size_t)(half * d.Q + a) * 512 + lane * 8) = hi;
             *(half8 *)(tile_lo + (size_t)(half * d.Q + a) * 512 + lane * 8) = lo;
@@ -1061,21 +1062,13 @@ __device__ __forceinline__ float sum_over_g(float v) {
     auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
-// exp(x) for the softmax.  __expf is v_exp_f32(x * 1.44269502f): the float nearest to log2(e) is 1.33e-8 (relative) too
-// small, which evaluates every softmax at a temperature 1.33e-8 off -- for x = H - max = -8 every probability comes out
-// 1e-7 too LARGE, the same way in every sequence: a coherent error that the gradient sums add up N-fold.  It was the
-// systematic part of |g_hip - g_f64| at scale (4.7e-4 |x| at the headline, growing with N L; round 2 attributed it to
-// the MFMA accumulation).  Adding the low part of the constant to the PRODUCT does not help: x * LO is below half an ulp
-// of x * HI and rounds away every time.  It is applied to the RESULT instead: exp(x) = 2^(x HI) * 2^(x LO) =
-// r + r * (x * LO ln 2).  What is left is the random rounding of x * HI, which averages out over the sequences.
-// (x = -inf, a masked state, is clamped to a finite value whose exponential is still exactly 0: 0 * inf would be NaN.)
-__device__ __forceinline__ float exp_unbiased(float x) {
-    const float LOG2E_HI = 1.44269502162933349609375f;       // 0x3fb8aa3b, the float nearest to log2(e)
-    const float LO_LN2 = 1.3349758e-8f;                      // (log2(e) - LOG2E_HI) * ln 2
-    x = fmaxf(x, -200.f);
-    const float r = __builtin_amdgcn_exp2f(x * LOG2E_HI);
-    return __builtin_fmaf(r, x * LO_LN2, r);
-}
+// exp(x) for the softmax: __expf = v_exp_f32(x * 1.44269502f).  The float nearest to log2(e) is 1.33e-8 (relative) too
+// small, i.e. every softmax runs at a temperature 1.33e-8 off -- a coherent error in principle (the same way in every
+// sequence).  Round 3 suspected it of the systematic part of |g_hip - g_f64| at scale, corrected it (the low part of the
+// constant applied to the result, r + r * x * 1.335e-8) and measured NO change of that error (4.0e-4 |x| at the headline
+// either way: it is the f32 accumulation of the forward GEMM, tests/probes/operand_grid_probe.py) at +0.1 ms per pass
+// over HJ: not kept.
+__device__ __forceinline__ float exp_softmax(float x) { return __expf(x); }
 // log(z) = log2(z) * ln 2 with the same care (the f32 ln 2 is 2.1e-9 too large; irrelevant for the gradient, kept exact
 // for the objective's sake)
 __device__ __forceinline__ float log_unbiased(float z) {
@@ -1117,7 +1110,24 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     const int gap = d.gap_mode;
     const int i = b16 * 16 + r;
     const bool site_ok = i < d.L;
-    // (the fields are read inside the loop over the two halves: see there)
+    // The fields (+ the reference-state constants of the forward GEMM) as hi + lo f32 pairs of their f64 values.  A field
+    // rounded to f32 shifts H of EVERY sequence by the same ~1e-7, a systematic error of the gradient sums that put a
+    // floor of ~1e-2 under |g_h| at N = 50 000; with the low part added separately the rounding of (HJ + lo) + hi
+    // differs from sequence to sequence and averages out.  The statistics-only instantiations read them once; the ones
+    // that write residual fragments read them again for the second half (42 registers that would otherwise stay live
+    // through the residual epilogue of the first half; the second read hits L2).
+    float hv[Q], hl[Q];
+    auto load_fields = [&](bool opaque) {
+        u32 hoff = (u32)(site_ok ? i - d.h_site0 : 0) * Q, coff = (u32)(b16l * 16 + r) * Q;
+        if (opaque) asm volatile("" : "+v"(hoff), "+v"(coff));   // per iteration: the loads must not be hoisted out of the loop
+#pragma unroll
+        for (int a = 0; a < Q; a++) {
+            const double h64 = site_ok ? A.h[hoff + a] + (A.c ? A.c[coff + a] : 0.0) : 0.0;
+            hv[a] = (float)h64;
+            hl[a] = (float)(h64 - (double)hv[a]);
+        }
+    };
+    if constexpr (!WRITE_RT) load_fields(false);
     float fxl = 0.f;
     // statistics areas, one per wave: gradient sums [site][Q] in f64, then Hessian sums [site][NH] in f32.  Lanes add
     // with fire-and-forget LDS adds (the 4 lanes of a site collide on one address inside one instruction: resolved in
@@ -1138,20 +1148,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     asm volatile("" : "+s"(m_end));   // opaque trip count: the loop must not be unrolled (register pressure)
 #pragma nounroll
     for (int m = 0; m < m_end; m++) {
-        // the fields (+ the reference-state constants of the forward GEMM) as hi + lo f32 pairs of their f64 values.  A
-        // field rounded to f32 shifts H of EVERY sequence by the same ~1e-7, a systematic error of the gradient sums that
-        // put a floor of ~1e-2 under |g_h| at N = 50 000; with the low part added separately the rounding of
-        // (HJ + lo) + hi differs from sequence to sequence and averages out.  Read once per half (42 registers that
-        // would otherwise stay live through the residual epilogue of the first half; the second read hits L2).
-        float hv[Q], hl[Q];
-        u32 hoff = (u32)(site_ok ? i - d.h_site0 : 0) * Q, coff = (u32)(b16l * 16 + r) * Q;
-        asm volatile("" : "+v"(hoff), "+v"(coff));   // opaque per iteration: the loads must not be hoisted out of the loop
-#pragma unroll
-        for (int a = 0; a < Q; a++) {
-            const double h64 = site_ok ? A.h[hoff + a] + (A.c ? A.c[coff + a] : 0.0) : 0.0;
-            hv[a] = (float)h64;
-            hl[a] = (float)(h64 - (double)hv[a]);
-        }
+        if constexpr (WRITE_RT) load_fields(true);
         f32x4 acc[Q];
 #pragma unroll
         for (int a = 0; a < Q; a++) {
@@ -1178,7 +1175,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             for (int a = 0; a < Q; a++) {
                 const float H = acc[a][reg] - mx;
                 hx = (a == xi) ? H : hx;
-                const float ev = exp_unbiased(H);
+                const float ev = exp_softmax(H);
                 acc[a][reg] = ev;
                 Z += ev;
             }

@@ -9,7 +9,9 @@ checked is a switch (PLM_CONV_* of include/plm_hip.h).  This script
   2. runs `plmc` on each with exactly the argv `run_plmc` assembles (evcouplings/couplings/tools.py:202-262), with and
      without -g, run to convergence (-m max would take plmc hours: the iteration count is an option),
   3. runs the HIP solver on the same files for every combination of the convention switches that applies to the mode
-     (solver "joint" at the same iteration count -- plmc's own algorithm -- and solver "vp" to convergence),
+     (solver "joint" at the same iteration count -- plmc's own algorithm, the like-for-like comparison when plmc was
+     stopped by its iteration limit -- and solver "vp" to a 10x tighter stop rule: the optimum itself, which a converged
+     plmc must sit within its own tolerance of),
   4. prints a table of max |dCN| per combination and names the combination that agrees best,
   5. stores plmc's _ECs.txt under tests/golden/plmc_<case>[_g]_ECs.txt with a JSON record of argv, plmc's stderr and the
      winning switches: from then on tests/ can pin the solver without the binary.
@@ -124,7 +126,8 @@ def main(argv=None):
                         t0 = time.time()
                         tools.infer_to_files(ali, out_ec, None, focus_seq=focus, theta=theta, ignore_gaps=gaps,
                                              iterations=int(iters) if str(iters).isdigit() else iters, lambda_h=lambda_h,
-                                             lambda_J=lambda_j, conventions=conv, solver=solver)
+                                             lambda_J=lambda_j, conventions=conv, solver=solver,
+                                             epsilon=1e-4 if solver == "vp" else None)
                         got = read_cn(out_ec)
                         d = float(np.abs(np.array([got[kk] for kk in keys]) - refv).max())
                         rows.append({"solver": solver, "iterations": str(iters), "conventions": conv, "max_abs_dCN": d,

@@ -3,7 +3,7 @@
 # no kernels) + the PMC passes (each counter set is its own run, never combined with trace domains other than
 # --kernel-trace); summaries left under gpurun_out/prof_TAG for copying into profiles/ (run through gpurun).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -13,7 +13,7 @@ echo "stats rc=$?"
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
-           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INST_CYCLES_VMEM" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_I8" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc/p$i -o p$i --output-format csv -- python $GRAFT_REPO_ROOT/scripts/eval_loop.py > $OUT/pmc_p$i.log 2>&1

@@ -897,8 +897,9 @@ def test_pin_kit_sweeps_the_conventions_against_a_plmc_like_binary(plm, tmp_path
     best = r["best"]
     assert best["max_abs_dCN"] < 1e-4 and best["conventions"] in (0, 32), best      # 32 = f32 threshold: same counts at 0.8
     by = {(row["solver"], row["conventions"]): row["max_abs_dCN"] for row in r["table"]}
-    assert by[("vp", 0)] < 2e-5                       # the same solver on both sides
-    assert by[("joint", 0)] < 1e-4                    # plmc's algorithm, run to the same stop rule: the same optimum
+    assert by[("vp", 0)] < 1e-4                       # the optimum (10x tighter stop rule) against the 'binary' at its own rule
+    assert by[("joint", 0)] < 5e-4                    # plmc's algorithm to the same stop rule: a second point inside that
+                                                      # tolerance of the same optimum (1.9e-4 apart on this small problem)
     assert by[("vp", 512)] > 1e-3                     # a convention that changes the scores is told apart
     assert json.load(open(str(tmp_path / "g" / "plmc_small.json")))["best"]["solver"] in ("vp", "joint")
 
