@@ -201,6 +201,7 @@ struct plm_ctx {
     uint32_t *maxbits = nullptr;
     int32_t *jexp = nullptr;
     float *x = nullptr, *g = nullptr, *xp = nullptr, *gp = nullptr, *dir = nullptr, *hist = nullptr;
+    float *xa = nullptr, *ga = nullptr;   // anchor point of the next curvature pair when pairs had to be skipped (lazy)
     float *canon = nullptr;    // canonical-layout staging (n_canon floats, + L*L for fn)
     float *dinv = nullptr;     // H0 diagonal of the preconditioned L-BFGS (n_local floats), built by plm_ctx_optimize
     // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
@@ -642,7 +643,8 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     hipSetDevice(c->device);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->vp_flag};
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->vp_flag,
+                    c->xa, c->ga};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);
@@ -1162,6 +1164,10 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
     c->eval_valid = false;
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
+    // The next pair is (x - anchor, g - g(anchor)).  The anchor is the previous accepted point (xp, gp) -- unless the
+    // pair(s) since were skipped as noise (below): then it stays where the last STORED pair ended, in its own buffers,
+    // so that the difference is taken over a longer baseline, where H s outgrows the evaluation error again.
+    bool anchored = false;
     double last_cond = std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx));   // |g|/max(1,|x|) at the last accepted point
     if (last_cond > eps) {
         // first step: unit displacement along the plain gradient; the D^-1-scaled direction is Newton-like for the
@@ -1213,7 +1219,7 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
                     // overwritten by the next one -- and run the Gram pass now, so that ONE host
                     // synchronisation (and, sharded, one all-reduce) per trial brings back f, the directional
                     // derivative and everything the next direction needs.
-                    HIP_TRY(plm_launch_sy(s_new, y_new, c->x, c->xp, c->g, c->gp, n, c->st));
+                    HIP_TRY(plm_launch_sy(s_new, y_new, c->x, anchored ? c->xa : c->xp, c->g, anchored ? c->ga : c->gp, n, c->st));
                     HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, dinv, wq, wb, c->st));
                     PLM_TRY(norm_dots());
                     PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
@@ -1288,6 +1294,7 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
                     restarts++;
                     stored = 0;
                     end = 0;
+                    anchored = false;
                     step = first_step();
                     continue;
                 }
@@ -1319,12 +1326,36 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
             last_cond = gnorm / std::max(1.0, xnorm);
             if (last_cond <= eps) { status = PLM_STATUS_CONVERGED; break; }
             if (max_iter > 0 && k + k_off >= max_iter) { status = PLM_STATUS_MAXITER; break; }
-            if (SY[e * m + e] > 0) {   // curvature pair accepted (always true under the Wolfe conditions)
+            // Curvature pair of the accepted step (slot e).  s.y > 0 always holds under the Wolfe conditions -- for exact
+            // gradients.  Near the noise floor of the evaluation (config 3: error 1e-3 |x| at a stop rule of 1e-3) steps
+            // get so short that y = H s + (difference of two evaluation errors) is mostly the latter: s.y is then a tiny
+            // number of either sign, 1 / s.y blows the two-loop coefficients up (seen with PLM_DEBUG: directions whose
+            // g.d disagreed in sign with the value the coefficients imply, a unit step raising f by 8e14) and the fit
+            // ends in a line-search failure.  For a convex quadratic cos(s, H s) >= 2 sqrt(k) / (1 + k) with k the
+            // condition number (0.12 at the headline's 120 : 3.5e4; the field part of s lowers it to ~0.04), a pair of
+            // pure noise has cos ~ 1 / sqrt(P) = 2e-4: pairs below 1e-3 are not stored (the history keeps its other
+            // pairs; the slot is written again by the next iteration -- with a pair over the longer baseline from the
+            // anchor, see `anchored`).
+            const double sy = SY[e * m + e], ss = md[0 * nbv + e], yy = md[1 * nbv + nst + e];
+            if (sy > 0 && sy * sy >= 1e-6 * ss * yy) {
                 stored = nst;
                 end = (end + 1) % m;
+                anchored = false;
+            } else if (sy > 0) {       // noise-dominated pair: skipped; slot e (the oldest pair once the ring is full) is gone
+                stored = std::min(stored, m - 1);
+                if (!anchored) {       // keep the point the pair started from: (xp, gp) is overwritten by the next swap
+                    if (!c->xa) {
+                        PLM_TRY(dalloc(&c->xa, (size_t)n));
+                        PLM_TRY(dalloc(&c->ga, (size_t)n));
+                    }
+                    HIP_TRY(hipMemcpyAsync(c->xa, c->xp, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+                    HIP_TRY(hipMemcpyAsync(c->ga, c->gp, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+                    anchored = true;
+                }
             } else {                   // slot e now holds a rejected pair: restart the history
                 stored = 0;
                 end = 0;
+                anchored = false;
             }
             step = 1.0;
         }
