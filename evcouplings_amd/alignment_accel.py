@@ -23,9 +23,9 @@ _ORIGINAL = {}
 
 
 def _gpu_weights(seq_weights):
-    """float32 weights in the range the library's f16 residual split accepts (< 4).  Frequencies are ratios of
-    weighted sums, so a power-of-two rescale changes nothing -- the reference accepts any non-negative weights
-    (align/alignment.py:1078-1153) and so does this."""
+    """float32 weights for the library.  Frequencies are ratios of weighted sums, so a power-of-two rescale changes
+    nothing -- the reference accepts any non-negative weights (align/alignment.py:1078-1153) and so does this; large
+    weights are brought into (0.5, 1] so that their float32 sum N_eff keeps its precision."""
     w = np.asarray(seq_weights, dtype=np.float64)
     top = float(w.max()) if w.size else 0.0
     if top >= 2.0:

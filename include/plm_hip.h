@@ -54,7 +54,9 @@ typedef struct {
     double lambda_j;     /* L2 strength on couplings, as passed to plmc -le (already scaled
                             by (q-1)(L-1), protocol.py:179) */
     int32_t max_iter;    /* L-BFGS iterations; 0 = until converged */
-    double epsilon;      /* stop when |g| / max(1,|x|) < epsilon */
+    double epsilon;      /* stop when |g| / max(1,|x|) < epsilon.  Also selects the precision of the backward GEMM's
+                            fixed-point residuals at context creation: 24 bits (three int8 digit planes), or 32 bits
+                            (four planes, 4/3 of the cost) when 0 < epsilon < 1e-4 */
     int32_t lbfgs_m;     /* history length; 0 = default (6) */
     int32_t n_shards;    /* site shards (GPUs); 1 = single GPU */
     int32_t shard;       /* this process' shard index */
@@ -81,7 +83,8 @@ typedef struct {
  * projection (fields solved exactly by Newton for every trial couplings, L-BFGS over the couplings only:
  * DESIGN.md section 2c).  Same objective, same optimum; the joint path needs ~10-20x more iterations to reach
  * |g|/|x| < epsilon.  With max_iter far below convergence (the reference default 100) the two paths stop at
- * different points. */
+ * different points.  The Python boundary exposes it as solver="joint" / PLM_HIP_SOLVER=joint / plmc_hip --solver joint.
+ * (lambda_h = 0 always runs this path: the per-site Hessians of the field solver are then singular.) */
 #define PLM_FLAG_JOINT_LBFGS 16
 /* ---- convention switches ---------------------------------------------------------------------------------------
  * plmc is not available to this project, so a few of its conventions cannot be checked; each
