@@ -116,3 +116,44 @@ def test_onehot16_marks_matches_with_minus128():
         a = ~y & np.uint32(0x80808080)
         for k in range(4):
             np.testing.assert_array_equal(as_i8((a >> np.uint32(8 * k)) & np.uint32(0xff)), np.where(xb[:, k] == b, -128, 0))
+
+
+def test_residual_fragment_addressing_writer_and_reader_agree():
+    """The Rt layout [plane][128-sequence step][column fragment][half][64 lanes][16 B] as k_hpass writes it (a workgroup =
+    256 sequences x 16 sites, wave w = 32 sequences, two halves m of 16, lane (g = lane / 16, r = lane % 16) holding the
+    4 sequences 4 g .. 4 g + 3 of the half) against how k_bwd reads it (K step ss, half H, fragment lane (G, c) = the 16
+    consecutive sequences 128 ss + 64 H + 16 G + e of site c).  Every (plane, sequence, column fragment, site) byte
+    must have exactly one writer, at the address the reader expects."""
+    Np, nnfl, Q, nplanes = 512, 2 * 5, 5, 3
+    nst128 = Np // 128
+    expect = {}
+    # reader: byte address -> (plane, sequence, nf, site)
+    for p in range(nplanes):
+        for ss in range(nst128):
+            for nf in range(nnfl):
+                for H in range(2):
+                    for lane in range(64):
+                        G, c = lane >> 4, lane & 15
+                        for e in range(16):
+                            addr = ((((p * nst128 + ss) * nnfl + nf) * 2 + H) * 1024) + lane * 16 + e
+                            expect[addr] = (p, 128 * ss + 64 * H + 16 * G + e, nf, c)
+    # writer (k_hpass): tile stile of 256 sequences, wave, half m, lane (g, r), state a of site block b16l
+    seen = {}
+    for stile in range(Np // 256):
+        for b16l in range(nnfl // Q):
+            for wave in range(8):
+                s64 = stile * 4 + (wave >> 1)
+                for m in range(2):
+                    Gq = 2 * (wave & 1) + m
+                    for lane in range(64):
+                        g, r = lane >> 4, lane & 15
+                        for a in range(Q):
+                            nf = b16l * Q + a
+                            for p in range(nplanes):
+                                base = ((((p * nst128 + (s64 >> 1)) * nnfl + nf) * 2 + (s64 & 1)) * 1024) + (Gq * 16 + r) * 16
+                                for reg in range(4):
+                                    s = stile * 256 + wave * 32 + 16 * m + 4 * g + reg
+                                    addr = base + 4 * g + reg
+                                    assert addr not in seen
+                                    seen[addr] = (p, s, nf, r)
+    assert seen == expect
