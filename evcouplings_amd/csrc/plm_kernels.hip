@@ -682,12 +682,14 @@ hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhal
 }
 
 // =========================================================================================
-// K_fwd: potentials + conditional softmax + residuals (rows a6 forward half)
-//   workgroup = 256 sequences x one 16-site block (all Q states); 8 waves x 32 sequences.
-//   K loop: 32 sites x one state per MFMA step; A = one-hot from registers, B = Bt tile
-//   streamed global -> LDS by global_load_lds (double buffered, one barrier per step).
-//   Accumulator fragment `a` of a wave holds H[s, i, a] for 16 sites i (lane & 15) and
-//   4 sequences per lane, so the softmax over states is pure in-lane register work.
+// K_fwd: the coupling part of every conditional, HJ[s,(i,a)] = sum_{j != i} J_ij(a, x_sj)   (row a6, forward half)
+//   One-hot(MSA) x J as a GEMM on the 2:4 sparse f16 MFMA.  Workgroup = 256 sequences x one 16-site block (all Q
+//   states); 8 waves x 32 sequences.  K loop: one step = (32-site block u, instruction slice ci, plane hi / lo); A =
+//   compressed one-hot fragments built in registers from the packed alignment, B = Bt tile streamed global -> LDS by
+//   global_load_lds (double buffered, one barrier per step).  Accumulator fragment `a` of a wave holds HJ[s, i, a] for
+//   16 sites i (lane & 15) and 4 sequences per lane.  Epilogues (template parameter MODE): FWD_STORE writes HJ for
+//   k_hpass (the fit and plm_eval: softmax, residuals and the field solver live there -- the fused softmax epilogue of
+//   rounds 1-2 is gone), FWD_ENERGY / FWD_POTENTIALS serve the statistical energies of row N2.
 // =========================================================================================
 struct FwdArgs {
     const int8_t *msa_rm;

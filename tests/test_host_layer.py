@@ -270,3 +270,21 @@ def test_real_alignment_through_the_host_layer_matches_the_reference(golden_dir,
     fi, fij = oracle64.marginals(enc.msa, w, 21)
     np.testing.assert_allclose(fi, z["fi"], atol=1e-13)
     np.testing.assert_allclose(fij, z["fij_pairs"], atol=2e-7)                # stored as float32
+
+
+def test_multi_gpu_launch_errors_stay_inside_the_error_conventions(tmp_path, monkeypatch):
+    """Without a GPU the ranks of a multi-GPU job die at once: dist.launch_fit must report that as LaunchError (with the
+    ranks' stderr), and the run_plmc drop-in -- whose single-GPU fallback cannot work here either -- must surface an
+    ExternalToolError, as for every other solver failure; nothing may fall back to a CPU computation."""
+    from evcouplings_amd import _lib, dist
+    if _lib.load().plm_device_count() > 0:
+        pytest.skip("needs a host without a GPU")
+    msa, _ = synthetic_msa(40, 16, seed=2)
+    monkeypatch.setenv("PLM_DIST_BACKEND", "gloo")
+    with pytest.raises(dist.LaunchError) as err:
+        dist.launch_fit(msa, 2, q=21, max_iter=3, timeout=600)
+    assert "multi-GPU fit failed" in str(err.value)
+    ali = msa_to_a2m(msa, str(tmp_path / "s.a2m"))
+    with pytest.warns(UserWarning, match="running on one GPU"):
+        with pytest.raises(tools.ExternalToolError):
+            tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), focus_seq="SYN/1-16", iterations=3, gpus=2)
