@@ -9,6 +9,8 @@ attribute ``ct.run_plmc``, so the ``standard`` (:363) and ``complex`` (:480) pro
 unchanged on top of the GPU inference.  ``uninstall()`` restores the subprocess path.
 
 The alternative that needs no Python hook at all is the CLI shim: ``tools: plmc: bin/plmc_hip``.
+``register_protocols()`` adds ``standard_hip`` / ``complex_hip`` to the reference's protocol registry
+(couplings/protocol.py:922-931), selectable with the config key ``protocol``.
 
 ``install_all()`` additionally installs the optional GPU drop-ins of the rows SURVEY.md section 8f lists:
 statistical energies behind ``CouplingsModel`` (``model_accel``), mean-field DCA (``mean_field``) and the
@@ -46,6 +48,54 @@ def infer_plmc(**kwargs):
         return cp.infer_plmc(**kwargs)
     finally:
         uninstall()
+
+
+# ---- protocol registry entries ------------------------------------------------------------------------------------
+# `couplings/protocol.py:922-931` keeps its inference protocols in the dict PROTOCOLS and `run()` (:934-974) looks the
+# config key `protocol` up there.  register_protocols() adds "standard_hip" and "complex_hip": the reference's own
+# `standard` / `complex` functions with the HIP solver installed for the duration of the call, so a pipeline config
+# selects the GPU path with `protocol: standard_hip` -- and may carry three keys plmc does not have, `hip_solver`
+# ("vp" | "joint"), `hip_gpus` (N | "max") and `hip_conventions` (PLM_CONV_* bits), which travel to run_plmc_hip
+# through the environment variables it reads (the reference's infer_plmc passes a fixed argument list on).
+_ENV_KEYS = {"hip_solver": "PLM_HIP_SOLVER", "hip_gpus": "PLM_HIP_GPUS", "hip_conventions": "PLM_HIP_CONVENTIONS"}
+
+
+def _wrapped(name):
+    def protocol(**kwargs):
+        import os
+        import evcouplings.couplings.protocol as cp
+        saved = {}
+        for key, env in _ENV_KEYS.items():
+            if kwargs.get(key) is not None:
+                saved[env] = os.environ.get(env)
+                os.environ[env] = str(kwargs[key])
+        install()
+        try:
+            return cp.PROTOCOLS[name](**kwargs)
+        finally:
+            uninstall()
+            for env, old in saved.items():
+                if old is None:
+                    os.environ.pop(env, None)
+                else:
+                    os.environ[env] = old
+    protocol.__name__ = name + "_hip"
+    protocol.__doc__ = "evcouplings.couplings.protocol.%s on the MI355X solver (evcouplings_amd.tools.run_plmc_hip)" % name
+    return protocol
+
+
+def register_protocols():
+    """Add "standard_hip" / "complex_hip" to evcouplings.couplings.protocol.PROTOCOLS.  Returns the registry."""
+    import evcouplings.couplings.protocol as cp
+    for name in ("standard", "complex"):
+        cp.PROTOCOLS.setdefault(name + "_hip", _wrapped(name))
+    return cp.PROTOCOLS
+
+
+def unregister_protocols():
+    import evcouplings.couplings.protocol as cp
+    for name in ("standard_hip", "complex_hip"):
+        cp.PROTOCOLS.pop(name, None)
 
 
 def install_all():

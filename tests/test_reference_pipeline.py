@@ -120,6 +120,36 @@ def test_reference_standard_protocol_runs_on_our_backend(ref, gpu_fit, golden_di
     assert calls == [] and out2["num_sites"] == 24
 
 
+def test_registered_protocol_selects_the_gpu_path_and_carries_the_solver_options(ref, gpu_fit, golden_dir, tmp_path, monkeypatch):
+    """`protocol: standard_hip` in a pipeline config (couplings/protocol.py:934-974 looks the key up in PROTOCOLS): the
+    reference's `standard` runs with the HIP solver installed for the call only; the extra config keys hip_solver /
+    hip_conventions reach the solver, the environment is left as it was."""
+    fit, calls, z = gpu_fit
+    from evcouplings_amd import protocol as hip_protocol
+    from evcouplings_amd import tools as hip_tools
+    cp = ref["cp"]
+    monkeypatch.delenv("PLM_HIP_SOLVER", raising=False)
+    monkeypatch.delenv("PLM_HIP_CONVENTIONS", raising=False)
+    reg = hip_protocol.register_protocols()
+    try:
+        assert {"standard", "complex", "mean_field", "standard_hip", "complex_hip"} <= set(reg)
+        kwargs = dict(
+            prefix=str(tmp_path / "c" / "job"), alignment_file=os.path.join(golden_dir, "hip_fit_L24.a2m"), focus_mode=True,
+            focus_sequence="SYN/10-33", segments=None, theta=0.8, alphabet=None, ignore_gaps=False, iterations=100,
+            lambda_h=0.01, lambda_J=0.01, lambda_J_times_Lq=True, lambda_group=None, scale_clusters=None, cpu=2,
+            plmc="plmc", reuse_ecs=False, min_sequence_distance=6, frequencies_file=None, scoring_model="skewnormal",
+            save_model=True, hip_solver="joint", hip_conventions=512)
+        outcfg = cp.run(protocol="standard_hip", **kwargs)
+        assert ref["ct"].run_plmc is not hip_tools.run_plmc_hip                      # installed for the call only
+        (shape, kw), = calls
+        assert shape == (500, 24) and kw["joint"] is True and kw["conventions"] == 512
+        assert "PLM_HIP_SOLVER" not in os.environ and "PLM_HIP_CONVENTIONS" not in os.environ
+        assert outcfg["num_sites"] == 24 and os.path.getsize(outcfg["ec_file"]) > 0
+    finally:
+        hip_protocol.unregister_protocols()
+    assert "standard_hip" not in cp.PROTOCOLS
+
+
 def test_fast_model_reader_is_a_drop_in_for_the_reference_reader(ref, golden_dir):
     """model_accel's vectorised plmc_v2 reader vs the reference's own (model.py:317-400): every attribute the
     reference reader sets, same dtype, same values; derived scores unchanged."""
