@@ -13,8 +13,9 @@ on tests/golden/hip_fit_L24.a2m with a few sequences turned into fragments and t
 filters bite.  Output: tests/golden/align_stats.npz.
 
 Real data: the one alignment the reference ships, notebooks/example/example_aln.a2m (53 cadherin
-sequences x 423 columns, 3 insert columns in lowercase / '.', real gap runs), is copied to tests/golden/example_aln.a2m
-(a test fixture) and run through the reference's own Alignment class the way the couplings stage sees it: match columns
+sequences x 423 columns, 3 insert columns in lowercase / '.', real gap runs), is read where it lies (its character
+matrix and ids go into the fixture; the tests write an A2M file from them) and run through the reference's own
+Alignment class the way the couplings stage sees it: match columns
 of the first sequence (couplings/mean_field.py:103-109), sequence weights at 80 % identity, single-site and pair
 frequencies, the describe_frequencies table.  Output: tests/golden/example_aln.npz.
 
@@ -84,14 +85,11 @@ def main():
 
 
 def real_data():
-    import shutil
     import evcouplings.align.alignment as ra
     import evcouplings.align.protocol as rp
     from oracle.oracle import Oracle
     src = os.path.join(refstubs.REFERENCE, "notebooks", "example", "example_aln.a2m")
-    dst = os.path.join(HERE, "example_aln.a2m")
-    shutil.copyfile(src, dst)
-    with open(dst) as f:
+    with open(src) as f:
         ali = ra.Alignment.from_file(f, "fasta")
     focus = ali.matrix[0]
     keep_cols = np.array([c.isupper() for c in focus])             # uppercase = match state, not a gap, not an insert
@@ -105,7 +103,7 @@ def real_data():
     L = sel.L
     iu, ju = np.triu_indices(L, 1)
     freq = rp.describe_frequencies(sel, 1, target_seq_index=0)
-    out = dict(ids=np.array(list(ali.ids)), keep_cols=keep_cols, mapped=mapped.astype(np.int8), counts=counts.astype(np.int32),
+    out = dict(ids=np.array(list(ali.ids)), chars_full=ali.matrix.astype("S1"), keep_cols=keep_cols, mapped=mapped.astype(np.int8), counts=counts.astype(np.int32),
                weights=sel.weights, fi=fi, fij_pairs=fij[iu, ju].astype(np.float32), n_eff=float(sel.weights.sum()),
                freq_columns=np.array(list(freq.columns)), freq_values=freq.drop(columns=["A_i"]).to_numpy(dtype=float),
                freq_target=np.array(list(freq["A_i"])), seq_gap_frac=sel.count("-", axis="seq"),

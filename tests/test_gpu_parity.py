@@ -837,13 +837,22 @@ def test_solver_selection_reaches_the_joint_path_through_the_boundary(plm, tmp_p
         tools.run_plmc_hip(ali, str(tmp_path / "x.txt"), solver="newton", **kw)
 
 
+def _example_a2m(z, tmp_path):
+    """the reference's example alignment as an A2M file, written from the character matrix the fixture holds"""
+    path = str(tmp_path / "example_aln.a2m")
+    with open(path, "w") as f:
+        for name, row in zip(z["ids"].tolist(), z["chars_full"]):
+            f.write(">%s\n%s\n" % (name, row.tobytes().decode("ascii")))
+    return path
+
+
 def test_real_alignment_end_to_end(plm, oracle64, golden_dir, tmp_path):
     """Real data: the reference's example alignment (53 x 423 with insert columns and gap runs)
     through encoder -> reweighting -> marginals -> frequency table on the GPU against what the reference's Alignment
     class computed (tests/golden/example_aln.npz), an evaluation against the oracle, and the whole run_plmc drop-in."""
     from evcouplings_amd import alignment_accel, alignment_io, model_io, tools
     z = np.load(os.path.join(golden_dir, "example_aln.npz"))
-    a2m = os.path.join(golden_dir, "example_aln.a2m")
+    a2m = _example_a2m(z, tmp_path)
     enc = alignment_io.encode_alignment(a2m, focus_seq="Q641K6_MOUSE")
     np.testing.assert_array_equal(enc.msa, z["mapped"])
     counts = plm.reweight(enc.msa, 0.8)

@@ -251,12 +251,22 @@ def test_map_matrix_drop_in_handles_empty_cells():
         alignment_accel._int8_states(np.array([[0, 200]]), "matrix")
 
 
-def test_real_alignment_through_the_host_layer_matches_the_reference(golden_dir, oracle64):
+def _example_a2m(z, tmp_path):
+    """the reference's example alignment as an A2M file, written from the character matrix the fixture holds"""
+    path = str(tmp_path / "example_aln.a2m")
+    with open(path, "w") as f:
+        for name, row in zip(z["ids"].tolist(), z["chars_full"]):
+            f.write(">%s\n%s\n" % (name, row.tobytes().decode("ascii")))
+    return path
+
+
+def test_real_alignment_through_the_host_layer_matches_the_reference(golden_dir, oracle64, tmp_path):
     """The one alignment the reference ships (notebooks/example/example_aln.a2m: 53 cadherin sequences, 423 columns, three
     of them inserts -- lowercase in the first sequence, '.' elsewhere --, real gap runs) through the A2M reader and
     the oracle, against what the reference's own Alignment class made of it (tests/golden/make_golden_align.py)."""
     z = np.load(os.path.join(golden_dir, "example_aln.npz"))
-    enc = alignment_io.encode_alignment(os.path.join(golden_dir, "example_aln.a2m"), focus_seq="Q641K6_MOUSE")
+    a2m = _example_a2m(z, tmp_path)
+    enc = alignment_io.encode_alignment(a2m, focus_seq="Q641K6_MOUSE")
     assert enc.msa.shape == (53, 420) and enc.n_total_sites == 423 and enc.n_valid_seqs == enc.n_total_seqs == 53
     np.testing.assert_array_equal(enc.msa, z["mapped"])                       # same columns kept, same encoding
     # index_list numbers the focus residues: the three insert positions leave gaps in the numbering
