@@ -129,7 +129,10 @@ def alignment_count(self, char, axis="pos", normalize=True):
     codes = _char_codes(self.matrix)
     ch = char.decode("latin-1") if isinstance(char, bytes) else char
     if codes is None or not isinstance(ch, str) or len(ch) != 1 or ord(ch) > 126:
-        return _ORIGINAL_COUNT[type(self)](self, char, axis=axis, normalize=normalize)   # exotic input: upstream code
+        # exotic input (other dtypes, code points above 127): the upstream arithmetic (align/alignment.py:742-746)
+        naxis = 0 if axis == "pos" else 1
+        c = np.sum(self.matrix == char, axis=naxis)
+        return c / self.matrix.shape[naxis] if normalize else c
     from evcouplings_amd import plm
     seq_counts, col_counts, _ = plm.alignment_stats(codes, ord(ch))
     c = (col_counts if axis == "pos" else seq_counts).astype(np.int64)

@@ -1001,11 +1001,12 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
 // entry of the Gram matrix of {s_j, y_j, g}, refreshed by ONE pass over the history per
 // iteration (k_multidot), and the direction is ONE fused linear combination (k_multiaxpy).
 // Two host synchronisations per iteration: after the line-search evaluation and after the pass.
-// One phase of an optimisation: L-BFGS from the current point until |g| / max(1, |x|) <= eps or the iteration budget is
-// spent.  k_off / t0: iterations already done and the start time of the whole optimisation (a second phase continues
-// the numbering of the iteration callback and the clock).
-static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res, const double eps, const int k_off,
-                          const double t0) {
+int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
+    HIP_TRY(hipSetDevice(c->device));
+    const double eps = c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3;
+    const double t0 = now_s();
     const PlmDims &d = c->d;
     const int64_t n = d.n_local;
     const int m = std::min(20, c->prob.lbfgs_m > 0 ? c->prob.lbfgs_m : 6);
@@ -1057,7 +1058,7 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
     std::vector<double> SY(m * m, 0.0), YDY(m * m, 0.0), Sg(m, 0.0), YDg(m, 0.0);
     double gg = 0, gDg = 0, xx = 0, hh = 0;
     std::vector<double> alpha(m), cs(m), cy(m);
-    if (k_off == 0) c->n_evals = 0;
+    c->n_evals = 0;
     // device scalar slots; in sharded-state mode each fetch is preceded by a sum over the shards of
     // exactly the slots that were just written ([FX..DG] after an evaluation, [XX..MD+..] after the pass)
     enum { SL_FX = 0, SL_NLL = 1, SL_DG = 2, SL_XX = 3, SL_HH = 4, SL_GH2 = 5, SL_MD = 8 };
@@ -1322,11 +1323,11 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
             gh2 = gh2_trial;
             const double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg + gh2);
             if (cb)
-                cb(k + k_off, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
+                cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
                    std::sqrt(std::max(0.0, xx - hh)), user);
             last_cond = gnorm / std::max(1.0, xnorm);
             if (last_cond <= eps) { status = PLM_STATUS_CONVERGED; break; }
-            if (max_iter > 0 && k + k_off >= max_iter) { status = PLM_STATUS_MAXITER; break; }
+            if (max_iter > 0 && k >= max_iter) { status = PLM_STATUS_MAXITER; break; }
             // Curvature pair of the accepted step (slot e).  s.y > 0 always holds under the Wolfe conditions -- for exact
             // gradients.  Near the noise floor of the evaluation (config 3: error 1e-3 |x| at a stop rule of 1e-3) steps
             // get so short that y = H s + (difference of two evaluation errors) is mostly the latter: s.y is then a tiny
@@ -1368,7 +1369,7 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
     c->last_nll = nll;
     c->last_gh2 = gh2;
     if (res) {
-        res->iters_done = k + k_off;
+        res->iters_done = k;
         res->n_evals = c->n_evals;
         res->status = status;
         res->fx = fx;
@@ -1386,13 +1387,6 @@ static int optimize_phase(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t
             snprintf(res->status_msg, sizeof res->status_msg, "%s", status_text(status));
     }
     return PLM_OK;
-}
-
-int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res) {
-    if (!c) return fail(PLM_EINVAL, "NULL ctx");
-    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
-    HIP_TRY(hipSetDevice(c->device));
-    return optimize_phase(c, cb, user, res, c->prob.epsilon > 0 ? c->prob.epsilon : 1e-3, 0, now_s());
 }
 
 int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
