@@ -13,10 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLM_HIP_LIB") or os.path.join(_HERE, "libplm_hip.so")
 
 PLM_OK = 0
-STATUS_CONVERGED, STATUS_MAXITER, STATUS_LINESEARCH = 0, 1, 2
-K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_FIELDS, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+STATUS_CONVERGED, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_INTERRUPTED = 0, 1, 2, 3
+ABI_VERSION = 2
+K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_FIELDS, K_FORWARD_ACCURATE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
-ITER_CB = C.CFUNCTYPE(None, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+ITER_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                       C.c_double, C.c_double, C.c_void_p)
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p)
 COLLECTIVE_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
@@ -100,6 +101,8 @@ SYMBOLS = [
     ("plm_ctx_optimize", C.c_int, [_P, ITER_CB, _P, C.POINTER(PlmResult)]),
     ("plm_ctx_scores", C.c_int, [_P, _P, _P]),
     ("plm_ctx_time_kernels", C.c_int, [_P, C.c_int32, _P]),
+    ("plm_lbfgs_coefficients", None, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 
 _lib = None
@@ -129,8 +132,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.plm_version() != 1:
-        raise ImportError("libplm_hip ABI version %d, expected 1" % lib.plm_version())
+    if lib.plm_version() != ABI_VERSION:
+        raise ImportError("libplm_hip ABI version %d, expected %d" % (lib.plm_version(), ABI_VERSION))
     _lib = lib
     return lib
 

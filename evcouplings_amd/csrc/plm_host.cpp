@@ -85,7 +85,22 @@ int cluster_threshold(double theta_id, int L, int conv) {
     return (int)std::ceil(theta_id * (double)L - 1e-9);
 }
 
-int make_dims(const plm_problem_t &p, PlmDims *out) {
+}  // namespace
+// every environment knob of the library, read once per context (nothing on the evaluation path calls getenv)
+PlmOptions plm_options_from_env() {
+    PlmOptions o;
+    if (const char *e = getenv("PLM_BWD_PLANES")) o.bwd_planes = atoi(e) == 4 ? 4 : 3;
+    if (const char *e = getenv("PLM_KSPLIT")) o.ksplit = std::max(1, atoi(e));
+    if (const char *e = getenv("PLM_JEXP_BIAS")) o.jexp_bias = atoi(e);
+    if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
+    o.debug = getenv("PLM_DEBUG") != nullptr;
+    o.debug_vp = getenv("PLM_DEBUG_VP") != nullptr;
+    return o;
+}
+namespace {
+
+int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     PlmDims d;
     memset(&d, 0, sizeof d);
     if (p.n_seqs <= 0 || p.n_sites <= 1) return fail(PLM_EINVAL, "need n_seqs > 0 and n_sites > 1");
@@ -108,7 +123,8 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
     // digit planes of the backward GEMM: 24-bit residuals by default, 32-bit for fits that must converge below 1e-4
     // (the quantisation noise of three planes is ~5e-5 |x| at the headline); PLM_BWD_PLANES = 3 | 4 overrides
     d.nplanes = (p.epsilon > 0 && p.epsilon < 1e-4) ? 4 : 3;
-    if (const char *e = getenv("PLM_BWD_PLANES")) d.nplanes = atoi(e) == 4 ? 4 : 3;
+    if (opt.bwd_planes) d.nplanes = opt.bwd_planes;
+    d.jexp_bias = opt.jexp_bias;
     const float qmax = d.nplanes == 4 ? PLM_R_QMAX4 : PLM_R_QMAX3;
     d.rscale = qmax;                    // for unit weights; plm_ctx_set_weights sets the pair for the weights in use
     d.gscale = 1.0f / (qmax * (float)PLM_BWD_ONEHOT_VALUE);
@@ -132,10 +148,14 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
         // it slightly worse), and every extra set of partial slabs costs k_assemble two more reads of it.
         // Cost in units of one full-K workgroup (a 128-sequence K step is ~1.3 us; the partial slabs reach k_assemble
         // largely through L2 / the 256 MB Infinity Cache -- measured at the headline: ks 1 -> 2 adds 0.11 ms to
-        // k_assemble for 0.98 GB more reads and takes 0.20 ms off k_bwd -- hence the 12 TB/s):
-        const int tiles = d.nrow_tiles * d.ncol_tiles, ks_max = std::max(1, std::min(16, d.nst128 / 8));
-        // int32 accumulators: |sum| <= 128 (one-hot value) * 127 (digit) * (sequences of the K range) must stay below 2^31
-        const int ks_min = std::min(ks_max, std::max(1, (int)(((int64_t)d.Np * 127 * 128) >> 31) + 1));
+        // k_assemble for 0.98 GB more reads and takes 0.20 ms off k_bwd -- hence the 12 TB/s of `beta`).
+        // int32 accumulators: a K range of ceil(nst128 / ks) steps of 128 sequences contributes at most 128 (|one-hot
+        // value|) * 128 (|digit|: signed base-256 digits reach -128) per sequence, which must stay below 2^31 -- K ranges
+        // of at most 1023 steps (130 944 sequences).  More sequences than 16 such ranges simply get more ranges.
+        const int ks_min = std::max(1, (d.nst128 + 1022) / 1023);
+        const int ks_max = std::max(ks_min, std::max(1, std::min(16, d.nst128 / 8)));
+        if ((int64_t)((d.nst128 + ks_min - 1) / ks_min) * PLM_BWD_KSTEP * 128 * 128 >= ((int64_t)1 << 31))
+            return fail(PLM_EUNSUPPORTED, "%d sequences: no admissible K split of the backward GEMM", p.n_seqs);
         const double beta = (2.0 * d.nplanes * (double)d.nmf * d.nnfl * 1024.0 / 12e12) / ((double)d.nst128 * 1.3e-6);
         int best = ks_min;
         double best_cost = 1e300;
@@ -146,8 +166,7 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
         }
         d.ksplit = best;
         // measurement knob: force the K split of the backward GEMM (results are identical for every value)
-        if (const char *e = getenv("PLM_KSPLIT")) d.ksplit = std::max(ks_min, std::min(ks_max, atoi(e)));
-        (void)tiles;
+        if (opt.ksplit) d.ksplit = std::max(ks_min, std::min(ks_max, opt.ksplit));
     }
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
@@ -178,8 +197,51 @@ int make_dims(const plm_problem_t &p, PlmDims *out) {
 
 }  // namespace
 
+// Two-loop recursion of L-BFGS (Nocedal 1980) in coefficient space: with the Gram matrix of {s_j, y_j, g} the direction
+//     p = sum_j cs[j] s_j + D^-1 (sum_j cy[j] y_j + cg g)      (D^-1 = I without preconditioning)
+// needs no pass over the vectors.  The history is a ring of m physical slots; the LIVE pairs are the `stored` slots before
+// `end` in ring order (newest = end - 1).  That is not always the physical range 0..stored-1: when a noise-dominated pair
+// is skipped on a full ring (plm_ctx_optimize), the dead slot is `end` -- wherever the ring stands.  Inputs and outputs
+// are indexed by PHYSICAL slot: SY[i*m+j] = s_i.y_j, YDY[i*m+j] = y_i.D^-1 y_j, Sg[i] = s_i.g, YDg[i] = y_i.D^-1 g,
+// gDg = g.D^-1 g; cs / cy get zeros in dead slots; *dg = g.p.  Exported for the host-side test (tests/test_host_layer.py).
+extern "C" void plm_lbfgs_coefficients(int m, int stored, int end, const double *SY, const double *YDY, const double *Sg,
+                                       const double *YDg, double gDg, double *cs, double *cy, double *cg_out,
+                                       double *dg_out) {
+    std::vector<double> alpha(m, 0.0);
+    std::vector<int> live(stored);                       // newest first
+    for (int i = 0; i < stored; i++) live[i] = (end + m - 1 - i) % m;
+    for (int j = 0; j < m; j++) cs[j] = cy[j] = 0.0;
+    double cg = -1.0;
+    // first loop (newest -> oldest): q = cg g + sum cy y lives in the plain space, only s_i.q is needed (cs is still zero)
+    for (int i = 0; i < stored; i++) {
+        const int j = live[i];
+        double v = cg * Sg[j];
+        for (int k : live) v += cy[k] * SY[j * m + k];
+        alpha[j] = v / SY[j * m + j];
+        cy[j] -= alpha[j];
+    }
+    if (stored > 0) {
+        const int newest = live[0];
+        const double gamma = SY[newest * m + newest] / YDY[newest * m + newest];
+        cg *= gamma;
+        for (int k : live) cy[k] *= gamma;
+    }
+    // second loop (oldest -> newest): r = sum cs s + D^-1 (cg g + sum cy y)
+    for (int i = stored - 1; i >= 0; i--) {
+        const int j = live[i];
+        double v = cg * YDg[j];
+        for (int k : live) v += cs[k] * SY[k * m + j] + cy[k] * YDY[j * m + k];
+        cs[j] += alpha[j] - v / SY[j * m + j];
+    }
+    double dg = cg * gDg;
+    for (int k : live) dg += cs[k] * Sg[k] + cy[k] * YDg[k];
+    *cg_out = cg;
+    *dg_out = dg;
+}
+
 struct plm_ctx {
     plm_problem_t prob;
+    PlmOptions opt;            // environment knobs, read once at creation
     PlmDims d;
     int device = 0;
     hipStream_t st = nullptr;
@@ -215,12 +277,18 @@ struct plm_ctx {
     int hist_m = 0;
     double *h_scal = nullptr;  // pinned host scalars
     bool have_weights = false;
+    float wmax = 0;            // largest weight in use (scale of the fixed-point residuals)
     // (x, g) and these values belong together: set when an optimisation ends, cleared by everything that
     // changes x, the weights or the scratch use of g -- lets a follow-up plm_ctx_optimize (a resumed fit)
     // start from the known point instead of re-evaluating it
     bool eval_valid = false;
     double last_fx = 0, last_nll = 0, last_gh2 = 0;
     bool eval_vp = false;      // ... and g is the gradient of the reduced (variable-projection) objective
+    // Forward GEMM of the next evaluation: the plain instantiation (f32 accumulation over the whole K range) or the
+    // accurate one (f64 outer sums, ~1.5x the time).  plm_ctx_eval always asks for the accurate one; a fit switches to it
+    // for its last iterations (plm_ctx_optimize); PLM_FWD_ACCURATE = 0 | 1 forces one of them (measurements).
+    bool fwd_accurate = false;
+    bool eval_accurate = false;   // the valid (x, g, f) above came from the accurate instantiation
     double n_eff = 0;
     int n_evals = 0;
     std::vector<float> h_fi;   // L*q, kept for the start point
@@ -281,7 +349,7 @@ int vp_alloc(plm_ctx *c);
 int forward_at_x(plm_ctx *c) {
     const PlmDims &d = c->d;
     PLM_TRY(vp_alloc(c));
-    HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
+    HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->fwd_accurate, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
     HIP_TRY(plm_launch_hpass(d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr, c->st));
     return PLM_OK;
@@ -294,7 +362,7 @@ int ctx_eval_enqueue_sharded(plm_ctx *c) {
     HIP_TRY(plm_launch_pack_x(d, c->x, c->xsend, c->st));
     PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
     HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
-                               d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, c->st));
+                               d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, d.jexp_bias, c->st));
     HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
     PLM_TRY(forward_at_x(c));
     if (d.nblk_own > 0) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
@@ -375,13 +443,13 @@ int vp_stage1(plm_ctx *c) {
         HIP_TRY(plm_launch_pack_x(d, c->x, c->xsend, c->st));
         PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
         HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
-                                   d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, c->st));
+                                   d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, d.jexp_bias, c->st));
         HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
     } else {
         HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
         HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
     }
-    HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
+    HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->fwd_accurate, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
     return PLM_OK;
 }
@@ -450,7 +518,7 @@ int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
     double prev = INFINITY, gh2 = INFINITY;
     int newton = *newton_io, rounds = 0;
     bool rt_current = false;   // Rt / fx_part were written at the fields the solver stopped at
-    static const bool debug_vp = getenv("PLM_DEBUG_VP") != nullptr;   // read once per process
+    const bool debug_vp = c->opt.debug_vp;
     for (int round = 0;; round++) {
         // Hessians: refreshed when none exist, periodically, and whenever a round with the cached ones fell short
         const bool refresh = c->vp_hess_age < 0 ||
@@ -583,6 +651,7 @@ const char *status_text(int status) {
     switch (status) {
     case PLM_STATUS_CONVERGED: return "converged (|g|/max(1,|x|) below epsilon)";
     case PLM_STATUS_MAXITER: return "maximum number of iterations reached";
+    case PLM_STATUS_INTERRUPTED: return "interrupted by the caller";
     default: return "line search could not improve further (treated as converged to precision)";
     }
 }
@@ -659,8 +728,9 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     if (!prob || !out || !prob->msa) return fail(PLM_EINVAL, "NULL problem / msa / out");
     *out = nullptr;
     PLM_TRY(check_device(device));
+    const PlmOptions opt = plm_options_from_env();
     PlmDims d;
-    PLM_TRY(make_dims(*prob, &d));
+    PLM_TRY(make_dims(*prob, opt, &d));
     if (!(prob->theta_id >= 0.0 && prob->theta_id <= 1.0)) return fail(PLM_EINVAL, "theta_id must be in [0,1]");
     if (prob->lambda_h < 0 || prob->lambda_j < 0) return fail(PLM_EINVAL, "negative regularisation strength");
     for (size_t k = 0; k < (size_t)d.N * d.L; k++)
@@ -669,6 +739,7 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     plm_ctx *c = new plm_ctx();
     c->prob = *prob;
     c->prob.msa = nullptr;  // host pointer not retained
+    c->opt = opt;
     c->d = d;
     c->device = device;
     c->st = (hipStream_t)stream;
@@ -806,8 +877,32 @@ int plm_rccl_selftest(int device, void *stream) {
 int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, double epsilon, int32_t lbfgs_m) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (max_iter >= 0) c->prob.max_iter = max_iter;
-    if (epsilon >= 0) c->prob.epsilon = epsilon;
     if (lbfgs_m >= 0) c->prob.lbfgs_m = lbfgs_m;
+    if (epsilon >= 0) {
+        c->prob.epsilon = epsilon;
+        // The stop rule also selects the precision of the backward GEMM's residuals (24 bits above 1e-4, 32 bits below:
+        // the quantisation noise of three digit planes, ~5e-5 |x|, would make a tighter rule unreachable).  A context
+        // whose rule crosses that threshold gets the matching operand and slab buffers.
+        PlmDims d2;
+        PLM_TRY(make_dims(c->prob, c->opt, &d2));
+        if (d2.nplanes != c->d.nplanes) {
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamSynchronize(c->st));
+            c->d.nplanes = d2.nplanes;
+            c->d.ksplit = d2.ksplit;
+            if (c->Rt) (void)hipFree(c->Rt);
+            if (c->G) (void)hipFree(c->G);
+            c->Rt = nullptr;
+            c->G = nullptr;
+            PLM_TRY(dalloc((char **)&c->Rt, plm_rt_bytes(c->d)));
+            PLM_TRY(dalloc((char **)&c->G, plm_g_bytes(c->d)));
+            HIP_TRY(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(c->d), c->st));
+            const float qmax = c->d.nplanes == 4 ? PLM_R_QMAX4 : PLM_R_QMAX3, wmax = c->wmax > 0 ? c->wmax : 1.f;
+            c->d.rscale = qmax / wmax;
+            c->d.gscale = wmax / (qmax * (float)PLM_BWD_ONEHOT_VALUE);
+            c->eval_valid = false;
+        }
+    }
     return PLM_OK;
 }
 
@@ -833,6 +928,7 @@ int plm_ctx_set_weights(plm_ctx_t *c, const float *weights_host) {
     HIP_TRY(hipStreamSynchronize(c->st));
     c->n_eff = neff;
     c->have_weights = true;
+    c->wmax = wmax;
     c->eval_valid = false;
     // residual quantisation of the backward GEMM: |r_s(i,a)| <= w_s, so the largest weight maps to the largest
     // 24-bit magnitude whose three signed digits fit int8
@@ -979,6 +1075,7 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
     HIP_TRY(hipSetDevice(c->device));
+    c->fwd_accurate = c->opt.fwd_mode != 0;       // a single evaluation is asked for its value: the accurate forward GEMM
     PLM_TRY(ctx_eval_enqueue(c));
     if (c->d.sharded) PLM_TRY(ctx_allreduce_scalars(c, 0, 2));   // every shard must call eval together
     c->eval_valid = false;
@@ -988,6 +1085,7 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
         if (nll_out) *nll_out = c->h_scal[1];
         c->eval_valid = true;
         c->eval_vp = false;
+        c->eval_accurate = c->fwd_accurate;
         c->last_fx = c->h_scal[0];
         c->last_nll = c->h_scal[1];
     }
@@ -1057,7 +1155,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     // YDg = y_i.D^-1 g, gDg = g.D^-1 g, gg = g.g (stop rule)
     std::vector<double> SY(m * m, 0.0), YDY(m * m, 0.0), Sg(m, 0.0), YDg(m, 0.0);
     double gg = 0, gDg = 0, xx = 0, hh = 0;
-    std::vector<double> alpha(m), cs(m), cy(m);
+    std::vector<double> cs(m), cy(m);
     c->n_evals = 0;
     // device scalar slots; in sharded-state mode each fetch is preceded by a sum over the shards of
     // exactly the slots that were just written ([FX..DG] after an evaluation, [XX..MD+..] after the pass)
@@ -1070,51 +1168,21 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         return PLM_OK;
     };
     auto direction = [&](int stored, int end, double *dginit) -> int {
-        // p = sum cs[j] s_j + D^-1 (sum cy[j] y_j + cg g): two-loop recursion in coefficient space
-        std::fill(cs.begin(), cs.end(), 0.0);
-        std::fill(cy.begin(), cy.end(), 0.0);
-        double cg = -1.0;
-        // first loop: q = cg g + sum cy y lives in the plain space, only s_i.q is needed (cs is still zero)
-        auto s_dot_q = [&](int i) {
-            double v = cg * Sg[i];
-            for (int j = 0; j < stored; j++) v += cy[j] * SY[i * m + j];
-            return v;
-        };
-        // second loop: r = sum cs s + D^-1 (cg g + sum cy y)
-        auto y_dot_r = [&](int i) {
-            double v = cg * YDg[i];
-            for (int j = 0; j < stored; j++) v += cs[j] * SY[j * m + i] + cy[j] * YDY[i * m + j];
-            return v;
-        };
-        int j = end;
-        for (int i = 0; i < stored; i++) {
-            j = (j + m - 1) % m;
-            alpha[j] = s_dot_q(j) / SY[j * m + j];
-            cy[j] -= alpha[j];
-        }
-        if (stored > 0) {
-            const int newest = (end + m - 1) % m;
-            const double gamma = SY[newest * m + newest] / YDY[newest * m + newest];
-            cg *= gamma;
-            for (int i = 0; i < stored; i++) cy[i] *= gamma;
-        }
-        for (int i = 0; i < stored; i++) {
-            const double beta = y_dot_r(j) / SY[j * m + j];
-            cs[j] += alpha[j] - beta;
-            j = (j + 1) % m;
-        }
+        // p = sum cs[j] s_j + D^-1 (sum cy[j] y_j + cg g): two-loop recursion in coefficient space over the LIVE pairs,
+        // the `stored` ring slots before `end` (after a skipped pair on a full ring the dead slot is `end` itself, not
+        // the highest physical slot)
+        double cg;
+        plm_lbfgs_coefficients(m, stored, end, SY.data(), YDY.data(), Sg.data(), YDg.data(), gDg, cs.data(), cy.data(), &cg,
+                               dginit);
         PlmVecList B;
         PlmCoefList C;
         B.n = 0;
-        for (int i = 0; i < stored; i++) { B.v[B.n] = S + (size_t)i * n; C.c[B.n++] = (float)cs[i]; }
+        for (int i = 0; i < stored; i++) { const int j = (end + m - 1 - i) % m; B.v[B.n] = S + (size_t)j * n; C.c[B.n++] = (float)cs[j]; }
         const int first_weighted = B.n;
-        for (int i = 0; i < stored; i++) { B.v[B.n] = Y + (size_t)i * n; C.c[B.n++] = (float)cy[i]; }
+        for (int i = 0; i < stored; i++) { const int j = (end + m - 1 - i) % m; B.v[B.n] = Y + (size_t)j * n; C.c[B.n++] = (float)cy[j]; }
         B.v[B.n] = c->g;
         C.c[B.n++] = (float)cg;
         HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, dinv, first_weighted, c->st));
-        double dg = cg * gDg;
-        for (int i = 0; i < stored; i++) dg += cs[i] * Sg[i] + cy[i] * YDg[i];
-        *dginit = dg;
         return PLM_OK;
     };
 
@@ -1132,17 +1200,25 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     // it an evaluation only burns rounds until the stall test of ctx_eval_vp ends it.
     // (A tolerance relative to the current gradient of the couplings -- inexact field solves far from the optimum --
     // was measured: 0.3 % of |g| costs 15 % more iterations at the headline and stalls config 2 at |g|/|x| = 0.1.)
-    double vp_floor = 2e-7;
-    if (const char *e = getenv("PLM_VP_FLOOR")) vp_floor = atof(e);   // probes only
+    const double vp_floor = c->opt.vp_floor;   // 2e-7 unless a probe set PLM_VP_FLOOR
     auto vp_tol2 = [&](double xnorm2) {
         const double t = std::max(0.1 * eps * std::max(1.0, std::sqrt(xnorm2)),
                                   vp_floor * std::sqrt(c->n_eff * (double)d.L * d.Q));
         return t * t;
     };
+    // Forward-GEMM mode.  The plain instantiation's f32 accumulation leaves an error of ~3e-11 N L |x| in the gradient
+    // (4.5e-4 |x| at the headline, 1e-3 |x| at N = 100 000 -- the size of the default stop rule).
+    // Far from the optimum that is irrelevant; the last iterations run the accurate instantiation (f64 outer sums), so the
+    // stop rule is decided on a gradient whose error is several times smaller.  The switch happens at an accepted point,
+    // which is evaluated once more so that f, g, the pair of the step and the Gram rows all come from one arithmetic.
+    const double fwd_noise = 3e-11 * (double)d.N * (double)d.L;
+    const double acc_thr = std::max(5.0 * eps, 3.0 * fwd_noise);
+    auto want_accurate = [&](double cond) { return c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && cond < acc_thr); };
     // objective and gradient at the start point -- unless this context still holds them (a resumed fit)
     const bool resume = c->eval_valid && c->eval_vp == vp;
-    {
-        if (!resume) {
+    c->fwd_accurate = c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && resume && c->eval_accurate);
+    auto start_eval = [&](bool have) -> int {
+        if (!have) {
             if (!vp) PLM_TRY(ctx_eval_enqueue(c));
             else {
                 int first = 3;   // J = 0 typically: the start fields are near the independent-site optimum
@@ -1154,17 +1230,25 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         Bg.n = 2; Bg.v[0] = c->g; Bg.v[1] = c->g;
         HIP_TRY(plm_launch_multidot(Qg, Bg, n, c->dot_scratch, c->scal + SL_MD, dinv, 1u, 1ull, c->st));   // gDg, gg
         PLM_TRY(norm_dots());
-        PLM_TRY(ctx_allreduce_scalars(c, resume ? SL_DG : 0, (resume ? 8 - SL_DG : 8) + 2));
+        PLM_TRY(ctx_allreduce_scalars(c, have ? SL_DG : 0, (have ? 8 - SL_DG : 8) + 2));
         PLM_TRY(fetch_scalars(c, 0, 10));
         gDg = c->h_scal[SL_MD];
         gg = c->h_scal[SL_MD + 1];
         xx = c->h_scal[SL_XX];
         hh = c->h_scal[SL_HH];
-    }
+        return PLM_OK;
+    };
+    PLM_TRY(start_eval(resume));
     if (resume) gh2 = c->last_gh2;
     double fx = resume ? c->last_fx : c->h_scal[SL_FX], nll = resume ? c->last_nll : c->h_scal[SL_NLL];
     c->eval_valid = false;
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
+    if (!c->fwd_accurate && want_accurate(std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx)))) {
+        c->fwd_accurate = true;      // a start point this close to the optimum: its gradient decides the stop rule
+        PLM_TRY(start_eval(false));
+        fx = c->h_scal[SL_FX];
+        nll = c->h_scal[SL_NLL];
+    }
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
     // The next pair is (x - anchor, g - g(anchor)).  The anchor is the previous accepted point (xp, gp) -- unless the
     // pair(s) since were skipped as noise (below): then it stays where the last STORED pair ended, in its own buffers,
@@ -1198,11 +1282,29 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             B.v[B.n++] = c->g;
             B.v[B.n++] = c->g;                            // once more, unweighted: g.g for the stop rule
             const unsigned wq = 6u;                       // queries y_new and g
+            double gh2_trial = 0;
+            // objective + gradient at the trial point c->x, and with it everything the NEXT direction needs
+            auto evaluate_trial = [&]() -> int {
+                if (!vp) PLM_TRY(ctx_eval_enqueue(c));
+                else PLM_TRY(ctx_eval_vp(c, &vp_newton, vp_tol2(xx), &gh2_trial));
+                const float *a[1] = {c->g}, *b[1] = {c->dir};
+                PLM_TRY(dots(c, 1, a, b, n, SL_DG));
+                // Speculate that this trial point is accepted (it is, 97 % of the time): form its (s, y) pair
+                // in slot `end` -- the slot the next pair goes to anyway; a rejected trial is simply
+                // overwritten by the next one -- and run the Gram pass now, so that ONE host
+                // synchronisation (and, sharded, one all-reduce) per trial brings back f, the directional
+                // derivative and everything the next direction needs.
+                HIP_TRY(plm_launch_sy(s_new, y_new, c->x, anchored ? c->xa : c->xp, c->g, anchored ? c->ga : c->gp, n, c->st));
+                HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, dinv, wq, wb, c->st));
+                PLM_TRY(norm_dots());
+                PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
+                PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
+                return PLM_OK;
+            };
             int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
             double width = stpmax - stpmin, prev_width = 2.0 * width;
             double stx = 0, fxx = finit, dgx = dginit, sty = 0, fy = finit, dgy = dginit, stp = step, stmin, stmax;
             double trace[64][3];
-            double gh2_trial = 0;
             for (;;) {
                 if (brackt) { stmin = std::min(stx, sty); stmax = std::max(stx, sty); }
                 else { stmin = stx; stmax = stp + 4.0 * (stp - stx); }
@@ -1211,22 +1313,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     (brackt && stmax - stmin <= xtol * stmax))
                     stp = stx;
                 HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, (float)stp, c->dir, n, c->st));
-                if (!vp) PLM_TRY(ctx_eval_enqueue(c));
-                else PLM_TRY(ctx_eval_vp(c, &vp_newton, vp_tol2(xx), &gh2_trial));
-                {
-                    const float *a[1] = {c->g}, *b[1] = {c->dir};
-                    PLM_TRY(dots(c, 1, a, b, n, SL_DG));
-                    // Speculate that this trial point is accepted (it is, 97 % of the time): form its (s, y) pair
-                    // in slot `end` -- the slot the next pair goes to anyway; a rejected trial is simply
-                    // overwritten by the next one -- and run the Gram pass now, so that ONE host
-                    // synchronisation (and, sharded, one all-reduce) per trial brings back f, the directional
-                    // derivative and everything the next direction needs.
-                    HIP_TRY(plm_launch_sy(s_new, y_new, c->x, anchored ? c->xa : c->xp, c->g, anchored ? c->ga : c->gp, n, c->st));
-                    HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, dinv, wq, wb, c->st));
-                    PLM_TRY(norm_dots());
-                    PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
-                    PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
-                }
+                PLM_TRY(evaluate_trial());
                 double dg = c->h_scal[SL_DG];
                 fx = c->h_scal[SL_FX];
                 nll = c->h_scal[SL_NLL];
@@ -1278,7 +1365,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                     width = std::fabs(sty - stx);
                 }
             }
-            if (lsrc < 0 && getenv("PLM_DEBUG")) {
+            if (lsrc < 0 && c->opt.debug) {
                 fprintf(stderr, "[plm] line search failed at iteration %d: code %d, finit=%.6f dginit=%.6e step0=%.3e brackt=%d stx=%.6e sty=%.6e\n", k, -lsrc, finit, dginit, step, brackt, stx, sty);
                 for (int t = 0; t < count && t < 64; t++)
                     fprintf(stderr, "[plm]   trial %d: stp=%.9e  f-f0=%.6e  dg=%.6e\n", t, trace[t][0], trace[t][1], trace[t][2]);
@@ -1309,6 +1396,14 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             // the pair of the accepted point already sits in slot `end` and its Gram rows in h_scal (see above)
             const double *md = c->h_scal + SL_MD;
             const int nbv = B.n, e = end;
+            if (!c->fwd_accurate &&
+                want_accurate(std::sqrt(md[2 * nbv + 2 * nst + 1] + gh2_trial) / std::max(1.0, std::sqrt(c->h_scal[SL_XX])))) {
+                c->fwd_accurate = true;         // from here on: the accurate forward GEMM, starting with this very point
+                PLM_TRY(evaluate_trial());
+                fx = c->h_scal[SL_FX];
+                nll = c->h_scal[SL_NLL];
+                if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite after the switch of the forward GEMM");
+            }
             for (int j = 0; j < nst; j++) {
                 SY[e * m + j] = md[0 * nbv + nst + j];            // s_e . y_j
                 SY[j * m + e] = md[1 * nbv + j];                  // s_j . y_e
@@ -1322,10 +1417,13 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             hh = c->h_scal[SL_HH];
             gh2 = gh2_trial;
             const double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg + gh2);
-            if (cb)
-                cb(k, now_s() - t0, gnorm / std::max(1.0, xnorm), fx, nll, std::sqrt(hh),
-                   std::sqrt(std::max(0.0, xx - hh)), user);
             last_cond = gnorm / std::max(1.0, xnorm);
+            // a non-zero return cancels the fit (a pipeline's SIGTERM / SIGINT handler, evcouplings/utils/pipeline.py:476-545,
+            // raised inside a Python callback): the point reached so far stays in the context
+            if (cb && cb(k, now_s() - t0, last_cond, fx, nll, std::sqrt(hh), std::sqrt(std::max(0.0, xx - hh)), user) != 0) {
+                status = PLM_STATUS_INTERRUPTED;
+                break;
+            }
             if (last_cond <= eps) { status = PLM_STATUS_CONVERGED; break; }
             if (max_iter > 0 && k >= max_iter) { status = PLM_STATUS_MAXITER; break; }
             // Curvature pair of the accepted step (slot e).  s.y > 0 always holds under the Wolfe conditions -- for exact
@@ -1365,6 +1463,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     HIP_TRY(hipStreamSynchronize(c->st));
     c->eval_valid = true;   // every exit path above leaves the last accepted point in (x, g)
     c->eval_vp = vp;
+    c->eval_accurate = c->fwd_accurate;
     c->last_fx = fx;
     c->last_nll = nll;
     c->last_gh2 = gh2;
@@ -1380,7 +1479,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         if (status == PLM_STATUS_LINESEARCH)
             snprintf(res->status_msg, sizeof res->status_msg, "%s [code %d]; |g|/max(1,|x|) = %.3e", status_text(status),
                      ls_reason, last_cond);
-        else if (status == PLM_STATUS_MAXITER)
+        else if (status == PLM_STATUS_MAXITER || status == PLM_STATUS_INTERRUPTED)
             snprintf(res->status_msg, sizeof res->status_msg, "%s; |g|/max(1,|x|) = %.3e (epsilon %.1e)",
                      status_text(status), last_cond, eps);
         else
@@ -1441,6 +1540,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "kernel timing runs on 1-shard contexts");
     HIP_TRY(hipSetDevice(c->device));
     c->eval_valid = false;
+    c->fwd_accurate = false;   // the evaluation pipeline is timed with the plain forward GEMM (the accurate one separately)
     const PlmDims &d = c->d;
     struct Events {   // destroyed on every exit path (HIP_TRY returns early)
         hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1458,7 +1558,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
         HIP_TRY(hipEventRecord(ev[1], c->st));
         if (vp) {   // the fit's pipeline: forward GEMM -> HJ, 2 Newton steps on the fields, residual pass
-            HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->st));
+            HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, 0, c->st));
             HIP_TRY(hipEventRecord(ev[2], c->st));
             PLM_TRY(vp_stage2(c, 1, r == 0, false, true));   // one Newton step + the residual pass
             HIP_TRY(hipEventRecord(ev[5], c->st));
@@ -1481,6 +1581,15 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         HIP_TRY(hipEventElapsedTime(&ms, ev[5], ev[3])); acc[PLM_K_BACKWARD] += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); acc[PLM_K_ASSEMBLE] += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[4])); acc[PLM_K_TOTAL] += ms;
+    }
+    if (vp) {   // the accurate instantiation of the forward GEMM (last iterations of a fit, plm_eval)
+        float ms;
+        HIP_TRY(hipEventRecord(ev[0], c->st));
+        for (int r = 0; r < reps; r++) HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, 1, c->st));
+        HIP_TRY(hipEventRecord(ev[1], c->st));
+        HIP_TRY(hipEventSynchronize(ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        acc[PLM_K_FORWARD_ACCURATE] = ms;
     }
     {
         const int thresh = cluster_threshold(c->prob.theta_id, d.L, d.conv);
@@ -1523,7 +1632,7 @@ int plm_reweight_ex(const int8_t *msa, int32_t n_seqs, int32_t n_sites, double t
     p.flags = flags & (PLM_FLAG_IGNORE_GAPS | PLM_CONV_MASK);
     PLM_TRY(check_device(0));
     PlmDims d;
-    PLM_TRY(make_dims(p, &d));
+    PLM_TRY(make_dims(p, plm_options_from_env(), &d));
     const size_t rm_rows = (size_t)d.Np + 32;
     std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE);
     for (int s = 0; s < d.N; s++) memcpy(&rm[(size_t)s * d.Lp32], msa + (size_t)s * d.L, d.L);
@@ -1585,7 +1694,7 @@ int plm_scores_ex(const float *jij, int32_t n_sites, int32_t n_states, int32_t f
     plm_problem_t p = basic_problem(dummy.data(), 1, n_sites, plm_q_supported(n_states) ? n_states : 21);
     PLM_TRY(check_device(0));
     PlmDims d;
-    PLM_TRY(make_dims(p, &d));
+    PLM_TRY(make_dims(p, plm_options_from_env(), &d));
     d.Q = n_states;
     const size_t nj = (size_t)n_sites * (n_sites - 1) / 2 * n_states * n_states;
     float *dj = nullptr, *dfn = nullptr;
@@ -1623,7 +1732,7 @@ static int energies_impl(const int8_t *seqs, int32_t n, int32_t L, int32_t q, co
     PLM_TRY(check_device(device));
     plm_problem_t p = basic_problem(seqs, n, L, q);
     PlmDims d;
-    PLM_TRY(make_dims(p, &d));
+    PLM_TRY(make_dims(p, plm_options_from_env(), &d));
     if ((int64_t)(d.Np + 32) * d.Lp32 >= (int64_t)1 << 31) return fail(PLM_EINVAL, "too many sequences for one call");
     for (size_t k = 0; k < (size_t)n * L; k++)
         if (seqs[k] < 0 || seqs[k] >= q) return fail(PLM_EINVAL, "seqs[%zu] = %d outside 0..%d", k, (int)seqs[k], q - 1);

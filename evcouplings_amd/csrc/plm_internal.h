@@ -49,13 +49,9 @@
 // (J_ij(a, x_sj) - J_ij(a, 0)) -- the first sum is a constant per (i, a) (k_fwd_ref, added in k_fwd's epilogues), the
 // GEMM runs on the differences and on Q - 1 states: 20 = 5 groups of 4 for the protein alphabet, no padding.
 // A K step covers, for the 32 sites of a block u, one of 2 * NG instruction slices (NG = ceil((Q - 1) / 4) state
-// groups per site, 4 (site, group) pairs per lane and instruction) and one of the two f16 planes.  0 = the dense
-// v_mfma_f32_16x16x32_f16 formulation of rounds 1-2 (K step = 32 sites x one state, both planes).
-#ifndef PLM_SPARSE_FWD
-#define PLM_SPARSE_FWD 1
-#endif
+// groups per site, 4 (site, group) pairs per lane and instruction) and one of the two f16 planes.
 #define PLM_FWD_NG(Q) (((Q) + 2) / 4)
-#define PLM_FWD_SPU(Q) (PLM_SPARSE_FWD ? 4 * PLM_FWD_NG(Q) : (Q))   // K steps per 32-site block
+#define PLM_FWD_SPU(Q) (4 * PLM_FWD_NG(Q))   // K steps per 32-site block
 
 struct PlmDims {
     int N, L, Q;       // Q: alphabet size the kernels are instantiated for (4, 5, 20, 21) -- the native layout's stride
@@ -87,6 +83,7 @@ struct PlmDims {
     int64_t n_native;  // nh_pad + nbp*Q*Q*256
     int64_t n_canon;   // L*Q + L(L-1)/2*Q*Q
     int gap_mode;      // 1: state 0 (gap) excluded from the model (plmc -g)
+    int jexp_bias;     // measurement knob (PlmOptions::jexp_bias): added to the scale exponent of the forward operand
     int conv;          // PLM_CONV_* convention switches (include/plm_hip.h)
     double theta;      // identity threshold (PLM_CONV_G_UNGAPPED_LENGTH evaluates it per pair)
     // ---- sharded-state mode (PLM_FLAG_SHARDED_STATE): parameters, gradient and L-BFGS vectors are
@@ -103,6 +100,19 @@ struct PlmDims {
     int64_t nx_halo;   // coupling blocks received per evaluation: own_lo * nblk_own   (pairs (J'<own_lo, I own))
     int64_t ng_halo;   // gradient blocks received per evaluation: nblk_own * (nb16 - own_hi)
 };
+
+// Environment knobs of the library, read ONCE per context (plm_options_from_env, plm_host.cpp) -- nothing on the
+// evaluation path calls getenv.  All of them are measurement / debugging aids; the product behaviour is the default.
+struct PlmOptions {
+    int bwd_planes = 0;     // PLM_BWD_PLANES = 3 | 4: digit planes of the backward GEMM (0: chosen from epsilon)
+    int ksplit = 0;         // PLM_KSPLIT: K split of the backward GEMM (0: cost model); results are identical for every value
+    int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
+    int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the fast / the accurate forward GEMM (-1: the solver decides)
+    double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)
+    bool debug = false;     // PLM_DEBUG: line-search failures are traced to stderr
+    bool debug_vp = false;  // PLM_DEBUG_VP: every round of the field solver is traced to stderr
+};
+PlmOptions plm_options_from_env();
 
 // balanced partition of the nb16 column blocks over the shards (19 blocks on 8 GPUs: 3,3,3,2,2,2,2,2 -- no idle GPU)
 static inline __host__ __device__ int plm_shard_lo(const PlmDims &d, int r) {
@@ -137,8 +147,10 @@ hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, con
 hipError_t plm_launch_energy_sum(const PlmDims &d, const float *part, double *out, hipStream_t st);
 // ---- variable-projection fit (fields eliminated by an inner Newton solve) ------------
 // forward GEMM only: HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj) in accumulator order (plm_hj_bytes)
+// accurate: the instantiation with f64 outer sums; plm_fwd_groups = state groups per workgroup of it
 hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const int32_t *jexp,
-                                    float *hj, hipStream_t st);
+                                    float *hj, int accurate, hipStream_t st);
+int plm_fwd_groups(int q, int accurate);
 // one pass over HJ with the fields of x: per-workgroup per-site sums for the field solver (stats 1: gradient sums
 // into gpart (f64), 2: also Hessian sums -- exact diagonal, sampled off-diagonal -- into hpart (f32)) and, with write_rt, the residual fragments (Rt) and -log P partials
 // (fx_part) of the solver's forward epilogue.  skip (device int, may be NULL): non-zero = do nothing.
@@ -183,7 +195,7 @@ hipError_t plm_launch_assemble(const PlmDims &d, const void *G, int ks_count, co
 hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, hipStream_t st);
 hipError_t plm_launch_pack_g(const PlmDims &d, const int32_t *G, float *sendbuf, hipStream_t st);
 hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_t nb, uint32_t *maxbits,
-                              int32_t *jexp, hipStream_t st);
+                              int32_t *jexp, int jexp_bias, hipStream_t st);
 hipError_t plm_launch_finish_fx(const PlmDims &d, const double *fx_part, int n_fx_part,
                                 const double *shard_nll, int n_shard_nll, const double *reg_part,
                                 int n_reg_part, double *out2 /* fx, nll */, hipStream_t st);

@@ -7,7 +7,8 @@
 //   k_fwd        one-hot(MSA) x J on the 2:4 sparse MFMA (K ordered (site, state): 4 states of one site per group
 //                of 4 slots, state 0 as reference state) -> the coupling part of every conditional (HJ), stored for
 //                k_hpass; two more epilogues turn the same GEMM into statistical energies / potentials of sequences
-//                under a fitted model (row N2).  PLM_SPARSE_FWD=0 builds the dense formulation of rounds 1-2.
+//                under a fitted model (row N2); an ACCURATE instantiation (state groups per workgroup, f64 outer sums)
+//                serves the last evaluations of a fit and plm_eval.
 //   k_bwd        one-hot(MSA)^T x residuals on MFMA -> asymmetric gradient slab
 //   k_assemble   slab + slab^T + L2 term -> gradient, regulariser partial sums
 //   k_hpass      per-site softmax over HJ + fields -> residuals (the backward operand), -log P, and the gradient /
@@ -17,8 +18,9 @@
 //   k_align_rows / k_align_cols   gap counts and identities of the align stage (row N3)
 // plus small streaming kernels for L-BFGS (dots / linear combinations) and scoring.  Mean-field DCA
 // (covariance inverse, fields, direct information) lives in plm_meanfield.hip.
-// Compile-time experiment switches (all off / neutral in the product build; DESIGN.md 4.3 has the measurements):
-// PLM_PIPE, PLM_DMA_STAGGER_*, PLM_ASYNC_A, PLM_ABLATE, PLM_PROBE.
+// Compile-time experiment switches (neutral in the product build; DESIGN.md 4.3 has the measurements):
+// PLM_DMA_STAGGER_*, PLM_ASYNC_A, PLM_PROBE.  (The dense forward formulation, the three-buffer pipeline and the ablation
+// masks of rounds 1-3 are gone: git history and profiles/r0[1-3]_* hold what they measured.)
 //
 // The alignment is int8 in HBM; one-hot MFMA A fragments are expanded from 8 packed bytes
 // in registers (never materialised in memory); the dense operand (couplings / residuals)
@@ -29,6 +31,7 @@
 #include "plm_internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 #include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -38,22 +41,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
-// PLM_PIPE selects how the streamed B tiles of k_fwd / k_bwd are synchronised.
-//   1 (default): three LDS buffers, ONE barrier per K step placed in the middle of the step.  Passing the
-//      barrier of step t proves that tile t+1 has landed and that everybody is done with tile t-1, so the
-//      copy of tile t+2 starts there, and the wave runs from step t straight into step t+1: the first B
-//      fragments of t+1 are read from LDS while the last MFMAs of t are still issuing.  No pipeline drain
-//      at step boundaries.
-//   0: double buffer, barrier at the top of every step (every wave restarts its LDS reads behind it).
-#ifndef PLM_PIPE
-#define PLM_PIPE 0
-#endif
-// PLM_ABLATE bit mask for timing experiments with PLM_PIPE=0 (RESULTS INVALID): 1 no per-step vmcnt wait +
-// barrier, 2 no LDS-DMA in the K loop, 4 no LDS reads in the K loop (first fragments reused), 8 no one-hot
-// expansion (raw bytes as the A operand)
-#ifndef PLM_ABLATE
-#define PLM_ABLATE 0
-#endif
 // PLM_DMA_STAGGER_FWD / _BWD (sixteenths of a K step): waves 0-3 issue their LDS-DMA pieces at the start of
 // the step, waves 4-7 (the SIMD partners of 0-3) this far into it.  Issuing a piece blocks a wave for
 // ~100-200 cycles; when both waves of a SIMD do that at the same time the MFMA pipe idles, but pieces issued
@@ -64,7 +51,6 @@ typedef unsigned int u32;
 #ifndef PLM_DMA_STAGGER_BWD
 #define PLM_DMA_STAGGER_BWD 0
 #endif
-#define PLM_NBUF (PLM_PIPE ? 3 : 2)
 typedef unsigned long long u64;
 // PLM_ASYNC_A: the alignment bytes of the next K step are fetched by a load the compiler does not track.
 // hipcc cannot count the LDS-DMA pieces issued under branches after an ordinary load, so it waits
@@ -203,28 +189,31 @@ struct DmaPlan {
     const char *a_src = nullptr;   // wave-uniform base (nullptr: no such piece)
     u32 a_off = 0;                 // per-lane byte offset
     char *a_dst = nullptr;         // LDS destination (wave-uniform)
+    // k_fwd with state groups: a workgroup copies the fragments of ITS states only -- two runs of a tile (slots 0-7 and
+    // slots 8-15 of every state's fragment).  Pieces from `split` on lie `gap` bytes further in the source.
+    int split = 1 << 30;
+    int gap = 0;
 };
-template <int NP> __device__ __forceinline__ void dma_issue_all(const DmaPlan &P) {
+// NW = waves of the workgroup: wave w copies pieces w, w + NW, ...
+template <int NP, int NW = 8> __device__ __forceinline__ void dma_issue_all(const DmaPlan &P) {
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-        const int p = P.first + 8 * k;
+        const int p = P.first + NW * k;
         if (p < P.limit)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024 + P.lane_off), LDS_PTR(P.dst + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(P.src + p * 1024 + (p >= P.split ? P.gap : 0) + P.lane_off),
+                                             LDS_PTR(P.dst + p * 1024), 16, 0, 0);
     }
     if (P.a_src) __builtin_amdgcn_global_load_lds(GLB_PTR(P.a_src + P.a_off), LDS_PTR(P.a_dst), 16, 0, 0);
 }
-// the two issue slots of a step with NF fragments: S0 for the early waves, S1 for the late ones
-template <int NF, int A, int NP, int STG> __device__ __forceinline__ void dma_at(const DmaPlan &P) {
-    if constexpr ((PLM_ABLATE & 2) != 0) return;
-    constexpr int MID = (NF - 2) / 2;                       // PLM_PIPE: fragment behind whose first MFMAs the barrier sits
-    constexpr int S0 = PLM_PIPE ? MID : 0;
+// the two issue slots of a step with NF fragments: fragment 0 for the early waves, fragment NF * STG / 16 for the late ones
+template <int NF, int A, int NP, int STG, int NW = 8> __device__ __forceinline__ void dma_at(const DmaPlan &P) {
     constexpr int D = (NF * STG) / 16;
-    constexpr int S1 = (S0 + D < NF) ? S0 + D : NF - 1;
-    if constexpr (S0 == S1) {
-        if constexpr (A == S0) dma_issue_all<NP>(P);
+    constexpr int S1 = (D < NF) ? D : NF - 1;
+    if constexpr (S1 == 0) {
+        if constexpr (A == 0) dma_issue_all<NP, NW>(P);
     } else {
-        if constexpr (A == S0) { if (!P.late) dma_issue_all<NP>(P); }
-        if constexpr (A == S1) { if (P.late) dma_issue_all<NP>(P); }
+        if constexpr (A == 0) { if (!P.late) dma_issue_all<NP, NW>(P); }
+        if constexpr (A == S1) { if (P.late) dma_issue_all<NP, NW>(P); }
     }
 }
 
@@ -522,14 +511,10 @@ __global__ __launch_bounds__(256) void k_maxabs(const float *__restrict__ x, int
     for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down((int)m, o, 64));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
 }
-// PLM_JEXP_BIAS (environment, measurement knob): added to the scale exponent of the coupling operand.  A different
+// bias (PlmOptions::jexp_bias, measurement knob): added to the scale exponent of the coupling operand.  A different
 // power-of-two pre-scale moves every hi/lo split point and every f32 rounding of the forward GEMM without
 // changing the mathematics: the difference of two evaluations that differ only in it measures the rounding
 // noise of the forward pass (tests/probes/noise_probe.py).  Negative values are safe; positive ones overflow f16.
-static int plm_jexp_bias() {
-    const char *e = getenv("PLM_JEXP_BIAS");
-    return e ? atoi(e) : 0;
-}
 __global__ void k_scale_from_max(const u32 *maxbits, int32_t *jexp, int bias) {
     const float mx = __uint_as_float(*maxbits);
     int e = 0;
@@ -539,12 +524,12 @@ __global__ void k_scale_from_max(const u32 *maxbits, int32_t *jexp, int bias) {
     *jexp = (mx > 0.f) ? s : 0;
 }
 hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_t nb, u32 *maxbits, int32_t *jexp,
-                              hipStream_t st) {
+                              int jexp_bias, hipStream_t st) {
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(u32), st);
     if (e != hipSuccess) return e;
     if (na > 0) hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, a, na, maxbits);
     if (nb > 0) hipLaunchKernelGGL(k_maxabs, dim3(256), dim3(256), 0, st, b, nb, maxbits);
-    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, plm_jexp_bias());
+    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, jexp_bias);
     return hipGetLastError();
 }
 hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int32_t *jexp, hipStream_t st) {
@@ -552,7 +537,7 @@ hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int
     if (e != hipSuccess) return e;
     const int64_t n = d.n_local - d.nh_pad_l;
     hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, x + d.nh_pad_l, n, maxbits);
-    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, plm_jexp_bias());
+    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, d.jexp_bias);
     return hipGetLastError();
 }
 
@@ -577,8 +562,7 @@ __device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__
     if (ii > jj) return xj[((plm_bp_index(I, I, d.nb16) - d.bp_base) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
     return 0.f;
 }
-#if PLM_SPARSE_FWD
-// Sparse-MFMA layout (PLM_SPARSE_FWD, plm_internal.h).  One workgroup writes the two tiles (hi plane, lo plane) of an
+// Sparse-MFMA layout (plm_internal.h).  One workgroup writes the two tiles (hi plane, lo plane) of an
 // instruction slice ci of block u.  Tile = for every state a a dense B fragment of v_smfmac_f32_16x16x64_f16, 64
 // lanes x 16 halves, stored as two 1 KB halves: slots 0-7 of every lane at fragment a, slots 8-15 at fragment Q + a
 // (the two ds_read_b128 of k_fwd).  Which (site j, state b) a slot holds follows from the instruction's operand
@@ -640,197 +624,137 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
         }
     }
 }
-#else
-__global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restrict__ x,
-                                               const float *__restrict__ xhalo,
-                                               const int32_t *__restrict__ jexp, _Float16 *__restrict__ Bt) {
-    const int kstep = blockIdx.x, b16l = blockIdx.y, b16 = d.b16_lo + b16l;
-    const int u = kstep / d.Q, b = kstep % d.Q;
-    const float sc = ldexpf(1.f, *jexp);
-    const float *__restrict__ xj = x + d.nh_pad_l;
-    _Float16 *tile = Bt + ((size_t)b16l * d.nksteps + kstep) * (size_t)(2 * d.Q * 512);
-    for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
-        const int a = idx >> 6, lane = idx & 63, kg = lane >> 4, r = lane & 15;
-        const int i = b16 * 16 + r;
-        const int J = 2 * u + (kg >> 1);
-        half8 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int jj = 8 * (kg & 1) + perm8(e);
-            const int j = J * 16 + jj;
-            float v = 0.f;
-            if (i < d.L && j < d.L && i != j) v = sc * load_coupling(d, xj, xhalo, b16, r, a, J, jj, b);
-            const _Float16 h = (_Float16)v;
-            hi[e] = h;
-            lo[e] = (_Float16)(v - (float)h);
-        }
-        *(half8 *)(tile + (size_t)a * 512 + lane * 8) = hi;
-        *(half8 *)(tile + (size_t)(d.Q + a) * 512 + lane * 8) = lo;
-    }
-}
-#endif
 hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhalo, const int32_t *jexp, void *Bt,
                              hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_expand, dim3(PLM_SPARSE_FWD ? d.nksteps / 2 : d.nksteps, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
+    hipLaunchKernelGGL(k_expand, dim3(d.nksteps / 2, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
                        (_Float16 *)Bt);
-#if PLM_SPARSE_FWD
     hipLaunchKernelGGL(k_fwd_ref, dim3(d.b16_hi - d.b16_lo, 16, d.Q), dim3(64), 0, st, d, x, xhalo,
                        (float *)bt_cref32(d, Bt), (double *)bt_cref64(d, Bt));
-#endif
     return hipGetLastError();
 }
 
 // =========================================================================================
 // K_fwd: the coupling part of every conditional, HJ[s,(i,a)] = sum_{j != i} J_ij(a, x_sj)   (row a6, forward half)
-//   One-hot(MSA) x J as a GEMM on the 2:4 sparse f16 MFMA.  Workgroup = 256 sequences x one 16-site block (all Q
-//   states); 8 waves x 32 sequences.  K loop: one step = (32-site block u, instruction slice ci, plane hi / lo); A =
-//   compressed one-hot fragments built in registers from the packed alignment, B = Bt tile streamed global -> LDS by
-//   global_load_lds (double buffered, one barrier per step).  Accumulator fragment `a` of a wave holds HJ[s, i, a] for
-//   16 sites i (lane & 15) and 4 sequences per lane.  Epilogues (template parameter MODE): FWD_STORE writes HJ for
-//   k_hpass (the fit and plm_eval: softmax, residuals and the field solver live there -- the fused softmax epilogue of
-//   rounds 1-2 is gone), FWD_ENERGY / FWD_POTENTIALS serve the statistical energies of row N2.
+//   One-hot(MSA) x J as a GEMM on the 2:4 sparse f16 MFMA.  Workgroup = 256 sequences x one 16-site block x one GROUP
+//   of QG = Q / NSG states (NSG = 1: all states); 8 waves x 32 sequences.  K loop: one step = (32-site block u,
+//   instruction slice ci, plane hi / lo); A = compressed one-hot fragments built in registers from the packed
+//   alignment, B = the group's fragments of the Bt tile streamed global -> LDS by global_load_lds (double buffered, one
+//   barrier per step).  Accumulator fragment `a` of a wave holds HJ[s, i, a0 + a] for 16 sites i (lane & 15) and 4
+//   sequences per lane.  Epilogues (template parameter MODE): FWD_STORE writes HJ for k_hpass (the fit and plm_eval:
+//   softmax, residuals and the field solver live there), FWD_ENERGY / FWD_POTENTIALS serve the statistical energies of
+//   row N2.
+//   ACC = 1, the ACCURATE instantiation: the f32 accumulators of the matrix cores are flushed into f64
+//   sums every FLUSH K steps.  The rounding error of a potential then comes from FLUSH accumulation steps on a partial
+//   sum of a few sites instead of 20 nu steps on the running total -- ~sqrt(FLUSH / (20 nu)) of the plain kernel's, which
+//   is what limited the whole evaluation (|g_hip - g_f64| ~ 3e-11 N L |x|, at N = 100 000 as large as the stop rule).
+//   The f64 sums cost 2 registers per value; with QG = 7 states per workgroup (NSG = 3 at Q = 21) the kernel fits the
+//   256 registers of two waves per SIMD.  Used for the last iterations of a fit and by plm_eval (plm_host.cpp).
 // =========================================================================================
 struct FwdArgs {
     const int8_t *msa_rm;
-    const float *w;
     const char *Bt;
     const float *h;       // native vector (fields first)
     const int32_t *jexp;
-    _Float16 *Rt;
-    double *fx_part;
-    float rscale;
-    float *out;           // MODE 1: float2 [Np][blocks] energy partials; MODE 2: potentials [N][L][Q]
+    float *out;           // FWD_ENERGY: float2 [Np][blocks * NSG] energy partials; FWD_POTENTIALS: [N][L][Q]; FWD_STORE: HJ
 };
 // k_fwd MODE.  The GEMM yields HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj), the coupling part of every conditional:
 // 1 = statistical energies of sequences under a fitted model (reference twins
-//     couplings/model.py:25-60 _hamiltonians and :63-109 _single_mutant_hamiltonians): per (sequence, site block)
-//     the pair (sum_i HJ[s,i,x_si], sum_i h_i(x_si)); 2 = the potentials HJ[s,i,a] themselves;
+//     couplings/model.py:25-60 _hamiltonians and :63-109 _single_mutant_hamiltonians): per (sequence, site block, state
+//     group) the pair (sum_i HJ[s,i,x_si], sum_i h_i(x_si)) over the sites whose state lies in the group;
+// 2 = the potentials HJ[s,i,a] themselves;
 // 3 = HJ stored in accumulator order (float4 per lane and state) for k_hpass below: the solver's forward pass.
 enum { FWD_ENERGY = 1, FWD_POTENTIALS = 2, FWD_STORE = 3 };
 
-
-// one K step of the forward GEMM for one wave: Q states x (hi, lo) planes x 2 row fragments.
-// The B fragments of state A+2 are issued before state A computes.  The fragment registers form a ring of
-// R slots, R | Q, so that with PLM_PIPE the ring runs on across step boundaries: the reads for states 0, 1
-// of the NEXT step (LDS address lbn) are issued behind states Q-2, Q-1 of this one.
-template <int Q> struct FwdRing {
-    static constexpr int R = (Q % 3 == 0) ? 3 : (Q % 4 == 0) ? 4 : Q;
-};
-template <int Q, int A>
-__device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, int i0, int i1, u32 lb,
-                                          u32 lbn, half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
-                                          const DmaPlan &dma) {
-    constexpr int R = FwdRing<Q>::R, MID = (Q - 2) / 2, NP = (2 * Q + 7) / 8;
-    if constexpr ((PLM_ABLATE & 4) != 0) {
-        if constexpr (A == 0) { lds_wait<0>(bh[0], bl[0]); lds_wait<0>(bh[1], bl[1]); }
-        if constexpr (A + 2 < Q) { bh[(A + 2) % R] = bh[A % R]; bl[(A + 2) % R] = bl[A % R]; }
-    } else if constexpr (A + 2 < Q) {
-        bh[(A + 2) % R] = lds_read_b128<(A + 2) * 1024>(lb);
-        bl[(A + 2) % R] = lds_read_b128<(Q + A + 2) * 1024>(lb);
-    } else if constexpr (PLM_PIPE) {
-        bh[(A + 2) % R] = lds_read_b128<(A + 2 - Q) * 1024>(lbn);
-        bl[(A + 2) % R] = lds_read_b128<(A + 2) * 1024>(lbn);
+// one K step of the forward GEMM for one wave: QG states x 2 row fragments, each instruction on both 8-slot halves of
+// a state's dense fragment.  The B fragments of state A+2 are issued before state A computes (ring of 3 register
+// pairs; without it hipcc waits lgkmcnt(0) before every group of MFMAs: LDS latency x QG).
+template <int QG, int A>
+__device__ __forceinline__ void fwd_state(f32x4 (&acc)[2][QG], const half8 &a0, const half8 &a1, int i0, int i1, u32 lb,
+                                          half8 (&bh)[3], half8 (&bl)[3], const DmaPlan &dma) {
+    constexpr int NP = (2 * QG + 7) / 8;
+    if constexpr (A + 2 < QG) {
+        bh[(A + 2) % 3] = lds_read_b128<(A + 2) * 1024>(lb);
+        bl[(A + 2) % 3] = lds_read_b128<(QG + A + 2) * 1024>(lb);
     }
-    constexpr int newer = PLM_PIPE ? 4 : (A + 2 < Q) ? 4 : (A + 1 < Q) ? 2 : 0;
-    if constexpr ((PLM_ABLATE & 4) == 0) lds_wait<newer>(bh[A % R], bl[A % R]);
-#if PLM_SPARSE_FWD
+    constexpr int newer = (A + 2 < QG) ? 4 : (A + 1 < QG) ? 2 : 0;
+    lds_wait<newer>(bh[A % 3], bl[A % 3]);
     // the two LDS reads of the fragment are the two halves of one 16-half dense B operand; a0 / a1 are compressed
     // one-hot fragments (8 halves + 2-bit positions i0 / i1): one instruction per row fragment covers 64 dense K slots
-    const half16 bb = __builtin_shufflevector(bh[A % R], bl[A % R], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const half16 bb = __builtin_shufflevector(bh[A % 3], bl[A % 3], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     acc[0][A] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(a0, bb, acc[0][A], i0, 0, 0);
-    if constexpr (PLM_PIPE && A == MID) {
-        vm_wait<0>();
-        barrier_raw();
-    }
-    dma_at<Q, A, NP, PLM_DMA_STAGGER_FWD>(dma);
+    dma_at<QG, A, NP, PLM_DMA_STAGGER_FWD>(dma);
     acc[1][A] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(a1, bb, acc[1][A], i1, 0, 0);
-#else
-    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh[A % R], acc[0][A], 0, 0, 0);
-    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[A % R], acc[1][A], 0, 0, 0);
-    if constexpr (PLM_PIPE && A == MID) {
-        vm_wait<0>();       // my pieces of tile t+1 (issued one step ago) have landed ...
-        barrier_raw();      // ... and so have everybody's; nobody reads tile t-1 any more
-    }
-    dma_at<Q, A, NP, PLM_DMA_STAGGER_FWD>(dma);  // PLM_PIPE: tile t+2 -> the buffer of tile t-1; else tile t+1 -> the other buffer
-    acc[0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[A % R], acc[0][A], 0, 0, 0);
-    acc[1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[A % R], acc[1][A], 0, 0, 0);
-#endif
 }
-template <int Q, int... A>
-__device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][Q], const half8 &a0, const half8 &a1, int i0, int i1, u32 lb,
-                                          u32 lbn, half8 (&bh)[FwdRing<Q>::R], half8 (&bl)[FwdRing<Q>::R],
-                                          const DmaPlan &dma, std::integer_sequence<int, A...>) {
-    if constexpr (!PLM_PIPE) {
-        bh[0] = lds_read_b128<0>(lb);
-        bl[0] = lds_read_b128<Q * 1024>(lb);
+template <int QG, int... A>
+__device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][QG], const half8 &a0, const half8 &a1, int i0, int i1, u32 lb,
+                                          half8 (&bh)[3], half8 (&bl)[3], const DmaPlan &dma,
+                                          std::integer_sequence<int, A...>) {
+    bh[0] = lds_read_b128<0>(lb);
+    bl[0] = lds_read_b128<QG * 1024>(lb);
+    if constexpr (QG > 1) {
         bh[1] = lds_read_b128<1024>(lb);
-        bl[1] = lds_read_b128<(Q + 1) * 1024>(lb);
+        bl[1] = lds_read_b128<(QG + 1) * 1024>(lb);
     }
-    (fwd_state<Q, A>(acc, a0, a1, i0, i1, lb, lbn, bh, bl, dma), ...);
+    (fwd_state<QG, A>(acc, a0, a1, i0, i1, lb, bh, bl, dma), ...);
 }
 
-template <int Q, int MODE>
+template <int Q, int MODE, int NSG, int ACC>
 __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
+    static_assert(Q % NSG == 0, "state groups must divide the alphabet");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (guide 5/4a)
-    constexpr int TILE = 2 * Q * 1024, NBUF = PLM_NBUF, NP = (2 * Q + 7) / 8, R = FwdRing<Q>::R;
+    constexpr int QG = Q / NSG;                                   // states of this workgroup
+    constexpr int TILE_G = 2 * Q * 1024, TILE = 2 * QG * 1024, NP = (2 * QG + 7) / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to be wave-uniform
-    // XCD-aware order: block b runs on XCD b % 8, each XCD has its own L2.  The (site block, sequence tile) work
-    // list is site-block major; XCD x takes the contiguous eighth [x, x+1) * ntiles / 8 of it, so the ~32 blocks
-    // resident on an XCD stream the SAME Bt slab (9 MB at the headline) at about the same time and a slab is
-    // fetched from HBM by at most two XCDs instead of all eight.  Everything below indexes by `tile`.
-    const int ntiles = d.nstiles * (d.b16_hi - d.b16_lo), per_xcd = (ntiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
-    const int stile = tile % d.nstiles, b16l = tile / d.nstiles;
+    // XCD-aware order: block b runs on XCD b % 8, each XCD has its own L2.  The (site block, state group, sequence
+    // tile) work list is site-block major; XCD x takes the contiguous eighth [x, x+1) * nwork / 8 of it, so the ~32
+    // blocks resident on an XCD stream the SAME Bt slab (9 MB at the headline; a third of it per state group) at about
+    // the same time and a slab is fetched from HBM by at most two XCDs instead of all eight.
+    const int nwork = d.nstiles * (d.b16_hi - d.b16_lo) * NSG, per_xcd = (nwork + 7) >> 3;
+    const int wk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || wk >= nwork) return;
+    const int stile = wk % d.nstiles, sg = (wk / d.nstiles) % NSG, b16l = wk / (d.nstiles * NSG);
+    const int tile = b16l * d.nstiles + stile;            // (site block, sequence tile): the index HJ is laid out by
+    const int a_lo = sg * QG;                             // first state of the group
     const int b16 = d.b16_lo + b16l;
     const int r = lane & 15, g = lane >> 4;
     const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
-    const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE;
+    // a step's tile in Bt: [2 halves][Q states][1 KB]; the group's fragments are the runs [a_lo, a_lo + QG) of both halves
+    const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE_G + (size_t)a_lo * 1024;
     // A operand: byte offsets of the two sequences' rows in msa_rm (< 2^31: Np * Lp32 bytes)
     const u32 arow0 = (u32)(s_wave + r) * (u32)d.Lp32 + 8 * g, arow1 = arow0 + 16 * (u32)d.Lp32;
 
-    f32x4 acc[2][Q];
+    f32x4 acc[2][QG];
 #pragma unroll
-    for (int a = 0; a < Q; a++) {
+    for (int a = 0; a < QG; a++) {
         acc[0][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-#if PLM_SPARSE_FWD
+    // ACCURATE: f64 sums the f32 accumulators are flushed into
+    double sum64[ACC ? 2 : 1][ACC ? QG : 1][4];
+    if constexpr (ACC) {
+#pragma unroll
+        for (int a = 0; a < QG; a++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) sum64[0][a][e] = sum64[1][a][e] = 0.0;
+    }
     // steps of a 32-site block: 2 NG instruction slices x 2 planes; gap mode needs no special case (k_expand leaves
     // the slots of state 0 zero)
-    constexpr int NG = PLM_FWD_NG(Q), SPU = 4 * NG, gap = 0;
+    constexpr int NG = PLM_FWD_NG(Q), SPU = 4 * NG;
+    constexpr int FLUSH = (SPU % 5 == 0) ? 5 : 4;        // K steps between two flushes (divides SPU)
     const int nsteps = d.nu * SPU;
-#else
-    // gap mode: the K steps of state 0 are skipped altogether (gapped neighbours contribute nothing)
-    constexpr int SPU = Q;
-    const int gap = d.gap_mode, Qe = Q - gap, nsteps = d.nu * Qe;
-#endif
 #if PLM_PROBE
     unsigned long long pr_wait = 0;
     const unsigned long long pr_t0 = PROBE_NOW();
 #endif
-    // prologue: tiles of the first NBUF-1 steps; (un, bn) = (u, b) of the step whose tile is copied next
-    int un = 0, bn = gap;
-    for (int k = 0; k < NBUF - 1; k++) {
-        if (k < nsteps) {
-            const DmaPlan first{bt + (size_t)(un * SPU + bn) * TILE, smem + k * TILE, wave_s, 2 * Q, (u32)lane * 16, false};
-            dma_issue_all<NP>(first);
-        }
-        if (++bn == SPU) { bn = gap; ++un; }
+    // prologue: tile of the first step
+    if (nsteps > 0) {
+        const DmaPlan first{bt, smem, wave_s, 2 * QG, (u32)lane * 16, false, nullptr, 0, nullptr, QG, (Q - QG) * 1024};
+        dma_issue_all<NP>(first);
     }
     u64 na0 = *(const u64 *)(A.msa_rm + arow0), na1 = *(const u64 *)(A.msa_rm + arow1);   // bytes of the NEXT u
-    half8 bh[R], bl[R];
-    if constexpr (PLM_PIPE) {
-        vm_wait<0>();
-        __syncthreads();
-        const u32 l0 = lds_addr(smem + lane * 16);
-        bh[0] = lds_read_b128<0>(l0);
-        bl[0] = lds_read_b128<Q * 1024>(l0);
-        bh[1] = lds_read_b128<1024>(l0);
-        bl[1] = lds_read_b128<(Q + 1) * 1024>(l0);
-    }
+    half8 bh[3], bl[3];
     int t = 0, cur = 0;
     for (int u = 0; u < d.nu; ++u) {
         // hand over the 32 sites of this u (landed: a vmcnt(0) lies between the load and here),
@@ -842,25 +766,19 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             load_b64_inplace(na0, A.msa_rm, arow0 + 32 * (u + 1));
             load_b64_inplace(na1, A.msa_rm, arow1 + 32 * (u + 1));
         }
-        for (int b = gap; b < SPU; ++b, ++t) {
-            if constexpr (!PLM_PIPE) {
+        for (int b = 0; b < SPU; ++b, ++t) {
 #if PLM_PROBE
-                const unsigned long long pa = PROBE_NOW();
+            const unsigned long long pa = PROBE_NOW();
 #endif
-                if constexpr ((PLM_ABLATE & 1) == 0) {
-                    vm_wait<0>();
-                    __syncthreads();
-                }
+            vm_wait<0>();       // my pieces of this step's tile have landed ...
+            __syncthreads();    // ... and so have everybody's; nobody reads the other buffer any more
 #if PLM_PROBE
-                pr_wait += PROBE_NOW() - pa;
+            pr_wait += PROBE_NOW() - pa;
 #endif
-            }
-            const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
-            const int tgt = PLM_PIPE ? ((nxt + 1 == NBUF) ? 0 : nxt + 1) : nxt;   // buffer of step t + NBUF - 1
-            const DmaPlan dma{bt + (size_t)(un * SPU + bn) * TILE, smem + tgt * TILE, wave_s,
-                              (t + NBUF - 1 < nsteps) ? 2 * Q : 0, (u32)lane * 16, wave_s >= 4};
-            const u32 lb = lds_addr(smem + cur * TILE + lane * 16), lbn = lds_addr(smem + nxt * TILE + lane * 16);
-#if PLM_SPARSE_FWD
+            const int nxt = cur ^ 1;
+            const DmaPlan dma{bt + (size_t)(t + 1) * TILE_G, smem + nxt * TILE, wave_s, (t + 1 < nsteps) ? 2 * QG : 0,
+                              (u32)lane * 16, wave_s >= 4, nullptr, 0, nullptr, QG, (Q - QG) * 1024};
+            const u32 lb = lds_addr(smem + cur * TILE + lane * 16);
             // compressed one-hot fragments of instruction slice ci = b / 2 (the two planes of a slice share them):
             // pair p = (site s8, state group sg) of the lane's 8 sites; value 1 in the pair's first slot when the
             // site's state lies in the group, its 2-bit position = state % 4; the pair's second slot stays 0
@@ -870,101 +788,91 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 const int ci = b >> 1;
 #pragma unroll
                 for (int pp = 0; pp < 4; pp++) {
-                    const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl - s8 * NG;
+                    const int gl = 4 * ci + pp, s8 = gl / NG, kg = gl - s8 * NG;
                     const u32 x0 = (u32)(xa0 >> (8 * s8)) & 0xffu, x1 = (u32)(xa1 >> (8 * s8)) & 0xffu;
                     // state x > 0 sits in slot (x - 1); x = 0 (the reference state) wraps to a group that does not exist
-                    ((u32 *)&a0)[pp] = (((x0 - 1u) >> 2) == (u32)sg) ? 0x3C00u : 0u;
-                    ((u32 *)&a1)[pp] = (((x1 - 1u) >> 2) == (u32)sg) ? 0x3C00u : 0u;
+                    ((u32 *)&a0)[pp] = (((x0 - 1u) >> 2) == (u32)kg) ? 0x3C00u : 0u;
+                    ((u32 *)&a1)[pp] = (((x1 - 1u) >> 2) == (u32)kg) ? 0x3C00u : 0u;
                     i0 |= (int)(((x0 - 1u) & 3u) << (4 * pp));
                     i1 |= (int)(((x1 - 1u) & 3u) << (4 * pp));
                 }
             }
-#elif !(PLM_ABLATE & 8)
-            const int i0 = 0, i1 = 0;
-            const u32 bb = (u32)b * 0x01010101u;
-            const half8 a0 = onehot8((u32)xa0, (u32)(xa0 >> 32), bb);
-            const half8 a1 = onehot8((u32)xa1, (u32)(xa1 >> 32), bb);
-#else
-            const int i0 = 0, i1 = 0;
-            const u32 bb = (u32)b * 0x01010101u;
-            half8 a0, a1;
-            ((u32 *)&a0)[0] = (u32)xa0; ((u32 *)&a0)[1] = (u32)(xa0 >> 32); ((u32 *)&a0)[2] = bb; ((u32 *)&a0)[3] = (u32)xa1;
-            ((u32 *)&a1)[0] = (u32)xa1; ((u32 *)&a1)[1] = (u32)(xa1 >> 32); ((u32 *)&a1)[2] = bb; ((u32 *)&a1)[3] = (u32)xa0;
-#endif
-            // software pipeline: the B fragments of state a+2 are in flight while state a computes
-            // (without it hipcc waits lgkmcnt(0) before every group of 4 MFMAs: LDS latency x21)
-            fwd_kstep<Q>(acc, a0, a1, i0, i1, lb, lbn, bh, bl, dma, std::make_integer_sequence<int, Q>{});
+            fwd_kstep<QG>(acc, a0, a1, i0, i1, lb, bh, bl, dma, std::make_integer_sequence<int, QG>{});
+            if constexpr (ACC) {
+                if (b % FLUSH == FLUSH - 1) {
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+#pragma unroll
+                        for (int a = 0; a < QG; a++) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) sum64[m][a][e] += (double)acc[m][a][e];
+                            acc[m][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                }
+            }
             cur = nxt;
-            if (++bn == SPU) { bn = gap; ++un; }
         }
     }
-    if constexpr (PLM_PIPE) {   // the last step read two fragments past the end: let them land before the
-#pragma unroll                  // registers are reused
-        for (int k = 0; k < R; k++) lds_wait<0>(bh[k], bl[k]);
-    }
-#if PLM_PROBE
-    const unsigned long long pr_t1 = PROBE_NOW();
-#endif
 #if PLM_PROBE
     if (lane == 0) {
-        atomicAdd(&plm_probe_acc[0][0], pr_wait); atomicAdd(&plm_probe_acc[0][3], pr_t1 - pr_t0);
+        atomicAdd(&plm_probe_acc[0][0], pr_wait); atomicAdd(&plm_probe_acc[0][3], PROBE_NOW() - pr_t0);
         atomicAdd(&plm_probe_acc[0][5], 1ull);
     }
 #endif
-
-    // reference-state constants of the lane's site (sparse formulation; see plm_internal.h), zero otherwise
-#if PLM_SPARSE_FWD
-    const float *cref = (const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE) + ((size_t)b16l * 16 + r) * Q;
-#define PLM_CREF(a) cref[a]
-#else
-#define PLM_CREF(a) 0.f
-#endif
+    // descaled value of accumulator element (m, a, e): one rounding of the f64 sum in the accurate instantiation
+    const int je = *A.jexp;
+    const float sc = ldexpf(1.f, -je);
+    const double sc64 = ldexp(1.0, -je);
+    auto value = [&](int m, int a, int e) -> float {
+        if constexpr (ACC) return (float)(sum64[m][a][e] * sc64);
+        else return acc[m][a][e] * sc;
+    };
+    // reference-state constants of the lane's site (see plm_internal.h), state a_lo + a
+    const float *cref = (const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE_G) + ((size_t)b16l * 16 + r) * Q + a_lo;
     if constexpr (MODE == FWD_STORE) {
-        const float sc = ldexpf(1.f, -(*A.jexp));
         float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + wave) * 2 * Q * 64 + lane;
-#pragma unroll
         // the reference-state constant C_i(a) is NOT added here: rounded into these f32 values it would shift the
         // potentials of every sequence of a (site, state) by the same ~1e-7 |C| -- a coherent error that the gradient
         // sums add up N-fold (tests/probes/fwd_bias_probe.py).  k_hpass adds it in f64 together with the field.
-        for (int a = 0; a < Q; a++) {
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const f32x4 v = acc[m][a];
-                hj[(size_t)(m * Q + a) * 64] = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
-            }
+        for (int a = 0; a < QG; a++) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                hj[(size_t)(m * Q + a_lo + a) * 64] = make_float4(value(m, a, 0), value(m, a, 1), value(m, a, 2), value(m, a, 3));
         }
         return;
     }
     {
         // ---- statistical energies / potentials of the given sequences (no softmax) ------------
-        const float sc = ldexpf(1.f, -(*A.jexp));
         const int i = b16 * 16 + r;
         const bool site_ok = i < d.L;
         if constexpr (MODE == FWD_ENERGY) {
-            float hv[Q];
+            float hv[QG];
 #pragma unroll
-            for (int a = 0; a < Q; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a] : 0.f;
-            const int nblk = d.b16_hi - d.b16_lo;
+            for (int a = 0; a < QG; a++) hv[a] = site_ok ? A.h[(size_t)(i - d.h_site0) * Q + a_lo + a] : 0.f;
+            const int nslot = (d.b16_hi - d.b16_lo) * NSG;
 #pragma unroll
             for (int m = 0; m < 2; m++) {
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int s = s_wave + 16 * m + 4 * g + reg;
-                    const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
+                    const int xi = A.msa_rm[(size_t)s * d.Lp32 + i] - a_lo;
                     float ej = 0.f, eh = 0.f, ec = 0.f;
+                    bool mine = false;      // the site's state lies in this workgroup's group
 #pragma unroll
-                    for (int a = 0; a < Q; a++) {
-                        ej = (a == xi) ? acc[m][a][reg] : ej;
+                    for (int a = 0; a < QG; a++) {
+                        ej = (a == xi) ? value(m, a, reg) : ej;
                         eh = (a == xi) ? hv[a] : eh;
-                        ec = (a == xi) ? PLM_CREF(a) : ec;
+                        ec = (a == xi) ? cref[a] : ec;
+                        mine = mine || a == xi;
                     }
-                    ej = fmaf(ej, sc, ec);
+                    ej = mine ? ej + ec : 0.f;
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) {   // sum over the 16 sites of the block (lanes r)
                         ej += __shfl_xor(ej, o, 64);
                         eh += __shfl_xor(eh, o, 64);
                     }
-                    if (r == 0) *(float2 *)(A.out + ((size_t)s * nblk + b16l) * 2) = make_float2(ej, eh);
+                    if (r == 0) *(float2 *)(A.out + ((size_t)s * nslot + b16l * NSG + sg) * 2) = make_float2(ej, eh);
                 }
             }
         } else {
@@ -974,10 +882,10 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 for (int reg = 0; reg < 4; reg++) {
                     const int s = s_wave + 16 * m + 4 * g + reg;
                     if (site_ok && s < d.N) {
-                        float *o = A.out + ((size_t)s * d.L + i) * d.Qc;   // the API's array: the problem's alphabet
+                        float *o = A.out + ((size_t)s * d.L + i) * d.Qc + a_lo;   // the API's array: the problem's alphabet
 #pragma unroll
-                        for (int a = 0; a < Q; a++)
-                            if (a < d.Qc) o[a] = fmaf(acc[m][a][reg], sc, PLM_CREF(a));
+                        for (int a = 0; a < QG; a++)
+                            if (a_lo + a < d.Qc) o[a] = value(m, a, reg) + cref[a];
                     }
                 }
             }
@@ -986,54 +894,65 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     }
 }
 
-static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, hipStream_t st) {
+// dynamic LDS above 64 KB needs the attribute once per (kernel, device); std::call_once makes the latch safe when
+// several host threads create contexts at the same time (dist.ThreadedShards does exactly that)
+template <auto KERNEL> static hipError_t plm_allow_lds(size_t lds) {
+    static std::once_flag once[PLM_MAX_DEVICES];
+    static hipError_t result[PLM_MAX_DEVICES];
+    const int dev = plm_current_device();
+    std::call_once(once[dev], [&] {
+        result[dev] = lds > 65536 ? hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                  : hipSuccess;
+    });
+    return result[dev];
+}
+
+// state groups per workgroup of the forward GEMM: the plain instantiation takes all states of an alphabet that fits
+// its registers (2 x Q accumulator fragments per wave), the accurate one (f64 sums: 3 registers per value) 7 or fewer
+int plm_fwd_groups(int q, int accurate) {
+    if (!accurate) return 1;
+    return q == 21 ? 3 : q == 20 ? 4 : 1;
+}
+template <int Q, int MODE, int NSG, int ACC>
+static hipError_t fwd_launch(const PlmDims &d, const FwdArgs &A, hipStream_t st) {
+    const int nwork = d.nstiles * (d.b16_hi - d.b16_lo) * NSG;
+    const dim3 grid(8 * ((nwork + 7) / 8)), block(512);   // XCD-aware order, padded to 8
+    const size_t lds = (size_t)2 * 2 * (Q / NSG) * 1024;  // double buffer of the group's fragments
+    hipError_t e = plm_allow_lds<k_fwd<Q, MODE, NSG, ACC>>(lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_fwd<Q, MODE, NSG, ACC>), grid, block, lds, st, d, A);
+    return hipGetLastError();
+}
+static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, int accurate, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    const int ntiles = d.nstiles * (d.b16_hi - d.b16_lo);
-    const dim3 grid(8 * ((ntiles + 7) / 8)), block(512);   // XCD-aware order, padded to 8
-    const size_t lds = (size_t)PLM_NBUF * 2 * d.Q * 1024;
-#define FWD_LAUNCH(QQ, MM)                                                                             \
-    {                                                                                                  \
-        static bool attr_done_dev[PLM_MAX_DEVICES] = {false};   /* the attribute is per device */     \
-        bool &attr_done = attr_done_dev[plm_current_device()];                                         \
-        if (!attr_done) {                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void *)k_fwd<QQ, MM>,                            \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            if (e != hipSuccess) return e;                                                             \
-            attr_done = true;                                                                          \
-        }                                                                                              \
-        hipLaunchKernelGGL((k_fwd<QQ, MM>), grid, block, lds, st, d, A);                               \
-    }
-#define FWD_STORE_LAUNCH(QQ) FWD_LAUNCH(QQ, FWD_STORE)
-#define FWD_CASE(QQ)                                                                                   \
+#define FWD_CASE(QQ, NACC)                                                                             \
     case QQ:                                                                                           \
-        if (mode == FWD_ENERGY) FWD_LAUNCH(QQ, FWD_ENERGY)                                             \
-        else if (mode == FWD_STORE) FWD_STORE_LAUNCH(QQ)                                               \
-        else FWD_LAUNCH(QQ, FWD_POTENTIALS)                                                            \
-        break;
+        if (mode == FWD_ENERGY) return fwd_launch<QQ, FWD_ENERGY, 1, 0>(d, A, st);                     \
+        if (mode == FWD_POTENTIALS) return fwd_launch<QQ, FWD_POTENTIALS, 1, 0>(d, A, st);             \
+        if (accurate) return fwd_launch<QQ, FWD_STORE, NACC, 1>(d, A, st);                             \
+        return fwd_launch<QQ, FWD_STORE, 1, 0>(d, A, st);
     switch (d.Q) {
-        FWD_CASE(21)
-        FWD_CASE(20)
-        FWD_CASE(5)
-        FWD_CASE(4)
+        FWD_CASE(21, 3)
+        FWD_CASE(20, 4)
+        FWD_CASE(5, 1)
+        FWD_CASE(4, 1)
     default:
         return hipErrorInvalidValue;
     }
 #undef FWD_CASE
-#undef FWD_STORE_LAUNCH
-#undef FWD_LAUNCH
-    return hipGetLastError();
 }
 // statistical energies: mode 1 -> out = float2 [Np][blocks] partial sums, mode 2 -> out = potentials [N][L][Q]
 hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
                                      const int32_t *jexp, int potentials, float *out, hipStream_t st) {
-    const FwdArgs A{msa_rm, nullptr, (const char *)Bt, x, jexp, nullptr, nullptr, 0.f, out};
-    return launch_forward_mode(d, A, potentials ? FWD_POTENTIALS : FWD_ENERGY, st);
+    const FwdArgs A{msa_rm, (const char *)Bt, x, jexp, out};
+    return launch_forward_mode(d, A, potentials ? FWD_POTENTIALS : FWD_ENERGY, 0, st);
 }
-// variable-projection fit: the forward GEMM alone; HJ (descaled) goes to HBM in accumulator order
+// the forward GEMM alone; HJ (descaled) goes to HBM in accumulator order.  accurate: the instantiation with f64 outer
+// sums (the last iterations of a fit, plm_eval)
 hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const int32_t *jexp,
-                                    float *hj, hipStream_t st) {
-    const FwdArgs A{msa_rm, nullptr, (const char *)Bt, nullptr, jexp, nullptr, nullptr, 0.f, hj};
-    return launch_forward_mode(d, A, FWD_STORE, st);
+                                    float *hj, int accurate, hipStream_t st) {
+    const FwdArgs A{msa_rm, (const char *)Bt, nullptr, jexp, hj};
+    return launch_forward_mode(d, A, FWD_STORE, accurate, st);
 }
 size_t plm_hj_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 8 * 2 * d.Q * 1024; }
 
@@ -1312,19 +1231,15 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const void *Bt, c
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const int nb = d.b16_hi - d.b16_lo, ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
     const dim3 block(512);
-    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (PLM_SPARSE_FWD && Bt) ? bt_cref64(d, Bt) : nullptr, (char *)Rt, fx_part,
+    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, Bt ? bt_cref64(d, Bt) : nullptr, (char *)Rt, fx_part,
                 hpart, gpart, d.rscale, skip, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
         const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
         const size_t lds = (size_t)8 * 16 * ((QQ) * sizeof(double) + ((SS) == 2 ? (QQ) * ((QQ) + 1) / 2 : 0) * sizeof(float)); \
-        static bool attr_done_dev[PLM_MAX_DEVICES] = {false};                                          \
-        bool &attr_done = attr_done_dev[plm_current_device()];                                         \
-        if (!attr_done && lds > 65536) {                                                               \
-            hipError_t e = hipFuncSetAttribute((const void *)k_hpass<QQ, WW, SS>,                      \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        {                                                                                              \
+            hipError_t e = plm_allow_lds<k_hpass<QQ, WW, SS>>(lds);                                    \
             if (e != hipSuccess) return e;                                                             \
-            attr_done = true;                                                                          \
         }                                                                                              \
         hipLaunchKernelGGL((k_hpass<QQ, WW, SS>), grid, block, lds, st, d, A);                         \
     }
@@ -1693,10 +1608,8 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
 #if PLM_PROBE
         const unsigned long long pa = PROBE_NOW();
 #endif
-        if constexpr ((PLM_ABLATE & 1) == 0) {
-            vm_wait<0>();
-            __syncthreads();
-        }
+        vm_wait<0>();
+        __syncthreads();
 #if PLM_PROBE
         pr_wait += PROBE_NOW() - pa;
 #endif
@@ -1753,13 +1666,9 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
 #define BWD_CASE(QQ, M, N)                                                                             \
     case QQ: {                                                                                         \
         const size_t lds = (size_t)2 * (2 * N * 2 * 1024 + 4 * 2 * 1024);   /* two buffers: digit tile + alignment bytes */ \
-        static bool attr_done_dev[PLM_MAX_DEVICES] = {false};   /* the attribute is per device */     \
-        bool &attr_done = attr_done_dev[plm_current_device()];                                         \
-        if (!attr_done) {                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void *)k_bwd<QQ, M, N>,                          \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        {                                                                                              \
+            hipError_t e = plm_allow_lds<k_bwd<QQ, M, N>>(lds);                                        \
             if (e != hipSuccess) return e;                                                             \
-            attr_done = true;                                                                          \
         }                                                                                              \
         hipLaunchKernelGGL((k_bwd<QQ, M, N>), grid, block, lds, st, d, msa_cm, (const char *)Rt, (int *)G, run);   \
     } break;

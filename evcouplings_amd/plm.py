@@ -224,6 +224,34 @@ FLAG_PRECOND = 8
 FLAG_JOINT_LBFGS = 16
 
 
+class _IterationCallback:
+    """The plm_iter_cb of one fit: collects the iteration table, forwards to the user's callback, and turns an exception
+    raised while Python code runs inside the callback -- the user's own, or the SystemExit / KeyboardInterrupt of a signal
+    handler (evcouplings/utils/pipeline.py:476-545 installs handlers that call sys.exit; Python runs a pending handler
+    the next time the main thread executes bytecode, which during a fit is here) -- into a cancellation: the library
+    stops after this iteration (status "interrupted"), and `reraise()` raises the exception where the fit was called.
+    ctypes would otherwise print and swallow it, and the fit would run on."""
+
+    def __init__(self, callback=None):
+        self.table, self.callback, self.pending = [], callback, None
+        self.cfunc = _lib.ITER_CB(self._call)
+
+    def _call(self, it, secs, cond, fx, nll, nh, ne, user):
+        try:
+            self.table.append((it, secs, cond, fx, nll, nh, ne))
+            if self.callback is not None:
+                self.callback(it, secs, cond, fx, nll, nh, ne)
+            return 0
+        except BaseException as exc:      # incl. SystemExit / KeyboardInterrupt: never let one cross the C boundary
+            self.pending = exc
+            return 1
+
+    def reraise(self):
+        if self.pending is not None:
+            exc, self.pending = self.pending, None
+            raise exc
+
+
 def _wrap_collective(collective):
     """python callable(op, send_ptr, recv_ptr, send_counts, recv_counts, n_shards, shard) -> 0  =>  C callback"""
     def _cb(op, send, recv, scounts, rcounts, n, shard, user):
@@ -309,14 +337,8 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     res = PlmResult()
     for k in ("weights", "fi", "fij", "hi", "jij", "fn", "cn"):
         setattr(res, k, None if out[k] is None else out[k].ctypes.data)
-    table = []
-
-    def _cb(it, secs, cond, fx, nll, nh, ne, user):
-        table.append((it, secs, cond, fx, nll, nh, ne))
-        if callback is not None:
-            callback(it, secs, cond, fx, nll, nh, ne)
-
-    cb = _lib.ITER_CB(_cb)
+    icb = _IterationCallback(callback)
+    cb, table = icb.cfunc, icb.table
     if exchange is not None:
         xcb = _lib.EXCHANGE_CB(lambda buf, nbytes, ns, sh, user: int(exchange(buf, nbytes, ns, sh)))
     else:
@@ -335,6 +357,7 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     else:
         check(lib.plm_fit(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
                           None, xcb, None))
+    icb.reraise()      # an exception (or a signal handler's SystemExit) met inside the iteration callback
     if ignore_gaps:   # drop the (all-zero) entries of state 0
         out["fi"], out["hi"] = out["fi"][:, 1:].copy(), out["hi"][:, 1:].copy()
         out["jij"] = out["jij"][:, 1:, 1:].copy()
@@ -480,15 +503,10 @@ class PlmContext:
 
     def optimize(self, callback=None):
         res = PlmResult()
-        table = []
-
-        def _cb(it, secs, cond, fx, nll, nh, ne, user):
-            table.append((it, secs, cond, fx, nll, nh, ne))
-            if callback is not None:
-                callback(it, secs, cond, fx, nll, nh, ne)
-
-        cb = _lib.ITER_CB(_cb)
-        check(self.lib.plm_ctx_optimize(self._h, cb, None, C.byref(res)))
+        icb = _IterationCallback(callback)
+        table = icb.table
+        check(self.lib.plm_ctx_optimize(self._h, icb.cfunc, None, C.byref(res)))
+        icb.reraise()
         return dict(iters=int(res.iters_done), n_evals=int(res.n_evals), status=int(res.status),
                     status_msg=res.status_msg.decode("ascii", "replace"), fx=float(res.fx),
                     seconds=float(res.seconds_optimize), table=table)
@@ -502,5 +520,5 @@ class PlmContext:
     def time_kernels(self, reps=5):
         ms = np.zeros(_lib.K_COUNT, np.float32)
         check(self.lib.plm_ctx_time_kernels(self._h, int(reps), _ptr(ms)))
-        names = ["expand", "forward", "backward", "assemble", "total", "reweight", "fields"]
+        names = ["expand", "forward", "backward", "assemble", "total", "reweight", "fields", "forward_accurate"]
         return dict(zip(names, ms.tolist()))

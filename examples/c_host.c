@@ -16,10 +16,11 @@ static unsigned rnd(void) {   /* xorshift64 */
     return (unsigned)(rng_state >> 32);
 }
 
-static void on_iteration(int32_t iter, double secs, double cond, double fx, double nll, double norm_h, double norm_e,
+static int on_iteration(int32_t iter, double secs, double cond, double fx, double nll, double norm_h, double norm_e,
                          void *user) {
     (void)secs; (void)nll; (void)norm_h; (void)norm_e;
     if (iter % 10 == 0) fprintf((FILE *)user, "iter %d  fx %.4f  |g|/|x| %.3e\n", iter, fx, cond);
+    return 0;   /* non-zero would cancel the fit */
 }
 
 int main(void) {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PLM_ABI_VERSION 1
+#define PLM_ABI_VERSION 2   /* 2: plm_iter_cb returns int (cancellation), PLM_STATUS_INTERRUPTED, lambda_group */
 
 #define PLM_OK 0
 #define PLM_EINVAL (-1)      /* bad argument (NULL, size <= 0, state outside 0..q-1, ...) */
@@ -38,6 +38,7 @@ extern "C" {
 #define PLM_STATUS_CONVERGED 0
 #define PLM_STATUS_MAXITER 1
 #define PLM_STATUS_LINESEARCH 2
+#define PLM_STATUS_INTERRUPTED 3   /* the iteration callback asked to stop; the result holds the point reached so far */
 
 typedef struct plm_ctx plm_ctx_t;
 
@@ -111,9 +112,13 @@ typedef struct {
 #define PLM_CONV_MASK (32 | 64 | 128 | 256 | 512)
 
 /* Per-iteration progress: the 7 columns of plmc's stderr table that
- * parse_plmc_log() collects (tools.py:59-83): iter time cond fx -loglk ||h|| ||e||. */
-typedef void (*plm_iter_cb)(int32_t iter, double secs, double cond, double fx, double nll,
-                            double norm_h, double norm_e, void *user);
+ * parse_plmc_log() collects (tools.py:59-83): iter time cond fx -loglk ||h|| ||e||.
+ * Return 0 to go on; any other value cancels the fit after this iteration (status PLM_STATUS_INTERRUPTED, the result
+ * arrays hold the point reached).  This is how the signal handlers a pipeline installs around the stage
+ * (evcouplings/utils/pipeline.py:476-545: SIGTERM / SIGINT -> sys.exit) reach a running fit: the plmc child process
+ * was killed by the signal itself, an in-process solver has to be told. */
+typedef int (*plm_iter_cb)(int32_t iter, double secs, double cond, double fx, double nll,
+                           double norm_h, double norm_e, void *user);
 
 /* Exchange step of the site-sharded evaluation: every shard has
  * written `bytes_per_shard` bytes at  dev_buf + shard * bytes_per_shard ; on return the
@@ -292,8 +297,17 @@ int plm_ctx_scores(plm_ctx_t *ctx, float *fn_host, float *cn_host);
 #define PLM_K_TOTAL 4
 #define PLM_K_REWEIGHT 5
 #define PLM_K_FIELDS 6      /* variable-projection fit: Newton passes on the fields + residual pass (0 otherwise) */
-#define PLM_K_COUNT 7
+#define PLM_K_FORWARD_ACCURATE 7   /* the forward GEMM's accurate instantiation (f64 outer sums): last iterations, plm_eval */
+#define PLM_K_COUNT 8
 int plm_ctx_time_kernels(plm_ctx_t *ctx, int32_t reps, float *out_ms /* [PLM_K_COUNT] */);
+
+/* -- host arithmetic exposed for tests (no device) ------------------------------------------ */
+/* Two-loop recursion of L-BFGS in coefficient space over a ring of m history slots, of which the `stored` slots
+ * before `end` (ring order, newest = end - 1) are live: direction p = sum_j cs[j] s_j + D^-1 (sum_j cy[j] y_j + cg g).
+ * All arrays are indexed by PHYSICAL slot: SY[i*m+j] = s_i.y_j, YDY[i*m+j] = y_i.D^-1 y_j, Sg[i] = s_i.g,
+ * YDg[i] = y_i.D^-1 g, gDg = g.D^-1 g; *dg = g.p.  This is the code plm_ctx_optimize runs every iteration. */
+void plm_lbfgs_coefficients(int m, int stored, int end, const double *SY, const double *YDY, const double *Sg,
+                            const double *YDg, double gDg, double *cs, double *cy, double *cg, double *dg);
 
 #ifdef __cplusplus
 }

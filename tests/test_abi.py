@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_error_strings():
     lib = _lib.load()
-    assert lib.plm_version() == 1
+    assert lib.plm_version() == _lib.ABI_VERSION == 2
     assert lib.plm_strerror(0) == b"ok"
     assert b"argument" in lib.plm_strerror(-1)
 

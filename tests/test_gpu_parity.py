@@ -1073,3 +1073,115 @@ def test_alignment_stats_shapes(plm, n, L):
     assert none is None
     np.testing.assert_array_equal(g5, (m == 5).sum(1))
     np.testing.assert_array_equal(c5, (m == 5).sum(0))
+
+
+# ---------------------------------------------------------------- round 4: accurate forward GEMM, cancellation, re-planing
+@pytest.mark.parametrize("N,L,q,gaps", [(3000, 300, 21, False), (2000, 130, 21, True), (700, 70, 5, False),
+                                         (500, 50, 4, False), (900, 90, 13, False)])
+def test_accurate_and_plain_forward_gemm_agree_and_accurate_is_closer_to_f64(plm, oracle64, monkeypatch, N, L, q, gaps):
+    """The forward GEMM has two instantiations: the plain one (f32 accumulation over the whole K range)
+    and the accurate one (state groups per workgroup, f64 outer sums; plm_eval and the last iterations of a fit).  Same
+    mathematics, different rounding: they must agree to the plain kernel's accuracy, and against the f64 oracle the
+    accurate one must be the closer of the two.  PLM_FWD_ACCURATE is read once per context."""
+    msa, _ = synthetic_msa(N, L, seed=N + L, q=q)
+    qm = q - 1 if gaps else q
+    x = (0.08 * np.random.default_rng(L).normal(size=plm.n_params(L, qm))).astype(np.float32)
+    w = (1.0 / (oracle64.reweight_gaps if gaps else oracle64.reweight)(msa, 0.8)).astype(np.float32)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PLM_FWD_ACCURATE", mode)
+        with plm.PlmContext(msa, q=q, ignore_gaps=gaps, lambda_h=0.01, lambda_j=2.0) as ctx:
+            ctx.set_weights(w)
+            ctx.set_x(x)
+            got[mode] = ctx.eval() + (ctx.get_g(),)
+    monkeypatch.delenv("PLM_FWD_ACCURATE")
+    fo, nllo, go = (oracle64.eval_gaps if gaps else oracle64.eval)(msa, w.astype(np.float64), q, 0.01, 2.0, x.astype(np.float64))
+    scale = np.abs(go).max()
+    e_plain, e_acc = np.linalg.norm(got["0"][2] - go), np.linalg.norm(got["1"][2] - go)
+    print("N=%d L=%d q=%d gaps=%d: |g - g64| plain %.3e accurate %.3e (|g64| %.3e)" % (N, L, q, gaps, e_plain, e_acc, np.linalg.norm(go)))
+    np.testing.assert_allclose(got["1"][2], got["0"][2], atol=3e-6 * scale, rtol=0)
+    assert abs(got["1"][0] - fo) <= 1e-6 * abs(fo) and abs(got["0"][0] - fo) <= 1e-6 * abs(fo)
+    np.testing.assert_allclose(got["1"][2], go, atol=3e-6 * scale, rtol=0)
+    assert e_acc <= 1.05 * e_plain + 1e-9 * np.linalg.norm(go)
+
+
+def test_fit_switches_to_the_accurate_forward_gemm_and_reports_the_same_optimum(plm, monkeypatch):
+    """A fit runs the plain forward GEMM far from the optimum and the accurate one for its last iterations.  Forcing
+    either instantiation for the whole fit must end at the same CN scores (1e-4, the tolerance on EC scores)."""
+    msa, _ = synthetic_msa(6000, 120, seed=77)
+    cn = {}
+    for mode in (None, "0", "1"):
+        if mode is None:
+            monkeypatch.delenv("PLM_FWD_ACCURATE", raising=False)
+        else:
+            monkeypatch.setenv("PLM_FWD_ACCURATE", mode)
+        r = plm.fit(msa, q=Q, max_iter=0, epsilon=1e-3)
+        assert r["status"] == 0, r["status_msg"]
+        cn[mode] = r["cn"]
+    monkeypatch.delenv("PLM_FWD_ACCURATE")
+    assert np.abs(cn[None] - cn["1"]).max() < 1e-4 and np.abs(cn[None] - cn["0"]).max() < 1e-4
+
+
+def test_a_fit_is_cancelled_from_the_iteration_callback(plm):
+    """evcouplings/utils/pipeline.py:476-545: a SIGTERM / SIGINT handler calls sys.exit().  Raised inside the iteration
+    callback (the only Python code the main thread runs during a fit) it must stop the fit and surface where the fit was
+    called; the library reports status 'interrupted'."""
+    import signal
+    msa, _ = synthetic_msa(1500, 60, seed=11)
+
+    def handler(signum, frame):
+        raise SystemExit(3)
+
+    old = signal.signal(signal.SIGTERM, handler)
+    try:
+        seen = []
+
+        def cb(it, *rest):
+            seen.append(it)
+            if it == 5:
+                signal.raise_signal(signal.SIGTERM)
+
+        with pytest.raises(SystemExit):
+            plm.fit(msa, q=Q, max_iter=200, epsilon=1e-9, callback=cb)
+        assert seen == [1, 2, 3, 4, 5]
+        with plm.PlmContext(msa, Q, max_iter=200, epsilon=1e-9) as ctx:
+            ctx.reweight()
+            ctx.marginals(pairs=False)
+            ctx.set_x(None)
+            stop_at = {"n": 3}
+
+            class Halt(Exception):
+                pass
+
+            def cb2(it, *rest):
+                if it == stop_at["n"]:
+                    raise Halt()
+
+            with pytest.raises(Halt):
+                ctx.optimize(callback=cb2)
+            stop_at["n"] = 10 ** 9
+            ctx.set_options(max_iter=5)
+            res = ctx.optimize()                       # the context is still usable: resumes from the point reached
+            assert res["iters"] == 5 and res["status"] == 1
+    finally:
+        signal.signal(signal.SIGTERM, old)
+
+
+def test_stop_rule_below_1e4_rebuilds_the_backward_operand_with_four_digit_planes(plm, oracle64):
+    """the digit planes of the backward GEMM were chosen once, from the epsilon at context creation; a context
+    created at 1e-3 and later asked for 1e-5 must get the 32-bit residuals (else the quantisation floor, ~5e-5 |x|, makes
+    the rule unreachable)."""
+    msa, _ = synthetic_msa(900, 30, seed=21)
+    with plm.PlmContext(msa, Q, max_iter=0, epsilon=1e-3) as ctx:
+        ctx.reweight()
+        ctx.marginals(pairs=False)
+        ctx.set_x(None)
+        r1 = ctx.optimize()
+        assert r1["status"] == 0
+        ctx.set_options(epsilon=1e-5)
+        r2 = ctx.optimize()
+        assert r2["status"] == 0 and r2["table"][-1][2] < 1e-5, r2["status_msg"]
+        x = ctx.get_x()
+        w, _, _ = ctx.weights()
+    _, _, go = oracle64.eval(msa, w.astype(np.float64), Q, 0.01, plm.default_lambda_j(30, Q), x.astype(np.float64))
+    assert np.linalg.norm(go) / max(1.0, np.linalg.norm(x)) < 3e-5

@@ -298,3 +298,94 @@ def test_multi_gpu_launch_errors_stay_inside_the_error_conventions(tmp_path, mon
     with pytest.warns(UserWarning, match="running on one GPU"):
         with pytest.raises(tools.ExternalToolError):
             tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), focus_seq="SYN/1-16", iterations=3, gpus=2)
+
+
+# ---- L-BFGS two-loop recursion in coefficient space (plm_lbfgs_coefficients, the code plm_ctx_optimize runs) --------
+def _two_loop_dense(g, pairs, dinv=None):
+    """textbook two-loop recursion on explicit vectors; pairs = [(s, y)] oldest -> newest; H0 = gamma * diag(dinv)"""
+    dinv = np.ones_like(g) if dinv is None else dinv
+    q = g.copy()
+    alphas = []
+    for s, y in reversed(pairs):
+        a = s.dot(q) / s.dot(y)
+        alphas.append(a)
+        q -= a * y
+    if pairs:
+        s, y = pairs[-1]
+        q = q * dinv * (s.dot(y) / (y * dinv).dot(y))
+    else:
+        q = q * dinv
+    for (s, y), a in zip(pairs, reversed(alphas)):
+        b = y.dot(q) / s.dot(y)
+        q += (a - b) * s
+    return -q
+
+
+@pytest.mark.parametrize("m,stored,end,precond", [(6, 0, 0, False), (6, 3, 3, False), (6, 6, 2, False), (6, 5, 2, False),
+                                                  (6, 5, 5, True), (6, 5, 0, False), (4, 3, 1, True), (6, 2, 2, False)])
+def test_lbfgs_coefficients_follow_the_ring(m, stored, end, precond):
+    """after a noise-dominated pair is skipped on a full ring the live pairs are every slot except
+    `end`, not the physical slots 0..stored-1 -- the direction must be the L-BFGS direction of exactly the live pairs.
+    Case (6, 5, 2): ring full, pair in slot 2 skipped."""
+    import ctypes as C
+    from evcouplings_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(m * 100 + stored * 10 + end)
+    n = 40
+    A = rng.normal(size=(n, n))
+    H = A @ A.T + n * np.eye(n)                     # SPD: s.y > 0 for every pair
+    S = rng.normal(size=(m, n))
+    Y = S @ H
+    g = rng.normal(size=n)
+    dinv = 1.0 / np.diag(H) if precond else np.ones(n)
+    SY = S @ Y.T
+    YDY = (Y * dinv) @ Y.T
+    Sg, YDg, gDg = S @ g, (Y * dinv) @ g, (g * dinv).dot(g)
+    live_new_to_old = [(end - 1 - i) % m for i in range(stored)]
+    dead = [j for j in range(m) if j not in live_new_to_old]
+    for j in dead:                                  # dead slots hold garbage that must never be read
+        SY[j, :] = SY[:, j] = YDY[j, :] = YDY[:, j] = np.nan
+        Sg[j] = YDg[j] = np.nan
+    cs, cy = np.full(m, 7.0), np.full(m, 7.0)
+    cg, dg = C.c_double(0), C.c_double(0)
+    SYc, YDYc, Sgc, YDgc = [np.ascontiguousarray(a, dtype=np.float64) for a in (SY, YDY, Sg, YDg)]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.plm_lbfgs_coefficients(m, stored, end, p(SYc), p(YDYc), p(Sgc), p(YDgc), float(gDg), p(cs), p(cy),
+                               C.byref(cg), C.byref(dg))
+    assert np.all(cs[dead] == 0) and np.all(cy[dead] == 0)
+    live = live_new_to_old
+    direction = dinv * (cg.value * g) + sum(cs[j] * S[j] + dinv * (cy[j] * Y[j]) for j in live)
+    ref = _two_loop_dense(g, [(S[j], Y[j]) for j in reversed(live)], dinv if precond else None)
+    np.testing.assert_allclose(direction, ref, rtol=1e-9, atol=1e-12)
+    assert dg.value == pytest.approx(g.dot(ref), rel=1e-9)
+    assert dg.value < 0
+
+
+# ---- cancellation: an exception / a signal handler's SystemExit inside the iteration callback --------------------
+def test_iteration_callback_turns_exceptions_and_signals_into_a_cancellation():
+    """evcouplings/utils/pipeline.py:476-545 installs SIGTERM / SIGINT handlers that call sys.exit().  During a fit the
+    only Python code the main thread runs is the iteration callback, so the handler's SystemExit is raised there; ctypes
+    would swallow it.  The wrapper must hand the library a non-zero return (cancel) and re-raise afterwards."""
+    import signal
+    from evcouplings_amd import plm
+
+    def handler(signum, frame):
+        raise SystemExit(1)
+
+    old = signal.signal(signal.SIGTERM, handler)
+    try:
+        seen = []
+        icb = plm._IterationCallback(lambda it, *rest: (seen.append(it), signal.raise_signal(signal.SIGTERM) if it == 2 else None))
+        assert icb.cfunc(1, 0.1, 0.5, 10.0, 9.0, 1.0, 2.0, None) == 0
+        assert icb.pending is None
+        assert icb.cfunc(2, 0.2, 0.4, 9.0, 8.0, 1.0, 2.0, None) == 1          # -> PLM_STATUS_INTERRUPTED in the library
+        assert isinstance(icb.pending, SystemExit) and seen == [1, 2] and len(icb.table) == 2
+        with pytest.raises(SystemExit):
+            icb.reraise()
+        icb.reraise()                                                          # raised once
+        icb2 = plm._IterationCallback(lambda *a: 1 / 0)
+        assert icb2.cfunc(1, 0.1, 0.5, 10.0, 9.0, 1.0, 2.0, None) == 1
+        with pytest.raises(ZeroDivisionError):
+            icb2.reraise()
+    finally:
+        signal.signal(signal.SIGTERM, old)
