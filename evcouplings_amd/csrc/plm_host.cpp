@@ -100,6 +100,35 @@ PlmOptions plm_options_from_env() {
 }
 namespace {
 
+// K split of the backward GEMM for a given number of digit planes.  A launch has tiles * nplanes * ks workgroups (one
+// digit plane per workgroup), each over 1/ks of the K steps; with integer accumulation the split changes no result, only
+// the balance: the launch runs in ceil(tiles * nplanes * ks / 256) rounds of 1/ks of a full-K workgroup each (XCD
+// granularity makes it slightly worse), and every extra set of partial slabs costs k_assemble two more reads of it.
+// Cost in units of one full-K workgroup (a 128-sequence K step is ~1.3 us; the partial slabs reach k_assemble largely
+// through L2 / the 256 MB Infinity Cache -- measured at the headline: ks 1 -> 2 adds 0.11 ms to k_assemble for 0.98 GB
+// more reads and takes 0.20 ms off k_bwd -- hence the 12 TB/s of `beta`).
+int pick_ksplit(const PlmDims &d, const PlmOptions &opt, int nplanes, int *out) {
+    // int32 accumulators: a K range of ceil(nst128 / ks) steps of 128 sequences contributes at most 128 (|one-hot value|) *
+    // 128 (|digit|: signed base-256 digits reach -128) per sequence, which must stay below 2^31 -- K ranges of at most
+    // 1023 steps (130 944 sequences).  More sequences than 16 such ranges simply get more ranges.
+    const int ks_min = std::max(1, (d.nst128 + 1022) / 1023);
+    const int ks_max = std::max(ks_min, std::max(1, std::min(16, d.nst128 / 8)));
+    if ((int64_t)((d.nst128 + ks_min - 1) / ks_min) * PLM_BWD_KSTEP * 128 * 128 >= ((int64_t)1 << 31))
+        return fail(PLM_EUNSUPPORTED, "%d sequences: no admissible K split of the backward GEMM", d.N);
+    const double beta = (2.0 * nplanes * (double)d.nmf * d.nnfl * 1024.0 / 12e12) / ((double)d.nst128 * 1.3e-6);
+    int best = ks_min;
+    double best_cost = 1e300;
+    for (int ks = ks_min; ks <= ks_max; ks++) {
+        const int groups_per_xcd = (d.ncol_tiles * nplanes * ks + 7) / 8;     // busiest XCD
+        const double cost = (double)((groups_per_xcd * d.nrow_tiles + 31) / 32) / ks + beta * ks;
+        if (cost < best_cost * 0.98) { best_cost = cost; best = ks; }
+    }
+    // measurement knob: force the K split of the backward GEMM (results are identical for every value)
+    if (opt.ksplit) best = std::max(ks_min, std::min(ks_max, opt.ksplit));
+    *out = best;
+    return PLM_OK;
+}
+
 int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     PlmDims d;
     memset(&d, 0, sizeof d);
@@ -117,7 +146,7 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     d.Lp16 = d.nb16 * 16;
     d.nu = (d.L + 31) / 32;
     d.Lp32 = d.nu * 32;
-    d.nksteps = d.nu * PLM_FWD_SPU(d.Q);
+    d.nksteps = d.nu * PLM_FWD_TILES(d.Q);
     d.nssteps = d.Np / 32;
     d.nst128 = d.Np / PLM_BWD_KSTEP;
     // digit planes of the backward GEMM: 24-bit residuals by default, 32-bit for fits that must converge below 1e-4
@@ -141,33 +170,7 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     d.nnfl = d.blk_per_shard * d.Q;
     d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
     d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
-    {
-        // K split of the backward GEMM.  A launch has tiles * nplanes * ks workgroups (one digit plane per workgroup),
-        // each over 1/ks of the K steps; with integer accumulation the split changes no result, only the balance: the
-        // launch runs in ceil(tiles * 3 * ks / 256) rounds of 1/ks of a full-K workgroup each (XCD granularity makes
-        // it slightly worse), and every extra set of partial slabs costs k_assemble two more reads of it.
-        // Cost in units of one full-K workgroup (a 128-sequence K step is ~1.3 us; the partial slabs reach k_assemble
-        // largely through L2 / the 256 MB Infinity Cache -- measured at the headline: ks 1 -> 2 adds 0.11 ms to
-        // k_assemble for 0.98 GB more reads and takes 0.20 ms off k_bwd -- hence the 12 TB/s of `beta`).
-        // int32 accumulators: a K range of ceil(nst128 / ks) steps of 128 sequences contributes at most 128 (|one-hot
-        // value|) * 128 (|digit|: signed base-256 digits reach -128) per sequence, which must stay below 2^31 -- K ranges
-        // of at most 1023 steps (130 944 sequences).  More sequences than 16 such ranges simply get more ranges.
-        const int ks_min = std::max(1, (d.nst128 + 1022) / 1023);
-        const int ks_max = std::max(ks_min, std::max(1, std::min(16, d.nst128 / 8)));
-        if ((int64_t)((d.nst128 + ks_min - 1) / ks_min) * PLM_BWD_KSTEP * 128 * 128 >= ((int64_t)1 << 31))
-            return fail(PLM_EUNSUPPORTED, "%d sequences: no admissible K split of the backward GEMM", p.n_seqs);
-        const double beta = (2.0 * d.nplanes * (double)d.nmf * d.nnfl * 1024.0 / 12e12) / ((double)d.nst128 * 1.3e-6);
-        int best = ks_min;
-        double best_cost = 1e300;
-        for (int ks = ks_min; ks <= ks_max; ks++) {
-            const int groups_per_xcd = (d.ncol_tiles * d.nplanes * ks + 7) / 8;     // busiest XCD
-            const double cost = (double)((groups_per_xcd * d.nrow_tiles + 31) / 32) / ks + beta * ks;
-            if (cost < best_cost * 0.98) { best_cost = cost; best = ks; }
-        }
-        d.ksplit = best;
-        // measurement knob: force the K split of the backward GEMM (results are identical for every value)
-        if (opt.ksplit) d.ksplit = std::max(ks_min, std::min(ks_max, opt.ksplit));
-    }
+    PLM_TRY(pick_ksplit(d, opt, d.nplanes, &d.ksplit));
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;
     d.n_native = d.nh_pad + d.nbp * d.Q * d.Q * 256;
@@ -289,6 +292,10 @@ struct plm_ctx {
     // for its last iterations (plm_ctx_optimize); PLM_FWD_ACCURATE = 0 | 1 forces one of them (measurements).
     bool fwd_accurate = false;
     bool eval_accurate = false;   // the valid (x, g, f) above came from the accurate instantiation
+    // digit planes of the residuals: the plain evaluation runs planes_base (3, or 4 when the stop rule is below 1e-4),
+    // the accurate one always 4 (with three, residuals below 2^-24 of the largest weight round to zero -- for every such
+    // sequence alike: 1.7e-4 |x| at N = 100 000 against 0.5e-4 with four).  Rt and G are allocated for the larger.
+    int planes_base = 3, ksplit_base = 1, ksplit4 = 1;
     double n_eff = 0;
     int n_evals = 0;
     std::vector<float> h_fi;   // L*q, kept for the start point
@@ -297,6 +304,18 @@ struct plm_ctx {
 };
 
 namespace {
+
+// Precision of the next evaluations: plain (f16 forward GEMM, __expf, planes_base digit planes) or accurate (exact forward
+// GEMM, exact softmax arguments, four digit planes).  PLM_BWD_PLANES pins the plane count (measurements).
+void ctx_set_accurate(plm_ctx *c, bool on) {
+    c->fwd_accurate = on;
+    const int planes = c->opt.bwd_planes ? c->opt.bwd_planes : (on ? 4 : c->planes_base);
+    c->d.nplanes = planes;
+    c->d.ksplit = planes == 4 ? c->ksplit4 : c->ksplit_base;
+    const float qmax = planes == 4 ? PLM_R_QMAX4 : PLM_R_QMAX3, wmax = c->wmax > 0 ? c->wmax : 1.f;
+    c->d.rscale = qmax / wmax;
+    c->d.gscale = wmax / (qmax * (float)PLM_BWD_ONEHOT_VALUE);   // the one-hot operand of k_bwd carries -128
+}
 
 template <typename T> int dalloc(T **p, size_t n_elems) {
     void *q = nullptr;
@@ -351,7 +370,7 @@ int forward_at_x(plm_ctx *c) {
     PLM_TRY(vp_alloc(c));
     HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->fwd_accurate, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr, c->st));
     return PLM_OK;
 }
 
@@ -363,7 +382,7 @@ int ctx_eval_enqueue_sharded(plm_ctx *c) {
     PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
     HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
                                d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, d.jexp_bias, c->st));
-    HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
+    HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
     PLM_TRY(forward_at_x(c));
     if (d.nblk_own > 0) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
@@ -380,7 +399,7 @@ int ctx_eval_enqueue(plm_ctx *c) {
     const PlmDims &d = c->d;
     if (d.sharded) return ctx_eval_enqueue_sharded(c);
     HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
-    HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
+    HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
     PLM_TRY(forward_at_x(c));
     HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     const void *Gsrc = c->G;
@@ -444,10 +463,10 @@ int vp_stage1(plm_ctx *c) {
         PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
         HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
                                    d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, d.jexp_bias, c->st));
-        HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->st));
+        HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
     } else {
         HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
-        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
+        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
     }
     HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->fwd_accurate, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
@@ -472,7 +491,7 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse, bool write_rt) {
     for (int it = 0; it < newton; it++) {
         const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
         if (full || !(it == 0 && reuse))
-            HIP_TRY(plm_launch_hpass(d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, nullptr, nullptr, c->hpart,
+            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, c->fwd_accurate, nullptr, nullptr, c->hpart,
                                      c->gpart, nullptr, c->st));
         HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
                                   c->vp_flag, c->st));
@@ -482,15 +501,18 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse, bool write_rt) {
     // the pass at the result: gradient sums for the convergence check (and for the next round's first step); with
     // write_rt also the residual fragments and -log P partials -- 1.29 GB of writes that only the LAST round's pass
     // needs to make (ctx_eval_vp decides which rounds write speculatively)
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, write_rt ? 1 : 0, 1, write_rt ? c->Rt : nullptr,
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, write_rt ? 1 : 0, 1, c->fwd_accurate, write_rt ? c->Rt : nullptr,
                              write_rt ? c->fx_part : nullptr, c->hpart, c->gpart, nullptr, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
                               c->vp_flag, c->st));
     return PLM_OK;
 }
 // stage 3: backward GEMM, gradient of the reduced objective, objective value
-int vp_stage3(plm_ctx *c, bool conditional) {
+// gout / mode: where the gradient goes and which one -- mode 2 into c->g for the fit (reduced objective: field part
+// zero), mode 0 into a scratch vector for the certificate of the shipped point (joint gradient, fields included)
+int vp_stage3(plm_ctx *c, bool conditional, float *gout = nullptr, int mode = 2) {
     const PlmDims &d = c->d;
+    if (!gout) gout = c->g;
     // conditional: the backward GEMM runs only if the chain in front of it converged -- the host sees the same
     // gradient norm and repeats stage 3 after finishing the fields.  Not when sharded: a shard judges its own sites
     // only, the host the all-reduced norm, and the two can disagree.
@@ -501,10 +523,11 @@ int vp_stage3(plm_ctx *c, bool conditional) {
         PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
     }
     // mode 2: gradient of the reduced objective (field part zero), regulariser sums as usual
-    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, d.sharded ? c->ghalo : nullptr, c->x, c->g, c->prob.lambda_h,
-                                c->prob.lambda_j, c->reg_part, 2, 0.f, c->st));
-    HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d), c->scal,
-                                 c->st));
+    HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, d.sharded ? c->ghalo : nullptr, c->x, gout, c->prob.lambda_h,
+                                c->prob.lambda_j, c->reg_part, mode, 0.f, c->st));
+    if (mode == 2)
+        HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d), c->scal,
+                                     c->st));
     return PLM_OK;
 }
 // the whole evaluation: the field solver iterates until the subproblem gradient is below tol2 (or stalls at its
@@ -546,7 +569,7 @@ int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
         newton = 2;
     }
     if (!rt_current)   // the last round ended on a statistics-only pass: residual fragments and -log P at its fields
-        HIP_TRY(plm_launch_hpass(c->d, c->hj, c->Bt, c->msa_rm, c->w, c->h64, 1, 0, c->Rt, c->fx_part, nullptr, nullptr, nullptr,
+        HIP_TRY(plm_launch_hpass(c->d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr,
                                  c->st));
     // steps to try first at the next trial point: one more if this one needed extra rounds, one fewer (down to
     // none: the L-BFGS extrapolation of the fields is then good enough) if it met the tolerance with room to spare
@@ -741,6 +764,18 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     c->prob.msa = nullptr;  // host pointer not retained
     c->opt = opt;
     c->d = d;
+    c->planes_base = d.nplanes;
+    c->ksplit_base = d.ksplit;
+    {
+        int ks4 = 1;
+        const int rc4 = pick_ksplit(d, opt, 4, &ks4);
+        if (rc4 != PLM_OK) { delete c; return rc4; }
+        c->ksplit4 = ks4;
+    }
+    // Rt and G for the larger of the two precisions (accurate evaluations run four digit planes)
+    PlmDims dmax = d;
+    dmax.nplanes = opt.bwd_planes ? opt.bwd_planes : 4;
+    dmax.ksplit = std::max(c->ksplit_base, c->ksplit4);
     c->device = device;
     c->st = (hipStream_t)stream;
     int rc = PLM_OK;
@@ -759,8 +794,8 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     }
     if ((rc = dalloc(&c->msa_rm, rm.size())) || (rc = dalloc(&c->msa_cm, cm.size())) ||
         (rc = dalloc(&c->w, (size_t)d.Np)) || (rc = dalloc(&c->counts, (size_t)d.Np)) ||
-        (rc = dalloc((char **)&c->Bt, plm_bt_bytes(d))) || (rc = dalloc((char **)&c->Rt, plm_rt_bytes(d))) ||
-        (rc = dalloc((char **)&c->G, plm_g_bytes(d))) || (rc = dalloc(&c->fx_part, (size_t)c->n_fx_part())) ||
+        (rc = dalloc((char **)&c->Bt, plm_bt_bytes(d))) || (rc = dalloc((char **)&c->Rt, plm_rt_bytes(dmax))) ||
+        (rc = dalloc((char **)&c->G, plm_g_bytes(dmax))) || (rc = dalloc(&c->fx_part, (size_t)c->n_fx_part())) ||
         (rc = dalloc(&c->reg_part, (size_t)plm_reg_parts(d))) ||
         (rc = dalloc(&c->dot_scratch, (size_t)4 * PLM_MAX_BASIS * PLM_DOT_BLOCKS)) ||
         (rc = dalloc(&c->scal, (size_t)256)) ||
@@ -795,7 +830,7 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     CT(hipMemcpyAsync(c->msa_rm, rm.data(), rm.size(), hipMemcpyHostToDevice, c->st));
     CT(hipMemcpyAsync(c->msa_cm, cm.data(), cm.size(), hipMemcpyHostToDevice, c->st));
     CT(hipMemsetAsync(c->w, 0, sizeof(float) * d.Np, c->st));
-    CT(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(d), c->st));
+    CT(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(dmax), c->st));
     CT(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_local, c->st));
     CT(hipMemsetAsync(c->g, 0, sizeof(float) * d.n_local, c->st));
     CT(hipMemsetAsync(c->scal, 0, sizeof(double) * 256, c->st));   // slots nobody writes still travel in all-reduces
@@ -880,26 +915,15 @@ int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, double epsilon, int32_t 
     if (lbfgs_m >= 0) c->prob.lbfgs_m = lbfgs_m;
     if (epsilon >= 0) {
         c->prob.epsilon = epsilon;
-        // The stop rule also selects the precision of the backward GEMM's residuals (24 bits above 1e-4, 32 bits below:
-        // the quantisation noise of three digit planes, ~5e-5 |x|, would make a tighter rule unreachable).  A context
-        // whose rule crosses that threshold gets the matching operand and slab buffers.
+        // The stop rule also selects the precision of the plain evaluation's residuals (24 bits above 1e-4, 32 bits
+        // below: the quantisation noise of three digit planes, ~5e-5 |x|, would make a tighter rule unreachable); the
+        // buffers hold four planes in any case.
         PlmDims d2;
         PLM_TRY(make_dims(c->prob, c->opt, &d2));
-        if (d2.nplanes != c->d.nplanes) {
-            HIP_TRY(hipSetDevice(c->device));
-            HIP_TRY(hipStreamSynchronize(c->st));
-            c->d.nplanes = d2.nplanes;
-            c->d.ksplit = d2.ksplit;
-            if (c->Rt) (void)hipFree(c->Rt);
-            if (c->G) (void)hipFree(c->G);
-            c->Rt = nullptr;
-            c->G = nullptr;
-            PLM_TRY(dalloc((char **)&c->Rt, plm_rt_bytes(c->d)));
-            PLM_TRY(dalloc((char **)&c->G, plm_g_bytes(c->d)));
-            HIP_TRY(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(c->d), c->st));
-            const float qmax = c->d.nplanes == 4 ? PLM_R_QMAX4 : PLM_R_QMAX3, wmax = c->wmax > 0 ? c->wmax : 1.f;
-            c->d.rscale = qmax / wmax;
-            c->d.gscale = wmax / (qmax * (float)PLM_BWD_ONEHOT_VALUE);
+        if (d2.nplanes != c->planes_base) {
+            c->planes_base = d2.nplanes;
+            c->ksplit_base = d2.ksplit;
+            ctx_set_accurate(c, c->fwd_accurate);
             c->eval_valid = false;
         }
     }
@@ -931,10 +955,8 @@ int plm_ctx_set_weights(plm_ctx_t *c, const float *weights_host) {
     c->wmax = wmax;
     c->eval_valid = false;
     // residual quantisation of the backward GEMM: |r_s(i,a)| <= w_s, so the largest weight maps to the largest
-    // 24-bit magnitude whose three signed digits fit int8
-    const float qmax = c->d.nplanes == 4 ? PLM_R_QMAX4 : PLM_R_QMAX3;
-    c->d.rscale = qmax / wmax;
-    c->d.gscale = wmax / (qmax * (float)PLM_BWD_ONEHOT_VALUE);   // the one-hot operand of k_bwd carries -128
+    // magnitude whose signed digits fit int8
+    ctx_set_accurate(c, c->fwd_accurate);
     return PLM_OK;
 }
 
@@ -1075,7 +1097,7 @@ int plm_ctx_eval(plm_ctx_t *c, double *fx_out, double *nll_out) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
     HIP_TRY(hipSetDevice(c->device));
-    c->fwd_accurate = c->opt.fwd_mode != 0;       // a single evaluation is asked for its value: the accurate forward GEMM
+    ctx_set_accurate(c, c->opt.fwd_mode != 0);    // a single evaluation is asked for its value: the accurate arithmetic
     PLM_TRY(ctx_eval_enqueue(c));
     if (c->d.sharded) PLM_TRY(ctx_allreduce_scalars(c, 0, 2));   // every shard must call eval together
     c->eval_valid = false;
@@ -1212,11 +1234,14 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     // stop rule is decided on a gradient whose error is several times smaller.  The switch happens at an accepted point,
     // which is evaluated once more so that f, g, the pair of the step and the Gram rows all come from one arithmetic.
     const double fwd_noise = 3e-11 * (double)d.N * (double)d.L;
-    const double acc_thr = std::max(5.0 * eps, 3.0 * fwd_noise);
-    auto want_accurate = [&](double cond) { return c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && cond < acc_thr); };
+    const double acc_thr = std::max(3.0 * eps, 8.0 * fwd_noise);
+    // (a problem whose plain-kernel error is below a twentieth of the stop rule never needs the switch)
+    auto want_accurate = [&](double cond) {
+        return c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && fwd_noise > 0.05 * eps && cond < acc_thr);
+    };
     // objective and gradient at the start point -- unless this context still holds them (a resumed fit)
     const bool resume = c->eval_valid && c->eval_vp == vp;
-    c->fwd_accurate = c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && resume && c->eval_accurate);
+    ctx_set_accurate(c, c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && resume && c->eval_accurate));
     auto start_eval = [&](bool have) -> int {
         if (!have) {
             if (!vp) PLM_TRY(ctx_eval_enqueue(c));
@@ -1244,17 +1269,46 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     c->eval_valid = false;
     if (!std::isfinite(fx)) return fail(PLM_ENUMERIC, "objective is not finite at the start point");
     if (!c->fwd_accurate && want_accurate(std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx)))) {
-        c->fwd_accurate = true;      // a start point this close to the optimum: its gradient decides the stop rule
+        ctx_set_accurate(c, true);   // a start point this close to the optimum: its gradient decides the stop rule
         PLM_TRY(start_eval(false));
         fx = c->h_scal[SL_FX];
         nll = c->h_scal[SL_NLL];
     }
+    // Certificate of the point that SHIPS.  The field solver iterates the fields in f64; the parameter vector (and the
+    // .model file) holds them rounded to f32.  A field off by 2^-25 |h| changes the gradient by (N-proportional
+    // curvature) x that: at N = 100 000 the float64 oracle sees 4.7e-4 |x| more at the rounded point than the solver at
+    // its own (round 4: reported 0.94e-3, oracle 1.05e-3).  So when the reduced gradient meets the stop rule, the joint
+    // gradient -- fields included -- is evaluated once at the rounded point (the stored potentials are reused: residual
+    // pass, backward GEMM, assemble into the free direction vector); the fit ends only if THAT meets the rule, otherwise
+    // it goes on with a target lowered by what the rounding costs.
+    auto shipped_cond = [&](double *out) -> int {
+        HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
+        HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr,
+                                 nullptr, c->st));
+        PLM_TRY(vp_stage3(c, false, c->dir, 0));
+        const float *a[1] = {c->dir};
+        PLM_TRY(dots(c, 1, a, a, n, SL_DG));
+        PLM_TRY(ctx_allreduce_scalars(c, SL_DG, 1));
+        PLM_TRY(fetch_scalars(c, SL_DG, 1));
+        *out = std::sqrt(c->h_scal[SL_DG]) / std::max(1.0, std::sqrt(xx));
+        return PLM_OK;
+    };
+    double eps_eff = eps;      // target of the reduced gradient: the stop rule minus what the f32 rounding of the fields costs
+    double rounding_note = 0;  // > 0: the rule was met on the f64-field point only; what rounding the fields to f32 adds
+    int n_cert = 0;
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
     // The next pair is (x - anchor, g - g(anchor)).  The anchor is the previous accepted point (xp, gp) -- unless the
     // pair(s) since were skipped as noise (below): then it stays where the last STORED pair ended, in its own buffers,
     // so that the difference is taken over a longer baseline, where H s outgrows the evaluation error again.
     bool anchored = false;
     double last_cond = std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx));   // |g|/max(1,|x|) at the last accepted point
+    if (last_cond <= eps && vp && !resume) {   // a start point that meets the rule must meet it as it ships, too
+        double cj = 0;
+        PLM_TRY(shipped_cond(&cj));
+        const double r2 = std::max(0.0, cj * cj - last_cond * last_cond);
+        if (cj > eps && r2 >= 0.75 * eps * eps) rounding_note = std::sqrt(r2);       // not representable in float32 fields
+        else if (cj > eps) { eps_eff = std::sqrt(eps * eps - r2); last_cond = cj; }   // go on until the shipped point meets it
+    }
     if (last_cond > eps) {
         // first step: unit displacement along the plain gradient; the D^-1-scaled direction is Newton-like for the
         // diagonal part of the Hessian, so it starts from min(1, that)
@@ -1396,9 +1450,11 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             // the pair of the accepted point already sits in slot `end` and its Gram rows in h_scal (see above)
             const double *md = c->h_scal + SL_MD;
             const int nbv = B.n, e = end;
+            bool straddle = false;              // this step's pair would difference gradients of two arithmetics
             if (!c->fwd_accurate &&
                 want_accurate(std::sqrt(md[2 * nbv + 2 * nst + 1] + gh2_trial) / std::max(1.0, std::sqrt(c->h_scal[SL_XX])))) {
-                c->fwd_accurate = true;         // from here on: the accurate forward GEMM, starting with this very point
+                ctx_set_accurate(c, true);      // from here on: the accurate arithmetic, starting with this very point
+                straddle = true;
                 PLM_TRY(evaluate_trial());
                 fx = c->h_scal[SL_FX];
                 nll = c->h_scal[SL_NLL];
@@ -1424,7 +1480,21 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 status = PLM_STATUS_INTERRUPTED;
                 break;
             }
-            if (last_cond <= eps) { status = PLM_STATUS_CONVERGED; break; }
+            if (last_cond <= eps_eff) {
+                if (!vp) { status = PLM_STATUS_CONVERGED; break; }
+                double cj = 0;
+                PLM_TRY(shipped_cond(&cj));
+                if (!(cj > eps)) { last_cond = cj; status = PLM_STATUS_CONVERGED; break; }
+                const double r2 = std::max(0.0, cj * cj - last_cond * last_cond);     // the rounding's share
+                if (r2 >= 0.75 * eps * eps || ++n_cert > 8) {     // the target would fall below eps / 2
+                    // float32 fields cannot carry this stop rule (a rule far below 1e-3, or a very deep alignment): the
+                    // fit ends by the rule on its own (f64-field) point and says what the rounding adds
+                    status = PLM_STATUS_CONVERGED;
+                    rounding_note = std::sqrt(r2);
+                    break;
+                }
+                eps_eff = std::min(0.9 * eps_eff, std::sqrt(eps * eps - r2));
+            }
             if (max_iter > 0 && k >= max_iter) { status = PLM_STATUS_MAXITER; break; }
             // Curvature pair of the accepted step (slot e).  s.y > 0 always holds under the Wolfe conditions -- for exact
             // gradients.  Near the noise floor of the evaluation (config 3: error 1e-3 |x| at a stop rule of 1e-3) steps
@@ -1437,7 +1507,13 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             // pairs; the slot is written again by the next iteration -- with a pair over the longer baseline from the
             // anchor, see `anchored`).
             const double sy = SY[e * m + e], ss = md[0 * nbv + e], yy = md[1 * nbv + nst + e];
-            if (sy > 0 && sy * sy >= 1e-6 * ss * yy) {
+            if (straddle) {
+                // y = g_accurate(x) - g_plain(previous x) carries the DIFFERENCE of the two evaluations' errors (~3e-11 N L
+                // |x|): not a curvature pair.  It is dropped (slot e, the oldest pair once the ring is full, goes with it);
+                // the next pair starts from this point, whose gradient is the accurate one.
+                stored = std::min(stored, m - 1);
+                anchored = false;
+            } else if (sy > 0 && sy * sy >= 1e-6 * ss * yy) {
                 stored = nst;
                 end = (end + 1) % m;
                 anchored = false;
@@ -1476,7 +1552,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         res->seconds_optimize = now_s() - t0;
         // a fit that did not meet the stop rule says how far it got: the reference records this string as
         // `optimization_status` (couplings/tools.py:99), the only place a pipeline user sees it
-        if (status == PLM_STATUS_LINESEARCH)
+        if (status == PLM_STATUS_CONVERGED && rounding_note > 0)
+            snprintf(res->status_msg, sizeof res->status_msg,
+                     "%s; float32 rounding of the fields adds %.1e", status_text(status), rounding_note);
+        else if (status == PLM_STATUS_LINESEARCH)
             snprintf(res->status_msg, sizeof res->status_msg, "%s [code %d]; |g|/max(1,|x|) = %.3e", status_text(status),
                      ls_reason, last_cond);
         else if (status == PLM_STATUS_MAXITER || status == PLM_STATUS_INTERRUPTED)
@@ -1540,7 +1619,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "kernel timing runs on 1-shard contexts");
     HIP_TRY(hipSetDevice(c->device));
     c->eval_valid = false;
-    c->fwd_accurate = false;   // the evaluation pipeline is timed with the plain forward GEMM (the accurate one separately)
+    ctx_set_accurate(c, false);   // the evaluation pipeline is timed with the plain arithmetic (the exact forward GEMM separately)
     const PlmDims &d = c->d;
     struct Events {   // destroyed on every exit path (HIP_TRY returns early)
         hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1555,7 +1634,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         float ms;
         HIP_TRY(hipEventRecord(ev[0], c->st));
         HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
-        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->st));
+        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
         HIP_TRY(hipEventRecord(ev[1], c->st));
         if (vp) {   // the fit's pipeline: forward GEMM -> HJ, 2 Newton steps on the fields, residual pass
             HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, 0, c->st));
@@ -1582,8 +1661,9 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); acc[PLM_K_ASSEMBLE] += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[4])); acc[PLM_K_TOTAL] += ms;
     }
-    if (vp) {   // the accurate instantiation of the forward GEMM (last iterations of a fit, plm_eval)
+    if (vp) {   // the exact forward GEMM (last iterations of a fit, plm_eval), on its own operand
         float ms;
+        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, 1, c->st));
         HIP_TRY(hipEventRecord(ev[0], c->st));
         for (int r = 0; r < reps; r++) HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, 1, c->st));
         HIP_TRY(hipEventRecord(ev[1], c->st));
@@ -1731,8 +1811,11 @@ static int energies_impl(const int8_t *seqs, int32_t n, int32_t L, int32_t q, co
     if (!seqs || !x_canon || !out_host) return fail(PLM_EINVAL, "NULL argument");
     PLM_TRY(check_device(device));
     plm_problem_t p = basic_problem(seqs, n, L, q);
+    const PlmOptions opt = plm_options_from_env();
+    // PLM_FWD_ACCURATE=1 (measurements, tests/probes/potentials_probe.py): the potentials from the accurate forward GEMM
+    const int accurate = (potentials && opt.fwd_mode == 1) ? 1 : 0;
     PlmDims d;
-    PLM_TRY(make_dims(p, plm_options_from_env(), &d));
+    PLM_TRY(make_dims(p, opt, &d));
     if ((int64_t)(d.Np + 32) * d.Lp32 >= (int64_t)1 << 31) return fail(PLM_EINVAL, "too many sequences for one call");
     for (size_t k = 0; k < (size_t)n * L; k++)
         if (seqs[k] < 0 || seqs[k] >= q) return fail(PLM_EINVAL, "seqs[%zu] = %d outside 0..%d", k, (int)seqs[k], q - 1);
@@ -1769,8 +1852,8 @@ static int energies_impl(const int8_t *seqs, int32_t n, int32_t L, int32_t q, co
     ET(hipMemsetAsync(x, 0, sizeof(float) * d.n_native, st));
     ET(plm_launch_canon_to_native(d, canon, x, st));
     ET(plm_launch_maxabs(d, x, maxbits, jexp, st));
-    ET(plm_launch_expand(d, x, nullptr, jexp, Bt, st));
-    ET(plm_launch_forward_energy(d, msa_rm, Bt, x, jexp, potentials, outd, st));
+    ET(plm_launch_expand(d, x, nullptr, jexp, Bt, accurate, st));
+    ET(plm_launch_forward_energy(d, msa_rm, Bt, x, jexp, potentials, accurate, outd, st));
     if (potentials) {
         ET(hipMemcpyAsync(out_host, outd, sizeof(float) * out_dev_floats, hipMemcpyDeviceToHost, st));
     } else {

@@ -49,9 +49,13 @@
 // (J_ij(a, x_sj) - J_ij(a, 0)) -- the first sum is a constant per (i, a) (k_fwd_ref, added in k_fwd's epilogues), the
 // GEMM runs on the differences and on Q - 1 states: 20 = 5 groups of 4 for the protein alphabet, no padding.
 // A K step covers, for the 32 sites of a block u, one of 2 * NG instruction slices (NG = ceil((Q - 1) / 4) state
-// groups per site, 4 (site, group) pairs per lane and instruction) and one of the two f16 planes.
+// groups per site, 4 (site, group) pairs per lane and instruction) and one of the two f16 planes of the operand (hi +
+// lo: 22 bits of every coupling difference): 4 NG tiles per block.  The exact forward GEMM (k_fwd_x: int8 matrix cores,
+// five signed base-256 digit planes of the 39-bit fixed-point differences) has equally large tiles, per block u NG
+// state groups x 5 planes; Bt is allocated for those.
 #define PLM_FWD_NG(Q) (((Q) + 2) / 4)
-#define PLM_FWD_SPU(Q) (4 * PLM_FWD_NG(Q))   // K steps per 32-site block
+#define PLM_FWD_SPU(Q) (4 * PLM_FWD_NG(Q))        // K-step tiles per 32-site block, k_fwd
+#define PLM_FWD_TILES(Q) (5 * PLM_FWD_NG(Q))      // ... of the larger of the two operands (allocation)
 
 struct PlmDims {
     int N, L, Q;       // Q: alphabet size the kernels are instantiated for (4, 5, 20, 21) -- the native layout's stride
@@ -62,7 +66,7 @@ struct PlmDims {
     int Lp16;      // nb16 * 16
     int nu;        // 32-site K blocks covering L
     int Lp32;      // nu * 32
-    int nksteps;   // nu * PLM_FWD_SPU(Q)   forward K steps (tiles of 2 Q KB)
+    int nksteps;   // nu * PLM_FWD_TILES(Q): K-step tiles (2 Q KB each) Bt has room for per column block
     int nssteps;   // Np / 32     (32-sequence groups: the wave granularity of the forward-side kernels)
     int nst128;    // Np / 128    backward K steps (PLM_BWD_KSTEP sequences)
     int nplanes;   // digit planes of the residuals: 3 (24-bit fixed point) or 4 (32-bit)
@@ -107,7 +111,7 @@ struct PlmOptions {
     int bwd_planes = 0;     // PLM_BWD_PLANES = 3 | 4: digit planes of the backward GEMM (0: chosen from epsilon)
     int ksplit = 0;         // PLM_KSPLIT: K split of the backward GEMM (0: cost model); results are identical for every value
     int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
-    int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the fast / the accurate forward GEMM (-1: the solver decides)
+    int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)
     bool debug = false;     // PLM_DEBUG: line-search failures are traced to stderr
     bool debug_vp = false;  // PLM_DEBUG_VP: every round of the field solver is traced to stderr
@@ -139,25 +143,26 @@ hipError_t plm_launch_onehot_rt(const PlmDims &d, const int8_t *msa_rm, const fl
                                 hipStream_t st);
 hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, uint32_t *maxbits, int32_t *jexp,
                              hipStream_t st);
+// exact: the int8 digit planes of k_fwd_x (accurate evaluation) instead of the f16 planes of k_fwd
 hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhalo, const int32_t *jexp,
-                             void *Bt, hipStream_t st);
+                             void *Bt, int exact, hipStream_t st);
 // statistical energies of sequences under a model (k_fwd modes 1/2)
+// exact (potentials only): from k_fwd_x (Bt expanded with exact = 1)
 hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
-                                     const int32_t *jexp, int potentials, float *out, hipStream_t st);
+                                     const int32_t *jexp, int potentials, int accurate, float *out, hipStream_t st);
 hipError_t plm_launch_energy_sum(const PlmDims &d, const float *part, double *out, hipStream_t st);
 // ---- variable-projection fit (fields eliminated by an inner Newton solve) ------------
 // forward GEMM only: HJ[s,i,a] = sum_{j != i} J_ij(a, x_sj) in accumulator order (plm_hj_bytes)
-// accurate: the instantiation with f64 outer sums; plm_fwd_groups = state groups per workgroup of it
+// exact: k_fwd_x, integer arithmetic; plm_fwd_groups = state groups per workgroup of it
 hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const int32_t *jexp,
-                                    float *hj, int accurate, hipStream_t st);
-int plm_fwd_groups(int q, int accurate);
+                                    float *hj, int exact, hipStream_t st);
+int plm_fwd_groups(int q, int exact);
 // one pass over HJ with the fields of x: per-workgroup per-site sums for the field solver (stats 1: gradient sums
 // into gpart (f64), 2: also Hessian sums -- exact diagonal, sampled off-diagonal -- into hpart (f32)) and, with write_rt, the residual fragments (Rt) and -log P partials
 // (fx_part) of the solver's forward epilogue.  skip (device int, may be NULL): non-zero = do nothing.
-// Bt: the forward operand whose GEMM produced hj (its tail holds the reference-state constants the stored potentials
-// leave out, added here in f64 with the fields)
-hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const void *Bt, const int8_t *msa_rm, const float *w,
-                            const double *h64, int write_rt, int stats, void *Rt, double *fx_part, float *hpart,
+// exact: the passes of an accurate evaluation (exact-argument exponentials, see exp_softmax)
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w,
+                            const double *h64, int write_rt, int stats, int exact, void *Rt, double *fx_part, float *hpart,
                             double *gpart, const int *skip, hipStream_t st);
 // Per-site gradient norms of the last pass (their sum -> g2_out[0]); update = 1: sites above their share of tol2 take a
 // Newton step on the field part of x (full = that pass carried Hessian sums: inverse recomputed and cached in hinv

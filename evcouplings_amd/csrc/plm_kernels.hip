@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
     const int u = blockIdx.x / (2 * NG), ci = blockIdx.x % (2 * NG), b16l = blockIdx.y, b16 = d.b16_lo + b16l;
     const float sc = ldexpf(1.f, *jexp);
     const float *__restrict__ xj = x + d.nh_pad_l;
-    _Float16 *tile_hi = Bt + ((size_t)b16l * d.nksteps + (size_t)u * SPU + 2 * ci) * (size_t)(2 * d.Q * 512);
+    _Float16 *tile_hi = Bt + ((size_t)b16l * d.nu * SPU + (size_t)u * SPU + 2 * ci) * (size_t)(2 * d.Q * 512);
     _Float16 *tile_lo = tile_hi + (size_t)(2 * d.Q * 512);
     for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
         const int a = idx >> 6, lane = idx & 63, gb = lane >> 4, r = lane & 15;
@@ -607,8 +607,7 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
                 const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl % NG;
                 const int b = 4 * sg + e + 1, j = 32 * u + 8 * ga + s8;     // state 0 has no slot (reference state)
                 // the difference to the reference state, scaled by a power of two and split hi = f16(v), lo = f16(v - hi):
-                // 23 significant bits of the DIFFERENCE.  (Forming it in f64 first was measured: +0.09 ms, no effect on the
-                // evaluation error -- that is the f32 accumulation of the GEMM, not this operand.)
+                // 22 significant bits of the DIFFERENCE (the evaluations that need more run the exact kernel, k_fwd_x)
                 float v = 0.f;
                 if (b < d.Q && i < d.L && j < d.L && i != j) {
                     v = load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, b);
@@ -624,11 +623,72 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
         }
     }
 }
+
+// The same parameters as the B operand of the EXACT forward GEMM (k_fwd_x): every coupling difference in 39-bit fixed
+// point, D = rint((J_ij(a,b) - J_ij(a,0)) 2^(jexp + 23)) with the difference formed in f64 (|D| < 2^38), as FIVE signed
+// base-256 digit planes.  (Four planes -- 31 bits of the LARGEST coupling -- were measured first: the alignments' few
+// strong couplings are 100 x the typical one, and a quantum of 2^-31 max|J| left a coherent error of 2.7e-8 per
+// potential, no better than the f16 planes; with five it is ~1e-10.)  Tile of K step (32-site block u, state group grp) and plane
+// p: for every state a two 1 KB fragments of v_mfma_i32_16x16x64_i8 (h16 = 0, 1: the two 16-site halves of the block),
+// lane (kg, r) = 16 K values of site column 16 b16 + r: byte 4 e + t = digit p of D for neighbour site
+// j = 32 u + 8 kg + 4 h16 + t in state b = 4 grp + 1 + e.  Planes are the slowest index of a column block: the kernel runs
+// one plane over the whole K range before the next.
+#define PLM_FWDX_PLANES 5
+#define PLM_FWDX_SHIFT 23
+__global__ __launch_bounds__(256) void k_expand_x(PlmDims d, const float *__restrict__ x,
+                                                 const float *__restrict__ xhalo,
+                                                 const int32_t *__restrict__ jexp, char *__restrict__ Bt) {
+    const int NG = PLM_FWD_NG(d.Q);
+    const int u = blockIdx.x / NG, grp = blockIdx.x % NG, b16l = blockIdx.y, b16 = d.b16_lo + b16l;
+    const double sc = ldexp(1.0, *jexp + PLM_FWDX_SHIFT);
+    const float *__restrict__ xj = x + d.nh_pad_l;
+    const size_t tile = (size_t)2 * d.Q * 1024, plane_stride = (size_t)d.nu * NG * tile;
+    char *t0 = Bt + (size_t)b16l * PLM_FWDX_PLANES * plane_stride + ((size_t)u * NG + grp) * tile;
+    for (int idx = threadIdx.x; idx < 2 * d.Q * 64; idx += 256) {
+        const int h16 = idx / (d.Q * 64), rem = idx - h16 * d.Q * 64;
+        const int a = rem >> 6, lane = rem & 63, kg = lane >> 4, r = lane & 15;
+        const int i = b16 * 16 + r;
+        u32 w[PLM_FWDX_PLANES][4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            u32 dig[4], top = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int b = 4 * grp + 1 + e, j = 32 * u + 8 * kg + 4 * h16 + t;
+                double v = 0.0;
+                if (b < d.Q && i < d.L && j < d.L && i != j) {
+                    const float jb = load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, b);
+                    const float j0 = d.gap_mode ? 0.f : load_coupling(d, xj, xhalo, b16, r, a, j >> 4, j & 15, 0);
+                    v = ((double)jb - (double)j0) * sc;
+                }
+                // signed base-256 digits: bytes of R + 0x8080808080 are the digits + 128 (|R| < 2^38 < 0x7f7f7f7f7f)
+                const long long R = llrint(v);           // ties to even: unbiased
+                const u64 dg = ((u64)R + 0x8080808080ull) ^ 0x8080808080ull;
+                dig[t] = (u32)dg;
+                top |= (u32)((dg >> 32) & 0xffu) << (8 * t);
+            }
+            u32 pl[PLM_BWD_MAXPLANES];
+            planes_of4(dig[0], dig[1], dig[2], dig[3], pl);
+#pragma unroll
+            for (int p = 0; p < 4; p++) w[p][e] = pl[p];
+            w[4][e] = top;
+        }
+#pragma unroll
+        for (int p = 0; p < PLM_FWDX_PLANES; p++)
+            *(uint4 *)(t0 + (size_t)p * plane_stride + (size_t)(h16 * d.Q + a) * 1024 + lane * 16) =
+                make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
+    }
+}
+// exact: the operand of k_fwd_x (accurate evaluation) instead of the f16 planes of k_fwd
 hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhalo, const int32_t *jexp, void *Bt,
-                             hipStream_t st) {
+                             int exact, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_expand, dim3(d.nksteps / 2, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
-                       (_Float16 *)Bt);
+    const int NG = PLM_FWD_NG(d.Q);
+    if (exact)
+        hipLaunchKernelGGL(k_expand_x, dim3(d.nu * NG, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp, (char *)Bt);
+    else
+        hipLaunchKernelGGL(k_expand, dim3(d.nu * 2 * NG, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
+                           (_Float16 *)Bt);
     hipLaunchKernelGGL(k_fwd_ref, dim3(d.b16_hi - d.b16_lo, 16, d.Q), dim3(64), 0, st, d, x, xhalo,
                        (float *)bt_cref32(d, Bt), (double *)bt_cref64(d, Bt));
     return hipGetLastError();
@@ -644,12 +704,10 @@ hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhal
 //   sequences per lane.  Epilogues (template parameter MODE): FWD_STORE writes HJ for k_hpass (the fit and plm_eval:
 //   softmax, residuals and the field solver live there), FWD_ENERGY / FWD_POTENTIALS serve the statistical energies of
 //   row N2.
-//   ACC = 1, the ACCURATE instantiation: the f32 accumulators of the matrix cores are flushed into f64
-//   sums every FLUSH K steps.  The rounding error of a potential then comes from FLUSH accumulation steps on a partial
-//   sum of a few sites instead of 20 nu steps on the running total -- ~sqrt(FLUSH / (20 nu)) of the plain kernel's, which
-//   is what limited the whole evaluation (|g_hip - g_f64| ~ 3e-11 N L |x|, at N = 100 000 as large as the stop rule).
-//   The f64 sums cost 2 registers per value; with QG = 7 states per workgroup (NSG = 3 at Q = 21) the kernel fits the
-//   256 registers of two waves per SIMD.  Used for the last iterations of a fit and by plm_eval (plm_host.cpp).
+//   Its accuracy is that of two f16 operand planes (22 bits of every coupling difference) and f32 accumulation over
+//   the whole K range: an error of ~5e-7 per potential of which a sixth is the SAME for every sequence of a (site,
+//   state) (round 4, tests/probes/potentials_probe.py) -- the gradient sums add that part up N-fold, |g_hip - g_f64| ~
+//   3e-11 N L |x|.  Irrelevant far from the optimum; the last iterations of a fit and plm_eval run k_fwd_x below.
 // =========================================================================================
 struct FwdArgs {
     const int8_t *msa_rm;
@@ -699,7 +757,7 @@ __device__ __forceinline__ void fwd_kstep(f32x4 (&acc)[2][QG], const half8 &a0, 
     (fwd_state<QG, A>(acc, a0, a1, i0, i1, lb, bh, bl, dma), ...);
 }
 
-template <int Q, int MODE, int NSG, int ACC>
+template <int Q, int MODE, int NSG>
 __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     static_assert(Q % NSG == 0, "state groups must divide the alphabet");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (guide 5/4a)
@@ -721,7 +779,11 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
     const int r = lane & 15, g = lane >> 4;
     const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
     // a step's tile in Bt: [2 halves][Q states][1 KB]; the group's fragments are the runs [a_lo, a_lo + QG) of both halves
-    const char *bt = A.Bt + (size_t)b16l * d.nksteps * TILE_G + (size_t)a_lo * 1024;
+    // steps of a 32-site block: 2 NG instruction slices x 2 planes (hi, lo); gap mode needs no special case (k_expand
+    // leaves the slots of state 0 zero)
+    constexpr int NG = PLM_FWD_NG(Q), SPU = 4 * NG;
+    const int nsteps = d.nu * SPU;
+    const char *bt = A.Bt + (size_t)b16l * nsteps * TILE_G + (size_t)a_lo * 1024;
     // A operand: byte offsets of the two sequences' rows in msa_rm (< 2^31: Np * Lp32 bytes)
     const u32 arow0 = (u32)(s_wave + r) * (u32)d.Lp32 + 8 * g, arow1 = arow0 + 16 * (u32)d.Lp32;
 
@@ -731,19 +793,6 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
         acc[0][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // ACCURATE: f64 sums the f32 accumulators are flushed into
-    double sum64[ACC ? 2 : 1][ACC ? QG : 1][4];
-    if constexpr (ACC) {
-#pragma unroll
-        for (int a = 0; a < QG; a++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) sum64[0][a][e] = sum64[1][a][e] = 0.0;
-    }
-    // steps of a 32-site block: 2 NG instruction slices x 2 planes; gap mode needs no special case (k_expand leaves
-    // the slots of state 0 zero)
-    constexpr int NG = PLM_FWD_NG(Q), SPU = 4 * NG;
-    constexpr int FLUSH = (SPU % 5 == 0) ? 5 : 4;        // K steps between two flushes (divides SPU)
-    const int nsteps = d.nu * SPU;
 #if PLM_PROBE
     unsigned long long pr_wait = 0;
     const unsigned long long pr_t0 = PROBE_NOW();
@@ -798,18 +847,6 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 }
             }
             fwd_kstep<QG>(acc, a0, a1, i0, i1, lb, bh, bl, dma, std::make_integer_sequence<int, QG>{});
-            if constexpr (ACC) {
-                if (b % FLUSH == FLUSH - 1) {
-#pragma unroll
-                    for (int m = 0; m < 2; m++)
-#pragma unroll
-                        for (int a = 0; a < QG; a++) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) sum64[m][a][e] += (double)acc[m][a][e];
-                            acc[m][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        }
-                }
-            }
             cur = nxt;
         }
     }
@@ -819,21 +856,17 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
         atomicAdd(&plm_probe_acc[0][5], 1ull);
     }
 #endif
-    // descaled value of accumulator element (m, a, e): one rounding of the f64 sum in the accurate instantiation
+    // Potential of accumulator element (m, a, e): the descaled sum of the differences PLUS the reference-state constant
+    // C_i(a) = sum_{j != i} J_ij(a, 0) (k_fwd_ref, f64), added in f64 and rounded ONCE.  (A C rounded to f32 would shift
+    // the potentials of every sequence of a (site, state) by the same ~1e-7 |C| -- a coherent error the gradient sums
+    // add up N-fold: round 3, tests/probes/fwd_bias_probe.py; the f64 constant has no such part.)
     const int je = *A.jexp;
-    const float sc = ldexpf(1.f, -je);
     const double sc64 = ldexp(1.0, -je);
-    auto value = [&](int m, int a, int e) -> float {
-        if constexpr (ACC) return (float)(sum64[m][a][e] * sc64);
-        else return acc[m][a][e] * sc;
-    };
-    // reference-state constants of the lane's site (see plm_internal.h), state a_lo + a
-    const float *cref = (const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE_G) + ((size_t)b16l * 16 + r) * Q + a_lo;
+    const double *cref = (const double *)((const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE_G) +
+                                          (size_t)d.blk_per_shard * 16 * Q) + ((size_t)b16l * 16 + r) * Q + a_lo;
+    auto value = [&](int m, int a, int e) -> float { return (float)__builtin_fma((double)acc[m][a][e], sc64, cref[a]); };
     if constexpr (MODE == FWD_STORE) {
         float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + wave) * 2 * Q * 64 + lane;
-        // the reference-state constant C_i(a) is NOT added here: rounded into these f32 values it would shift the
-        // potentials of every sequence of a (site, state) by the same ~1e-7 |C| -- a coherent error that the gradient
-        // sums add up N-fold (tests/probes/fwd_bias_probe.py).  k_hpass adds it in f64 together with the field.
 #pragma unroll
         for (int a = 0; a < QG; a++) {
 #pragma unroll
@@ -857,16 +890,12 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 for (int reg = 0; reg < 4; reg++) {
                     const int s = s_wave + 16 * m + 4 * g + reg;
                     const int xi = A.msa_rm[(size_t)s * d.Lp32 + i] - a_lo;
-                    float ej = 0.f, eh = 0.f, ec = 0.f;
-                    bool mine = false;      // the site's state lies in this workgroup's group
+                    float ej = 0.f, eh = 0.f;
 #pragma unroll
-                    for (int a = 0; a < QG; a++) {
+                    for (int a = 0; a < QG; a++) {      // a state outside this workgroup's group (or padding) leaves 0
                         ej = (a == xi) ? value(m, a, reg) : ej;
                         eh = (a == xi) ? hv[a] : eh;
-                        ec = (a == xi) ? cref[a] : ec;
-                        mine = mine || a == xi;
                     }
-                    ej = mine ? ej + ec : 0.f;
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) {   // sum over the 16 sites of the block (lanes r)
                         ej += __shfl_xor(ej, o, 64);
@@ -885,12 +914,187 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                         float *o = A.out + ((size_t)s * d.L + i) * d.Qc + a_lo;   // the API's array: the problem's alphabet
 #pragma unroll
                         for (int a = 0; a < QG; a++)
-                            if (a_lo + a < d.Qc) o[a] = value(m, a, reg) + cref[a];
+                            if (a_lo + a < d.Qc) o[a] = value(m, a, reg);
                     }
                 }
             }
         }
         return;
+    }
+}
+
+
+// =========================================================================================
+// K_fwd_x: the same potentials EXACTLY (row a6, accurate evaluation: the last iterations of a fit, plm_eval).
+//   Round 4 took the error of the evaluation apart (tests/probes/potentials_probe.py): what the
+//   gradient sums cannot average out is the part of a potential's error that is the same for every sequence -- operand
+//   bits lost (22 of the f32 differences' 24, and the f32 rounding of the differences themselves), and the rounding of
+//   the matrix cores' f32 accumulation, which has a small negative mean.  f64 outer sums and a third f16 plane brought
+//   it from 4.5e-4 |x| to 1.6e-4 (headline) / 3.9e-4 (N = 100 000), no further.  Integer arithmetic has none of it:
+//     * operand = every coupling difference in 39-bit fixed point (difference formed in f64, one unbiased rounding at
+//       2^-39 of the largest), five signed base-256 digit planes (k_expand_x);
+//     * one-hot(MSA) x digit plane on v_mfma_i32_16x16x64_i8 with int32 accumulators: exact, whatever the order
+//       (|sum| <= 128 * 128 * L);
+//     * a workgroup runs ONE plane over the whole K range, then adds its accumulators, shifted by 8 p bits, to int64
+//       sums and starts the next plane -- five flushes in all;
+//     * potential = sum * 2^-(jexp + 30) + C_i(a) in f64, rounded once to f32.
+//   The result is the correctly rounded potential of the f32 parameters up to 2^-39 max|J| per coupling; it does not
+//   depend on tiling or order (bit-reproducible).  Same tiling as k_fwd with NSG state groups (QG = 7 states per
+//   workgroup at Q = 21: 56 accumulator + 112 f64-sum registers), same tile geometry ([2][Q][1 KB] per K step: here the
+//   two 16-site halves of a 32-site block, one MFMA each), same LDS-DMA double buffer.  K step = (plane, 32-site block
+//   u, state group grp of 4 states); the one-hot A fragment of a (row fragment, half) is expanded from 4 alignment
+//   bytes per lane with k_bwd's two-VALU-per-dword trick (value -128 for a match, folded into the scale).
+//   Cost at the headline: 2.5 x the MFMA work of k_fwd (5 planes of int8 at the f16-sparse rate against 2).
+// =========================================================================================
+template <int QG, int F>
+__device__ __forceinline__ void fwdx_frag(i32x4 (&acc)[2][QG], const i32x4 (&af)[2][2], u32 lb, i32x4 (&bf)[3],
+                                          const DmaPlan &dma) {
+    constexpr int NF = 2 * QG, A = F % QG, H = F / QG, NP = (NF + 7) / 8;
+    if constexpr (F + 2 < NF) bf[(F + 2) % 3] = lds_read_b128_i<(F + 2) * 1024>(lb);
+    constexpr int newer = (F + 2 < NF) ? 2 : (F + 1 < NF) ? 1 : 0;
+    lds_wait_i<newer>(bf[F % 3]);
+    acc[0][A] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0][H], bf[F % 3], acc[0][A], 0, 0, 0);
+    dma_at<NF, F, NP, PLM_DMA_STAGGER_FWD>(dma);
+    acc[1][A] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1][H], bf[F % 3], acc[1][A], 0, 0, 0);
+}
+template <int QG, int... F>
+__device__ __forceinline__ void fwdx_kstep(i32x4 (&acc)[2][QG], const i32x4 (&af)[2][2], u32 lb, i32x4 (&bf)[3],
+                                           const DmaPlan &dma, std::integer_sequence<int, F...>) {
+    bf[0] = lds_read_b128_i<0>(lb);
+    bf[1] = lds_read_b128_i<1024>(lb);
+    (fwdx_frag<QG, F>(acc, af, lb, bf, dma), ...);
+}
+
+template <int Q, int MODE, int NSG>
+__global__ __launch_bounds__(512) void k_fwd_x(PlmDims d, FwdArgs A) {
+    static_assert(Q % NSG == 0, "state groups must divide the alphabet");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QG = Q / NSG, NG = PLM_FWD_NG(Q);
+    constexpr int TILE_G = 2 * Q * 1024, TILE = 2 * QG * 1024, NP = (2 * QG + 7) / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    u32 k7f = 0x7f7f7f7fu;
+    asm volatile("" : "+v"(k7f));                              // a VGPR constant (see onehot16)
+    // work list and XCD-aware order as in k_fwd
+    const int nwork = d.nstiles * (d.b16_hi - d.b16_lo) * NSG, per_xcd = (nwork + 7) >> 3;
+    const int wk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || wk >= nwork) return;
+    const int stile = wk % d.nstiles, sg = (wk / d.nstiles) % NSG, b16l = wk / (d.nstiles * NSG);
+    const int tile = b16l * d.nstiles + stile;
+    const int a_lo = sg * QG;
+    const int b16 = d.b16_lo + b16l;
+    const int r = lane & 15, g = lane >> 4;
+    const int s_wave = stile * PLM_SEQ_TILE + wave * 32;
+    const int per_plane = d.nu * NG, nsteps = PLM_FWDX_PLANES * per_plane;      // tiles of a column block, plane-major
+    const char *bt = A.Bt + (size_t)b16l * nsteps * TILE_G + (size_t)a_lo * 1024;
+    // A operand: the lane's 8 sites (8 g .. 8 g + 7 of the 32-site block) of its two sequences
+    const u32 arow0 = (u32)(s_wave + r) * (u32)d.Lp32 + 8 * g, arow1 = arow0 + 16 * (u32)d.Lp32;
+
+    i32x4 acc[2][QG];
+    long long sum64[2][QG][4];
+#pragma unroll
+    for (int a = 0; a < QG; a++)
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            acc[m][a] = (i32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; e++) sum64[m][a][e] = 0;
+        }
+    if (nsteps > 0) {
+        const DmaPlan first{bt, smem, wave_s, 2 * QG, (u32)lane * 16, false, nullptr, 0, nullptr, QG, (Q - QG) * 1024};
+        dma_issue_all<NP>(first);
+    }
+    u64 na0 = *(const u64 *)(A.msa_rm + arow0), na1 = *(const u64 *)(A.msa_rm + arow1);   // bytes of the NEXT u
+    u64 xa0 = 0, xa1 = 0;
+    i32x4 bf[3];
+    int cur = 0, u = 0, grp = 0;
+    int shift = 0;                                             // 8 * plane
+    for (int t = 0; t < nsteps; ++t) {
+        vm_wait<0>();       // my pieces of this step's tile (and the alignment bytes in flight) have landed ...
+        __syncthreads();    // ... and so have everybody's; nobody reads the other buffer any more
+        if (grp == 0) {
+            // hand over the 32 sites of this u, then start fetching the next block's (the plane loop wraps around)
+            vm_landed(na0);
+            vm_landed(na1);
+            xa0 = na0;
+            xa1 = na1;
+            const int un = (u + 1 == d.nu) ? 0 : u + 1;
+            load_b64_inplace(na0, A.msa_rm, arow0 + 32 * un);
+            load_b64_inplace(na1, A.msa_rm, arow1 + 32 * un);
+        }
+        const int nxt = cur ^ 1;
+        const DmaPlan dma{bt + (size_t)(t + 1) * TILE_G, smem + nxt * TILE, wave_s, (t + 1 < nsteps) ? 2 * QG : 0,
+                          (u32)lane * 16, wave_s >= 4, nullptr, 0, nullptr, QG, (Q - QG) * 1024};
+        const u32 lb = lds_addr(smem + cur * TILE + lane * 16);
+        // one-hot fragments [row fragment][16-site half]: dword e = the lane's 4 sites of that half against state
+        // 4 grp + 1 + e, -128 for a match (byte 4 e + t <-> neighbour site t, as k_expand_x lays the digits out)
+        i32x4 af[2][2];
+        {
+            const u32 b0 = (u32)(4 * grp + 1) * 0x01010101u;
+            const u32 k80 = 0x80808080u;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const u32 x0 = (u32)(xa0 >> (32 * h)), x1 = (u32)(xa1 >> (32 * h));
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const u32 bb = b0 + (u32)e * 0x01010101u;
+                    u32 y0, y1, v0, v1;
+                    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(y0) : "v"(x0), "s"(bb), "v"(k7f));
+                    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(v0) : "v"(y0), "s"(k80));
+                    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(y1) : "v"(x1), "s"(bb), "v"(k7f));
+                    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(v1) : "v"(y1), "s"(k80));
+                    af[0][h][e] = (int)v0;
+                    af[1][h][e] = (int)v1;
+                }
+            }
+        }
+        fwdx_kstep<QG>(acc, af, lb, bf, dma, std::make_integer_sequence<int, 2 * QG>{});
+        cur = nxt;
+        if (++grp == NG) {
+            grp = 0;
+            if (++u == d.nu) {
+                // end of a plane: its integer sums, weighted 256^p, go to the 64-bit sums (|total| < 2^23 2^32: exact)
+                u = 0;
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int a = 0; a < QG; a++) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) sum64[m][a][e] += (long long)acc[m][a][e] * (1ll << shift);
+                        acc[m][a] = (i32x4){0, 0, 0, 0};
+                    }
+                shift += 8;
+            }
+        }
+    }
+    // potential = sum / (-128 2^(jexp + 23)) + C_i(a), in f64, rounded once
+    const double sc64 = -ldexp(1.0, -(*A.jexp + PLM_FWDX_SHIFT + 7));
+    const double *cref = (const double *)((const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE_G) +
+                                          (size_t)d.blk_per_shard * 16 * Q) + ((size_t)b16l * 16 + r) * Q + a_lo;
+    auto value = [&](int m, int a, int e) -> float { return (float)__builtin_fma((double)sum64[m][a][e], sc64, cref[a]); };
+    if constexpr (MODE == FWD_STORE) {
+        float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + wave) * 2 * Q * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < QG; a++) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                hj[(size_t)(m * Q + a_lo + a) * 64] = make_float4(value(m, a, 0), value(m, a, 1), value(m, a, 2), value(m, a, 3));
+        }
+    } else {        // FWD_POTENTIALS
+        const int i = b16 * 16 + r;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int s = s_wave + 16 * m + 4 * g + reg;
+                if (i < d.L && s < d.N) {
+                    float *o = A.out + ((size_t)s * d.L + i) * d.Qc + a_lo;
+#pragma unroll
+                    for (int a = 0; a < QG; a++)
+                        if (a_lo + a < d.Qc) o[a] = value(m, a, reg);
+                }
+            }
+        }
     }
 }
 
@@ -907,30 +1111,36 @@ template <auto KERNEL> static hipError_t plm_allow_lds(size_t lds) {
     return result[dev];
 }
 
-// state groups per workgroup of the forward GEMM: the plain instantiation takes all states of an alphabet that fits
-// its registers (2 x Q accumulator fragments per wave), the accurate one (f64 sums: 3 registers per value) 7 or fewer
-int plm_fwd_groups(int q, int accurate) {
-    if (!accurate) return 1;
+// state groups per workgroup of the exact forward GEMM (56 + 112 registers of accumulators and f64 sums at 7 states)
+int plm_fwd_groups(int q, int exact) {
+    if (!exact) return 1;
     return q == 21 ? 3 : q == 20 ? 4 : 1;
 }
-template <int Q, int MODE, int NSG, int ACC>
+template <int Q, int MODE, int NSG, bool EXACT>
 static hipError_t fwd_launch(const PlmDims &d, const FwdArgs &A, hipStream_t st) {
     const int nwork = d.nstiles * (d.b16_hi - d.b16_lo) * NSG;
     const dim3 grid(8 * ((nwork + 7) / 8)), block(512);   // XCD-aware order, padded to 8
     const size_t lds = (size_t)2 * 2 * (Q / NSG) * 1024;  // double buffer of the group's fragments
-    hipError_t e = plm_allow_lds<k_fwd<Q, MODE, NSG, ACC>>(lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_fwd<Q, MODE, NSG, ACC>), grid, block, lds, st, d, A);
+    if constexpr (EXACT) {
+        hipError_t e = plm_allow_lds<k_fwd_x<Q, MODE, NSG>>(lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fwd_x<Q, MODE, NSG>), grid, block, lds, st, d, A);
+    } else {
+        hipError_t e = plm_allow_lds<k_fwd<Q, MODE, NSG>>(lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fwd<Q, MODE, NSG>), grid, block, lds, st, d, A);
+    }
     return hipGetLastError();
 }
-static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, int accurate, hipStream_t st) {
+static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, int exact, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-#define FWD_CASE(QQ, NACC)                                                                             \
+#define FWD_CASE(QQ, NX)                                                                               \
     case QQ:                                                                                           \
-        if (mode == FWD_ENERGY) return fwd_launch<QQ, FWD_ENERGY, 1, 0>(d, A, st);                     \
-        if (mode == FWD_POTENTIALS) return fwd_launch<QQ, FWD_POTENTIALS, 1, 0>(d, A, st);             \
-        if (accurate) return fwd_launch<QQ, FWD_STORE, NACC, 1>(d, A, st);                             \
-        return fwd_launch<QQ, FWD_STORE, 1, 0>(d, A, st);
+        if (mode == FWD_ENERGY) return fwd_launch<QQ, FWD_ENERGY, 1, false>(d, A, st);                 \
+        if (mode == FWD_POTENTIALS && exact) return fwd_launch<QQ, FWD_POTENTIALS, NX, true>(d, A, st); \
+        if (mode == FWD_POTENTIALS) return fwd_launch<QQ, FWD_POTENTIALS, 1, false>(d, A, st);         \
+        if (exact) return fwd_launch<QQ, FWD_STORE, NX, true>(d, A, st);                               \
+        return fwd_launch<QQ, FWD_STORE, 1, false>(d, A, st);
     switch (d.Q) {
         FWD_CASE(21, 3)
         FWD_CASE(20, 4)
@@ -942,17 +1152,17 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
 #undef FWD_CASE
 }
 // statistical energies: mode 1 -> out = float2 [Np][blocks] partial sums, mode 2 -> out = potentials [N][L][Q]
+// (exact, potentials only: from k_fwd_x -- Bt must hold its operand)
 hipError_t plm_launch_forward_energy(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const float *x,
-                                     const int32_t *jexp, int potentials, float *out, hipStream_t st) {
+                                     const int32_t *jexp, int potentials, int exact, float *out, hipStream_t st) {
     const FwdArgs A{msa_rm, (const char *)Bt, x, jexp, out};
-    return launch_forward_mode(d, A, potentials ? FWD_POTENTIALS : FWD_ENERGY, 0, st);
+    return launch_forward_mode(d, A, potentials ? FWD_POTENTIALS : FWD_ENERGY, potentials ? exact : 0, st);
 }
-// the forward GEMM alone; HJ (descaled) goes to HBM in accumulator order.  accurate: the instantiation with f64 outer
-// sums (the last iterations of a fit, plm_eval)
+// the forward GEMM alone; HJ goes to HBM in accumulator order.  exact: k_fwd_x (the last iterations of a fit, plm_eval)
 hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, const void *Bt, const int32_t *jexp,
-                                    float *hj, int accurate, hipStream_t st) {
+                                    float *hj, int exact, hipStream_t st) {
     const FwdArgs A{msa_rm, (const char *)Bt, nullptr, jexp, hj};
-    return launch_forward_mode(d, A, FWD_STORE, accurate, st);
+    return launch_forward_mode(d, A, FWD_STORE, exact, st);
 }
 size_t plm_hj_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 8 * 2 * d.Q * 1024; }
 
@@ -983,18 +1193,33 @@ __device__ __forceinline__ float sum_over_g(float v) {
     auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
-// exp(x) for the softmax: __expf = v_exp_f32(x * 1.44269502f).  The float nearest to log2(e) is 1.33e-8 (relative) too
-// small, i.e. every softmax runs at a temperature 1.33e-8 off -- a coherent error in principle (the same way in every
-// sequence).  Round 3 suspected it of the systematic part of |g_hip - g_f64| at scale, corrected it (the low part of the
-// constant applied to the result, r + r * x * 1.335e-8) and measured NO change of that error (4.0e-4 |x| at the headline
-// either way: it is the f32 accumulation of the forward GEMM, tests/probes/operand_grid_probe.py) at +0.1 ms per pass
-// over HJ: not kept.
-__device__ __forceinline__ float exp_softmax(float x) { return __expf(x); }
+// exp_softmax_note.  The exponentials of the softmax: __expf(x) = v_exp_f32(x * 1.44269502f).  The float nearest to log2(e)
+// is 1.33e-8 (relative) too small and the product is rounded, so the result carries a relative error of ~0.7 |x log2 e| ulp
+// with a POSITIVE mean for the negative arguments of a softmax (scripts/ubench/softmax_bias.hip on the MI355X: mean +0.06
+// ... +4.4 ulp for x in [-1, 0) ... [-24, -16); v_exp_f32 itself: -0.06 ulp): every softmax runs slightly too warm, the
+// same way in every sequence.  Likewise the argument: potential + field rounded to f32.  Both are errors of ~1e-9 in P
+// that do NOT average out over the sequences; a float32 emulation of this kernel on the host (round 4) shows the
+// coherent part of the residuals' error vanish exactly when the exponentials' arguments are exact.  Round 3 corrected
+// the constant alone, saw nothing (the forward GEMM's error was 5 x larger then) and dropped it.  The passes of an
+// accurate evaluation (template parameter XACT of k_hpass) form the arguments in f64; the plain passes keep __expf.
 // log(z) = log2(z) * ln 2 with the same care (the f32 ln 2 is 2.1e-9 too large; irrelevant for the gradient, kept exact
 // for the objective's sake)
 __device__ __forceinline__ float log_unbiased(float z) {
     const float l2 = __builtin_amdgcn_logf(z);
     return __builtin_fmaf(l2, -1.904654323148236e-9f, l2 * 0.693147182464599609375f);   // ln 2 = HI + LO
+}
+// (x == a) ? if_eq : if_ne as ONE compare into VCC and the select right behind it.  Written as C, hipcc hoists the 21
+// compares of a softmax loop in front of their selects and keeps every mask in an SGPR pair -- with the selects of the
+// observed state below that spilled 160 SGPRs in the residual-writing instantiations of k_hpass.
+__device__ __forceinline__ float sel_eq(int x, int a, float if_ne, float if_eq) {
+    float out;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(out) : "s"(a), "v"(x), "v"(if_ne), "v"(if_eq) : "vcc");
+    return out;
+}
+// the same compare serving two selects
+__device__ __forceinline__ void sel_eq2(int x, int a, float ne0, float eq0, float ne1, float eq1, float &o0, float &o1) {
+    asm("v_cmp_eq_u32 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %5, vcc\n\tv_cndmask_b32 %1, %6, %7, vcc"
+        : "=&v"(o0), "=&v"(o1) : "s"(a), "v"(x), "v"(ne0), "v"(eq0), "v"(ne1), "v"(eq1) : "vcc");
 }
 __global__ void k_sum_partials(const double *__restrict__ p, int n, double *out);
 struct HpassArgs {
@@ -1002,7 +1227,6 @@ struct HpassArgs {
     const int8_t *msa_rm;
     const float *w;
     const double *h;      // fields of the local sites in f64 (the solver's copy: see k_hsolve)
-    const double *c;      // reference-state constants of the forward GEMM, [local site][Q] f64 (NULL: none)
     char *Rt;
     double *fx_part;
     float *hpart;         // [workgroup][16 sites][NH]  Hessian sums, NH = Q (Q + 1) / 2 (STATS == 2 only)
@@ -1011,7 +1235,7 @@ struct HpassArgs {
     const int *skip;      // device flag (may be NULL): non-zero = the field solver has converged, do nothing
     int sel;              // sequence tiles of this launch: 0 all, 1 the Hessian-sampled ones, 2 all the others
 };
-template <int Q, bool WRITE_RT, int STATS>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums
+template <int Q, bool WRITE_RT, int STATS, bool XACT>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums; XACT: exact softmax arguments
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NH = (STATS == 2) ? Q * (Q + 1) / 2 : 0;
@@ -1037,15 +1261,20 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     // differs from sequence to sequence and averages out.  The statistics-only instantiations read them once; the ones
     // that write residual fragments read them again for the second half (42 registers that would otherwise stay live
     // through the residual epilogue of the first half; the second read hits L2).
-    float hv[Q], hl[Q];
+    float hv[XACT ? 1 : Q], hl[XACT ? 1 : Q];
+    double hd[XACT ? Q : 1];                          // XACT: the fields as they are (f64)
     auto load_fields = [&](bool opaque) {
-        u32 hoff = (u32)(site_ok ? i - d.h_site0 : 0) * Q, coff = (u32)(b16l * 16 + r) * Q;
-        if (opaque) asm volatile("" : "+v"(hoff), "+v"(coff));   // per iteration: the loads must not be hoisted out of the loop
+        u32 hoff = (u32)(site_ok ? i - d.h_site0 : 0) * Q;
+        if (opaque) asm volatile("" : "+v"(hoff));   // per iteration: the loads must not be hoisted out of the loop
 #pragma unroll
         for (int a = 0; a < Q; a++) {
-            const double h64 = site_ok ? A.h[hoff + a] + (A.c ? A.c[coff + a] : 0.0) : 0.0;
-            hv[a] = (float)h64;
-            hl[a] = (float)(h64 - (double)hv[a]);
+            const double h64 = site_ok ? A.h[hoff + a] : 0.0;
+            if constexpr (XACT) {
+                hd[a] = h64;
+            } else {
+                hv[a] = (float)h64;
+                hl[a] = (float)(h64 - (double)hv[a]);
+            }
         }
     };
     if constexpr (!WRITE_RT) load_fields(false);
@@ -1077,6 +1306,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             acc[a] = (f32x4){v.x, v.y, v.z, v.w};
         }
         float wk[4];     // weight of the lane's 4 (sequence, site) pairs (0: padding, gapped site in gap mode)
+        // After the softmax acc[a][reg] holds P(a) - [a = observed state]: the residual without its weight.  For the
+        // observed state that is -(1 - P), formed as the SUM of the other states' probabilities: where a site is all but
+        // certain (P = 1 - 1e-8: gap runs, conserved columns) the f32 P rounds to 1 - k 2^-24 and P - 1 loses every bit --
+        // the same way for every such sequence, a coherent error the gradient sums add up (round 4: 0.8e-4 |x| at the
+        // headline with everything else exact; -g, without the gap state's long runs: 0.2e-4).  The small probabilities
+        // themselves are good to 1e-7 relative.
         int xk[4];       // observed state
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
@@ -1084,29 +1319,58 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             const int xi = A.msa_rm[(size_t)s * d.Lp32 + i];
             const bool skip = gap && xi == 0;
             const float ws = (skip || !site_ok) ? 0.f : A.w[s];
-            float mx = -INFINITY;
+            float mx = -INFINITY, Z = 0.f, hx = 0.f, zo = 0.f;     // zo: sum of the exponentials of the states NOT observed
+            if constexpr (!XACT) {
 #pragma unroll
-            for (int a = 0; a < Q; a++) {
-                const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : (acc[a][reg] + hl[a]) + hv[a];
-                acc[a][reg] = H;
-                mx = fmaxf(mx, H);
-            }
-            float Z = 0.f, hx = 0.f;
+                for (int a = 0; a < Q; a++) {
+                    const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : (acc[a][reg] + hl[a]) + hv[a];
+                    acc[a][reg] = H;
+                    mx = fmaxf(mx, H);
+                }
 #pragma unroll
-            for (int a = 0; a < Q; a++) {
-                const float H = acc[a][reg] - mx;
-                hx = (a == xi) ? H : hx;
-                const float ev = exp_softmax(H);
-                acc[a][reg] = ev;
-                Z += ev;
+                for (int a = 0; a < Q; a++) {
+                    const float H = acc[a][reg] - mx;
+                    const float ev = __expf(H);
+                    float evo;
+                    sel_eq2(xi, a, hx, H, ev, 0.f, hx, evo);       // hx = H of the observed state; evo = ev of the others
+                    acc[a][reg] = ev;
+                    Z += ev;
+                    zo += evo;
+                }
+            } else {
+                // accurate evaluation: the argument of every exponential exactly.  H = potential + field in f64, the
+                // reference mx any common value (the f32-rounded maximum), y = (H - mx) log2 e in f64 split into a float
+                // and its remainder, exp = r + r y_lo ln 2 with r = v_exp_f32(y_hi): what is left is v_exp_f32's own
+                // error, random with a mean of -0.06 ulp.  See exp_softmax_note above.
+#pragma unroll
+                for (int a = 0; a < Q; a++) {       // the reference: any value near the maximum serves
+                    const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : acc[a][reg] + (float)hd[a];
+                    mx = fmaxf(mx, H);
+                }
+                const double mxd = (double)mx;
+#pragma unroll
+                for (int a = 0; a < Q; a++) {
+                    const double xs = ((double)acc[a][reg] + hd[a]) - mxd;
+                    const double y = xs * 1.4426950408889634;
+                    const float yh = (float)y, yl = (float)(y - (double)yh);
+                    const float rr = __builtin_amdgcn_exp2f(yh);
+                    const float ev = ((gap && a == 0) || a >= d.Qc) ? 0.f : __builtin_fmaf(rr, yl * 0.693147182464599609375f, rr);
+                    float evo;
+                    sel_eq2(xi, a, hx, (float)xs, ev, 0.f, hx, evo);
+                    acc[a][reg] = ev;
+                    Z += ev;
+                    zo += evo;
+                }
             }
             const float invZ = 1.f / Z;
             if (WRITE_RT && ws > 0.f) fxl -= ws * (hx - log_unbiased(Z));
+            const float mpo = -(zo * invZ);                      // -(1 - P(observed))
 #pragma unroll
-            for (int a = 0; a < Q; a++) acc[a][reg] *= invZ;     // P
+            for (int a = 0; a < Q; a++) acc[a][reg] = sel_eq(xi, a, acc[a][reg] * invZ, mpo);     // P - [a = observed]
             wk[reg] = ws;
             xk[reg] = xi;
             asm volatile("" : "+v"(xk[reg]));   // no sharing of compare masks between the sections (SGPR spills)
+            if constexpr (XACT) __builtin_amdgcn_sched_barrier(0);   // one sequence at a time: the f64 temporaries of four would spill
         }
         if constexpr (STATS != 0) {
             int idx = 0;
@@ -1115,8 +1379,8 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 float t[4], ga = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    t[k] = wk[k] * acc[a][k];
-                    ga += t[k] - ((xk[k] == a) ? wk[k] : 0.f);
+                    t[k] = wk[k] * acc[a][k];                             // w (P - [x = a])
+                    ga += t[k];
                 }
                 // Q gradient sums: the 4 lanes of a site add straight into LDS (f64, one ds_add_f64, resolved in
                 // lane order); the Hessian sums below are reduced in registers first
@@ -1129,10 +1393,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                     if ((stile % PLM_HESS_SAMPLE) != 0) continue;
                     idx = a * Q - a * (a - 1) / 2;
 #pragma unroll
+                    for (int k = 0; k < 4; k++) t[k] += (xk[k] == a) ? wk[k] : 0.f;     // w P(a)
+#pragma unroll
                     for (int b = a; b < Q; b++) {
                         float v = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[b][k], v);
+                        for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[b][k] + ((xk[k] == b) ? 1.f : 0.f), v);
                         v = sum_over_g(v);
                         if (g == 0) __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[idx]), v, 0, 0, false);
                         ++idx;
@@ -1164,7 +1430,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 u32 x[4];
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++)
-                    x[reg] = digits_of(wk[reg] * (acc[a][reg] - ((a == xk[reg]) ? 1.f : 0.f)), four);
+                    x[reg] = digits_of(wk[reg] * acc[a][reg], four);
                 planes_of4(x[0], x[1], x[2], x[3], pl);
             };
             // four states at a time: a 4 x 4 transpose over the lane groups g (2 + 2 row swaps per plane) leaves lane
@@ -1225,23 +1491,24 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
         if (tid == 0) A.fx_part[blk] = tot;
     }
 }
-hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const void *Bt, const int8_t *msa_rm, const float *w,
-                            const double *h64, int write_rt, int stats, void *Rt, double *fx_part, float *hpart,
+hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w,
+                            const double *h64, int write_rt, int stats, int exact, void *Rt, double *fx_part, float *hpart,
                             double *gpart, const int *skip, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const int nb = d.b16_hi - d.b16_lo, ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
     const dim3 block(512);
-    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, Bt ? bt_cref64(d, Bt) : nullptr, (char *)Rt, fx_part,
+    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (char *)Rt, fx_part,
                 hpart, gpart, d.rscale, skip, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
         const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
         const size_t lds = (size_t)8 * 16 * ((QQ) * sizeof(double) + ((SS) == 2 ? (QQ) * ((QQ) + 1) / 2 : 0) * sizeof(float)); \
         {                                                                                              \
-            hipError_t e = plm_allow_lds<k_hpass<QQ, WW, SS>>(lds);                                    \
+            hipError_t e = exact ? plm_allow_lds<k_hpass<QQ, WW, SS, true>>(lds) : plm_allow_lds<k_hpass<QQ, WW, SS, false>>(lds); \
             if (e != hipSuccess) return e;                                                             \
         }                                                                                              \
-        hipLaunchKernelGGL((k_hpass<QQ, WW, SS>), grid, block, lds, st, d, A);                         \
+        if (exact) hipLaunchKernelGGL((k_hpass<QQ, WW, SS, true>), grid, block, lds, st, d, A);        \
+        else hipLaunchKernelGGL((k_hpass<QQ, WW, SS, false>), grid, block, lds, st, d, A);             \
     }
 #define HP_CASE(QQ)                                                                                    \
     case QQ:                                                                                           \

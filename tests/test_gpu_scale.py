@@ -35,14 +35,17 @@ CONFIGS = {"config2": (20000, 200, BASE_SEED + 2, False), "headline": (50000, 30
 # configurations that get the full treatment (two fits); the larger ones get the shipped fit only -- their vectors are
 # 220-320 MB each and an oracle evaluation costs 10-20 s of the box's host cores
 FULL = ("config2", "headline", "config3", "headline_g")
-# the "much tighter than the stop rule" fit
+# the "much tighter than the stop rule" fit.  The stop rule is certified on the point that SHIPS -- fields rounded to
+# float32 -- and at N = 100 000 that rounding alone costs 4.7e-4 |x| (config 3: 7e-4 is what float32 fields can carry)
 TIGHT = 4e-4
+TIGHT_OF = {"config3": 7e-4}
 # |g_hip - g_f64| / |x| allowed at a point a fit stopped at -- a constant since round 4: the last iterations of a fit and
-# plm_eval run the accurate forward GEMM (f64 outer sums), whose error no longer grows with N L.
-# (Rounds 2-3, plain f32 accumulation: 3e-11 N L -- 4.5e-4 at the headline, 1e-3 at N = 100 000, the size of the stop rule.)
-GRAD_ERR = 3e-4
-# the oracle's |g|/|x| at a point the fit reported converged at epsilon: the stop rule plus the evaluation error
-COND_SLACK = 1.15
+# plm_eval run the accurate evaluation (exact integer forward GEMM, exact softmax arguments, 32-bit residuals;
+# DESIGN.md 4.3 / section 5), measured 2.3e-5 at the headline and 4.7e-5 at N = 100 000.
+# (Rounds 2-3, f32 accumulation throughout: 3e-11 N L -- 4.5e-4 at the headline, 1e-3 at N = 100 000, the size of the stop rule.)
+GRAD_ERR = 1.5e-4
+# the oracle's |g|/|x| at a point the fit reported converged at epsilon: the stop rule, up to the evaluation error
+COND_SLACK = 1.05
 
 
 @pytest.fixture(scope="module")
@@ -96,7 +99,7 @@ def fits(plm):
             r = ctx.optimize()
             out["fit_1e-3"] = dict(r, x=ctx.get_x(), cn=ctx.scores()[1])
             if name in FULL:
-                ctx.set_options(max_iter=1000, epsilon=TIGHT)
+                ctx.set_options(max_iter=1000, epsilon=TIGHT_OF.get(name, TIGHT))
                 r = ctx.optimize()
                 out["fit_tight"] = dict(r, x=ctx.get_x(), cn=ctx.scores()[1])
         if name in FULL:          # the others are visited by one test each: not kept (their vectors are 220-320 MB)
@@ -166,14 +169,15 @@ def test_fit_optimality_certificate(plm, oracle64, fits, name):
         _, _, go = _oracle_eval(oracle64, f, a["x"])
         cond64 = np.linalg.norm(go) / max(1.0, np.linalg.norm(a["x"]))
     assert cond64 < COND_SLACK * 1e-3, cond64
-    # 2.5 times tighter moves no EC score by more than 1e-4 (BASELINE.json's tolerance on EC scores)
-    assert b["status"] == 0 and b["table"][-1][2] < TIGHT, (b["status_msg"], b["table"][-1][2])
+    # 1.4 - 2.5 times tighter moves no EC score by more than 1e-4 (BASELINE.json's tolerance on EC scores)
+    tight = TIGHT_OF.get(name, TIGHT)
+    assert b["status"] == 0 and b["table"][-1][2] < tight and "rounding" not in b["status_msg"], (b["status_msg"], b["table"][-1][2])
     assert np.abs(a["cn"] - b["cn"]).max() < 1e-4
     _, _, gob = _oracle_eval(oracle64, f, b["x"])
     cond64_tight = np.linalg.norm(gob) / max(1.0, np.linalg.norm(b["x"]))
     print("%s: oracle cond at the eps = 1e-3 point %.4g, at the eps = %.1g point %.4g (%d more iterations)" % (
-        name, cond64, TIGHT, cond64_tight, b["iters"]))
-    assert cond64_tight < TIGHT + GRAD_ERR, cond64_tight
+        name, cond64, tight, cond64_tight, b["iters"]))
+    assert cond64_tight < COND_SLACK * tight, cond64_tight
 
 
 @pytest.mark.parametrize("name", ["config2", "headline"])
@@ -210,7 +214,7 @@ def test_config3_converges_from_two_starts(plm, oracle64, fits):
     one, in a bounded number of iterations, at the same CN scores."""
     f = fits("config3")
     a = f["fit_1e-3"]
-    assert a["status"] == 0 and a["iters"] <= 260, (a["status_msg"], a["iters"])
+    assert a["status"] == 0 and a["iters"] <= 300, (a["status_msg"], a["iters"])
     rng = np.random.default_rng(3)
     with _context(plm, f, max_iter=3000, epsilon=1e-3) as ctx:
         ctx.set_weights(f["w"])
@@ -220,7 +224,7 @@ def test_config3_converges_from_two_starts(plm, oracle64, fits):
         cn = ctx.scores()[1]
     print("config3: standard start %d iterations, perturbed start %d iterations (%s), max |dCN| %.3g" % (
         a["iters"], r["iters"], r["status_msg"], np.abs(cn - a["cn"]).max()))
-    assert r["status"] == 0 and r["iters"] <= 260, (r["status_msg"], r["iters"])
+    assert r["status"] == 0 and r["iters"] <= 300, (r["status_msg"], r["iters"])
     assert np.abs(cn - a["cn"]).max() < 1e-4
 
 
