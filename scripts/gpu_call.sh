@@ -1,6 +1,6 @@
 set -u
-OUT=gpurun_out/r4c18; mkdir -p $OUT
+OUT=gpurun_out/r4c20; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 300 python scripts/small_fit_probe.py > $OUT/small.log 2>&1; grep -v "trial" $OUT/small.log | grep mode
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_abi.py tests/test_gpu_variants.py tests/test_reference_pipeline.py tests/test_host_layer.py -m gpu -q -p no:cacheprovider > $OUT/pytest_parity.log 2>&1
-tail -12 $OUT/pytest_parity.log | cut -c1-200
+python scripts/time_kernels.py > $OUT/tk1.log 2>&1; tail -1 $OUT/tk1.log
+PLM_FWD_NSG=3 python scripts/time_kernels.py > $OUT/tk3.log 2>&1; tail -1 $OUT/tk3.log
+PLM_FWD_NSG=3 timeout 200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "eval_matches or fit_reaches or gap_mode or edge_shapes" 2>&1 | tail -2
