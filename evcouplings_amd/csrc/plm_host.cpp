@@ -134,7 +134,7 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     memset(&d, 0, sizeof d);
     if (p.n_seqs <= 0 || p.n_sites <= 1) return fail(PLM_EINVAL, "need n_seqs > 0 and n_sites > 1");
     if (!plm_q_supported(p.n_states))
-        return fail(PLM_EUNSUPPORTED, "alphabet size %d outside 2..21", p.n_states);
+        return fail(PLM_EUNSUPPORTED, "alphabet size %d outside 2..32", p.n_states);
     const int nshards = p.n_shards > 0 ? p.n_shards : 1;
     if (p.shard < 0 || p.shard >= nshards) return fail(PLM_EINVAL, "shard %d outside 0..%d", p.shard, nshards - 1);
     d.N = p.n_seqs;
@@ -436,7 +436,9 @@ int ctx_eval_enqueue(plm_ctx *c) {
 bool vp_enabled(const plm_ctx *c) {
     // lambda_h = 0: the per-site Hessians are singular along the softmax gauge direction (the Newton solver has no
     // pivoting) -- such a problem runs the joint path
-    return !(c->prob.flags & PLM_FLAG_JOINT_LBFGS) && (c->d.nshards == 1 || c->d.sharded) && c->prob.lambda_h > 0;
+    // (alphabets above 21 symbols run the 32-state instantiation, which has no field solver: joint path)
+    return !(c->prob.flags & PLM_FLAG_JOINT_LBFGS) && (c->d.nshards == 1 || c->d.sharded) && c->prob.lambda_h > 0 &&
+           c->d.Q <= 21;
 }
 int vp_alloc(plm_ctx *c) {
     if (c->hj) return PLM_OK;
@@ -1824,7 +1826,8 @@ static int energies_impl(const int8_t *seqs, int32_t n, int32_t L, int32_t q, co
     std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE);
     for (int s = 0; s < d.N; s++) memcpy(&rm[(size_t)s * d.Lp32], seqs + (size_t)s * d.L, d.L);
     const int nblk = d.b16_hi - d.b16_lo;
-    const size_t out_dev_floats = potentials ? (size_t)d.N * d.L * d.Qc : (size_t)d.Np * nblk * 2;
+    const int ngrp = plm_fwd_groups(d.Q, 0);     // energy partials per (sequence, site block, state group)
+    const size_t out_dev_floats = potentials ? (size_t)d.N * d.L * d.Qc : (size_t)d.Np * nblk * ngrp * 2;
     int8_t *msa_rm = nullptr;
     float *canon = nullptr, *x = nullptr, *outd = nullptr;
     char *Bt = nullptr;

@@ -234,13 +234,17 @@ static int plm_current_device() {
     (void)hipGetDevice(&dev);
     return (dev >= 0 && dev < PLM_MAX_DEVICES) ? dev : 0;
 }
-// Any alphabet of 2..21 symbols runs on the next instantiated size (4, 5, 20, 21): the surplus states are dead
+// Any alphabet of 2..32 symbols runs on the next instantiated size (4, 5, 20, 21, 32): the surplus states are dead
 // padding of the native layout (never observed, masked out of every softmax, parameters structurally zero), the
-// canonical arrays at the API keep the problem's own size (PlmDims::Qc).
-bool plm_q_supported(int q) { return q >= 2 && q <= 21; }
-int plm_q_template(int q) { return q <= 4 ? 4 : q == 5 ? 5 : q <= 20 ? 20 : 21; }
+// canonical arrays at the API keep the problem's own size (PlmDims::Qc).  The 32-state instantiation (alphabets of
+// 22..32 symbols: proteins with ambiguity codes, extended nucleotide alphabets) runs the forward GEMM with two state
+// groups per workgroup (2 x 32 accumulator fragments would not fit a wave) and has no field solver: such problems take
+// the joint L-BFGS path (plm_host.cpp vp_enabled).
+bool plm_q_supported(int q) { return q >= 2 && q <= 32; }
+int plm_q_template(int q) { return q <= 4 ? 4 : q == 5 ? 5 : q <= 20 ? 20 : q == 21 ? 21 : 32; }
 void plm_pick_tile(int q, int *fm, int *fn) {
-    if (q == 21) { *fm = 7; *fn = 7; }
+    if (q == 32) { *fm = 8; *fn = 5; }
+    else if (q == 21) { *fm = 7; *fn = 7; }
     else if (q == 20) { *fm = 5; *fn = 5; }
     else if (q == 5) { *fm = 5; *fn = 5; }
     else { *fm = 4; *fn = 4; }
@@ -1113,8 +1117,8 @@ template <auto KERNEL> static hipError_t plm_allow_lds(size_t lds) {
 
 // state groups per workgroup of the exact forward GEMM (56 + 112 registers of accumulators and f64 sums at 7 states)
 int plm_fwd_groups(int q, int exact) {
-    if (!exact) return 1;
-    return q == 21 ? 3 : q == 20 ? 4 : 1;
+    if (!exact) return q == 32 ? 2 : 1;
+    return q == 32 ? 8 : q == 21 ? 3 : q == 20 ? 4 : 1;
 }
 template <int Q, int MODE, int NSG, bool EXACT>
 static hipError_t fwd_launch(const PlmDims &d, const FwdArgs &A, hipStream_t st) {
@@ -1134,18 +1138,19 @@ static hipError_t fwd_launch(const PlmDims &d, const FwdArgs &A, hipStream_t st)
 }
 static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, int exact, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
-#define FWD_CASE(QQ, NX)                                                                               \
+#define FWD_CASE(QQ, NP, NX)      /* NP / NX: state groups per workgroup of the plain / the exact kernel (plm_fwd_groups) */ \
     case QQ:                                                                                           \
-        if (mode == FWD_ENERGY) return fwd_launch<QQ, FWD_ENERGY, 1, false>(d, A, st);                 \
+        if (mode == FWD_ENERGY) return fwd_launch<QQ, FWD_ENERGY, NP, false>(d, A, st);                \
         if (mode == FWD_POTENTIALS && exact) return fwd_launch<QQ, FWD_POTENTIALS, NX, true>(d, A, st); \
-        if (mode == FWD_POTENTIALS) return fwd_launch<QQ, FWD_POTENTIALS, 1, false>(d, A, st);         \
+        if (mode == FWD_POTENTIALS) return fwd_launch<QQ, FWD_POTENTIALS, NP, false>(d, A, st);        \
         if (exact) return fwd_launch<QQ, FWD_STORE, NX, true>(d, A, st);                               \
-        return fwd_launch<QQ, FWD_STORE, 1, false>(d, A, st);
+        return fwd_launch<QQ, FWD_STORE, NP, false>(d, A, st);
     switch (d.Q) {
-        FWD_CASE(21, 3)
-        FWD_CASE(20, 4)
-        FWD_CASE(5, 1)
-        FWD_CASE(4, 1)
+        FWD_CASE(32, 2, 8)
+        FWD_CASE(21, 1, 3)
+        FWD_CASE(20, 1, 4)
+        FWD_CASE(5, 1, 1)
+        FWD_CASE(4, 1, 1)
     default:
         return hipErrorInvalidValue;
     }
@@ -1523,6 +1528,10 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
         } else HP_LAUNCH(QQ, false, 1)                                                                 \
         break;
     switch (d.Q) {
+    case 32:        // no field solver at this size (joint L-BFGS only): the residual pass alone
+        if (!write_rt || stats != 0) return hipErrorInvalidValue;
+        HP_LAUNCH(32, true, 0)
+        break;
         HP_CASE(21)
         HP_CASE(20)
         HP_CASE(5)
@@ -1739,7 +1748,7 @@ __global__ __launch_bounds__(256) void k_energy_sum(const float2 *__restrict__ p
 }
 hipError_t plm_launch_energy_sum(const PlmDims &d, const float *part, double *out, hipStream_t st) {
     hipLaunchKernelGGL(k_energy_sum, dim3((d.N + 255) / 256), dim3(256), 0, st, (const float2 *)part, d.N,
-                       d.b16_hi - d.b16_lo, out);
+                       (d.b16_hi - d.b16_lo) * plm_fwd_groups(d.Q, 0), out);
     return hipGetLastError();
 }
 
@@ -1940,6 +1949,7 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
         hipLaunchKernelGGL((k_bwd<QQ, M, N>), grid, block, lds, st, d, msa_cm, (const char *)Rt, (int *)G, run);   \
     } break;
     switch (d.Q) {
+        BWD_CASE(32, 8, 5)
         BWD_CASE(21, 7, 7)
         BWD_CASE(20, 5, 5)
         BWD_CASE(5, 5, 5)

@@ -359,7 +359,7 @@ def test_gap_mode_fit_and_files(plm, oracle64, tmp_path):
 
 
 # ---------------------------------------------------------------- edge cases
-@pytest.mark.parametrize("N,L,q", [(1, 2, 21), (3, 17, 21), (33, 33, 21), (300, 47, 20), (260, 16, 5), (64, 50, 4),
+@pytest.mark.parametrize("N,L,q", [(1, 2, 21), (3, 17, 21), (33, 33, 21), (300, 47, 20), (260, 16, 5), (64, 50, 4), (280, 40, 27), (257, 33, 32),
                                    (200, 20, 2), (150, 33, 3), (220, 40, 7), (180, 35, 13), (90, 18, 19)])
 def test_edge_shapes_eval_and_reweight(plm, oracle64, N, L, q):
     """single sequence, L below/above the 16- and 32-site tiles, every instantiated alphabet size, and alphabets
@@ -397,7 +397,7 @@ def test_invalid_inputs_fail_with_error_codes(plm):
     bad = good.copy()
     bad[2, 3] = 21
     for call, code in ((lambda: plm.fit(bad, q=21, max_iter=1), -1),          # state outside 0..q-1
-                       (lambda: plm.fit(good, q=22, max_iter=1), -4),          # alphabets above 21 symbols
+                       (lambda: plm.fit(good, q=33, max_iter=1), -4),          # alphabets above 32 symbols
                        (lambda: plm.fit(good, q=1, max_iter=1), -4),
                        (lambda: plm.fit(good[:, :1], q=21, max_iter=1), -1),   # fewer than 2 sites
                        (lambda: plm.evaluate(good, -np.ones(8, np.float32), 21, 0.01, 1.0,
@@ -650,7 +650,7 @@ def test_alignment_accel_drop_ins_match_reference_golden(plm, golden_dir):
     assert mod.frequencies is None
 
 
-@pytest.mark.parametrize("q,L,N", [(20, 70, 300), (5, 45, 260), (4, 33, 100), (7, 40, 120), (13, 25, 80)])
+@pytest.mark.parametrize("q,L,N", [(20, 70, 300), (5, 45, 260), (4, 33, 100), (7, 40, 120), (13, 25, 80), (28, 36, 90), (32, 50, 300)])
 def test_hamiltonians_other_alphabets(plm, oracle64, q, L, N):
     """energies / single-mutant matrix for the other alphabets (q = 20: gap-free protein models; 7, 13: padded)."""
     rng = np.random.default_rng(q)
@@ -978,10 +978,12 @@ def test_convention_switches_match_the_oracle(plm, oracle64, conv):
         oracle64.set_conventions(0)
 
 
-@pytest.mark.parametrize("q,ignore_gaps", [(7, False), (13, False), (9, True), (3, False)])
+@pytest.mark.parametrize("q,ignore_gaps", [(7, False), (13, False), (9, True), (3, False), (25, False), (32, False), (26, True)])
 def test_fit_arbitrary_alphabet_reaches_the_oracle_optimum(plm, oracle64, q, ignore_gaps):
-    """Any alphabet of up to 21 symbols (couplings/protocol.py:139-155 passes `alphabet` through): the fit runs on the
-    next instantiated size with the surplus states dead, and lands on the oracle's optimum for the real alphabet."""
+    """Any alphabet of up to 32 symbols (couplings/protocol.py:139-155 and tools.py:230-233 pass `alphabet` through): the
+    fit runs on the next instantiated size with the surplus states dead, and lands on the oracle's optimum for the real
+    alphabet.  Above 21 symbols that is the 32-state instantiation (forward GEMM with two state groups per workgroup,
+    joint L-BFGS: it has no field solver)."""
     rng = np.random.default_rng(q)
     N, L = 400, 22
     msa = rng.integers(0, q, size=(N, L)).astype(np.int8)
