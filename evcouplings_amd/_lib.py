@@ -33,6 +33,7 @@ class PlmProblem(C.Structure):
         ("lambda_h", C.c_double), ("lambda_j", C.c_double),
         ("max_iter", C.c_int32), ("epsilon", C.c_double), ("lbfgs_m", C.c_int32),
         ("n_shards", C.c_int32), ("shard", C.c_int32), ("flags", C.c_int32),
+        ("lambda_group", C.c_double),
     ]
 
 

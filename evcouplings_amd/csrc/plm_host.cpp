@@ -268,6 +268,7 @@ struct plm_ctx {
     float *x = nullptr, *g = nullptr, *xp = nullptr, *gp = nullptr, *dir = nullptr, *hist = nullptr;
     float *xa = nullptr, *ga = nullptr;   // anchor point of the next curvature pair when pairs had to be skipped (lazy)
     float *canon = nullptr;    // canonical-layout staging (n_canon floats, + L*L for fn)
+    float *pair_n2 = nullptr;  // squared norms of the coupling blocks (group regulariser only)
     float *dinv = nullptr;     // H0 diagonal of the preconditioned L-BFGS (n_local floats), built by plm_ctx_optimize
     // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
     float *hj = nullptr, *hpart = nullptr;
@@ -364,6 +365,13 @@ int ctx_allreduce_scalars(plm_ctx *c, int first, int count) {
 
 // forward half of an evaluation at the fields and couplings of c->x (joint L-BFGS, plm_ctx_eval): the GEMM stores the
 // coupling potentials, one pass of the field kernel turns them into residuals (Rt) and -log P partials
+// group regulariser (lambda_group > 0): squared norms of the coupling blocks of the current x, for k_assemble
+int group_norms(plm_ctx *c) {
+    if (!(c->prob.lambda_group > 0)) return PLM_OK;
+    if (!c->pair_n2) PLM_TRY(dalloc(&c->pair_n2, (size_t)std::max<int64_t>(1, c->d.np_own) * 256));
+    HIP_TRY(plm_launch_pair_norms(c->d, c->x, c->pair_n2, c->st));
+    return PLM_OK;
+}
 int vp_alloc(plm_ctx *c);
 int forward_at_x(plm_ctx *c) {
     const PlmDims &d = c->d;
@@ -387,8 +395,9 @@ int ctx_eval_enqueue_sharded(plm_ctx *c) {
     if (d.nblk_own > 0) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
     HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
     PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
+    PLM_TRY(group_norms(c));
     HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, c->ghalo, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
-                                c->reg_part, 0, 0.f, c->st));
+                                c->reg_part, 0, 0.f, c->pair_n2, (float)c->prob.lambda_group, c->st));
     HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d), c->scal,
                                  c->st));
     c->n_evals++;
@@ -419,8 +428,9 @@ int ctx_eval_enqueue(plm_ctx *c) {
         n_shard_nll = d.nshards;
         shard_nll = (const double *)((char *)c->gather + slab - 256);
     }
+    PLM_TRY(group_norms(c));
     HIP_TRY(plm_launch_assemble(d, Gsrc, ks_count, nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
-                                c->reg_part, 0, 0.f, c->st));
+                                c->reg_part, 0, 0.f, c->pair_n2, (float)c->prob.lambda_group, c->st));
     HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), shard_nll, n_shard_nll, c->reg_part,
                                  plm_reg_parts(d), c->scal, c->st));
     c->n_evals++;
@@ -525,8 +535,9 @@ int vp_stage3(plm_ctx *c, bool conditional, float *gout = nullptr, int mode = 2)
         PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
     }
     // mode 2: gradient of the reduced objective (field part zero), regulariser sums as usual
+    PLM_TRY(group_norms(c));
     HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, d.sharded ? c->ghalo : nullptr, c->x, gout, c->prob.lambda_h,
-                                c->prob.lambda_j, c->reg_part, mode, 0.f, c->st));
+                                c->prob.lambda_j, c->reg_part, mode, 0.f, c->pair_n2, (float)c->prob.lambda_group, c->st));
     if (mode == 2)
         HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d), c->scal,
                                      c->st));
@@ -738,7 +749,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
                     c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->vp_flag,
-                    c->xa, c->ga};
+                    c->xa, c->ga, c->pair_n2};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (c->h_scal) hipHostFree(c->h_scal);
@@ -757,7 +768,8 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     PlmDims d;
     PLM_TRY(make_dims(*prob, opt, &d));
     if (!(prob->theta_id >= 0.0 && prob->theta_id <= 1.0)) return fail(PLM_EINVAL, "theta_id must be in [0,1]");
-    if (prob->lambda_h < 0 || prob->lambda_j < 0) return fail(PLM_EINVAL, "negative regularisation strength");
+    if (prob->lambda_h < 0 || prob->lambda_j < 0 || prob->lambda_group < 0)
+        return fail(PLM_EINVAL, "negative regularisation strength");
     for (size_t k = 0; k < (size_t)d.N * d.L; k++)
         if (prob->msa[k] < 0 || prob->msa[k] >= d.Qc)
             return fail(PLM_EINVAL, "msa[%zu] = %d outside 0..%d", k, (int)prob->msa[k], d.Qc - 1);
@@ -1007,7 +1019,7 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     // gap mode: raw weighted counts come back (factor 1) and are normalised per site / per pair over
     // the ungapped sequences on the host
     HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->g, c->g, 0.f, 0.f, c->reg_part, 1,
-                                d.gap_mode ? 1.f : (float)(1.0 / c->n_eff), c->st));
+                                d.gap_mode ? 1.f : (float)(1.0 / c->n_eff), nullptr, 0.f, c->st));
     HIP_TRY(plm_launch_native_to_canon(d, c->g, c->canon, c->st));
     c->h_fi.resize((size_t)d.L * d.Qc);
     HIP_TRY(hipMemcpyAsync(c->h_fi.data(), c->canon, sizeof(float) * d.L * d.Qc, hipMemcpyDeviceToHost, c->st));
@@ -1651,7 +1663,7 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
         HIP_TRY(hipEventRecord(ev[3], c->st));
         HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
-                                    c->reg_part, vp ? 2 : 0, 0.f, c->st));
+                                    c->reg_part, vp ? 2 : 0, 0.f, nullptr, 0.f, c->st));
         HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d),
                                      c->scal, c->st));
         HIP_TRY(hipEventRecord(ev[4], c->st));

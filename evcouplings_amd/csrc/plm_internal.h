@@ -192,9 +192,11 @@ hipError_t plm_launch_slab_reduce(const PlmDims &d, const int32_t *G, float *sla
 // g = gscale * (G + G^T) + 2 lambda x ; mode 1: marginals (out = G / neff, no symmetrisation).  G: the int32 plane /
 // K-range partials of k_bwd (ks_count = d.ksplit), or with ks_count = 0 a float slab already combined (the gathered
 // slabs of the replicated multi-shard mode)
+// pair_n2 / lambda_g: the group regulariser (plm_launch_pair_norms of the same x first; lambda_g = 0: none)
 hipError_t plm_launch_assemble(const PlmDims &d, const void *G, int ks_count, const float *ghalo,
                                const float *x, float *g, float lambda_h, float lambda_j, double *reg_part,
-                               int mode, float inv_neff, hipStream_t st);
+                               int mode, float inv_neff, const float *pair_n2, float lambda_g, hipStream_t st);
+hipError_t plm_launch_pair_norms(const PlmDims &d, const float *x, float *n2, hipStream_t st);
 // sharded-state exchange staging: blocks of Q*Q*256 floats
 #define PLM_BLOCK_FLOATS(d) ((size_t)(d).Q * (d).Q * 256)
 hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, hipStream_t st);

@@ -2008,11 +2008,27 @@ __device__ __forceinline__ size_t g_frag(const PlmDims &d, int ks_count, size_t 
     const int nfl = (block16 - plm_shard_lo(d, sh)) * d.Q + state;
     return (size_t)sh * slab_stride + ((size_t)mf * d.nnfl + nfl) * 256;
 }
+// squared Frobenius norm of every coupling block J_ij of an own block pair: n2[pair][ii * 16 + jj] (group regulariser)
+__global__ __launch_bounds__(256) void k_pair_norms(PlmDims d, const float *__restrict__ x, float *__restrict__ n2) {
+    const size_t base = d.nh_pad_l + (size_t)blockIdx.x * d.Q * d.Q * 256 + threadIdx.x;
+    double s = 0;
+    for (int ab = 0; ab < d.Q * d.Q; ab++) {
+        const float v = x[base + (size_t)ab * 256];
+        s += (double)v * (double)v;
+    }
+    n2[(size_t)blockIdx.x * 256 + threadIdx.x] = (float)s;
+}
+hipError_t plm_launch_pair_norms(const PlmDims &d, const float *x, float *n2, hipStream_t st) {
+    if (d.np_own <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pair_norms, dim3((unsigned)d.np_own), dim3(256), 0, st, d, x, n2);
+    return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restrict__ G, int ks_count,
                                                  size_t slab_stride, const float *__restrict__ ghalo,
                                                  const float *__restrict__ x,
                                                  float *__restrict__ gout, float lambda_j,
-                                                 double *__restrict__ reg_part, int mode, float scale) {
+                                                 double *__restrict__ reg_part, int mode, float scale,
+                                                 const float *__restrict__ pair_n2, float lambda_g) {
     __shared__ double red[4];
     const int a = blockIdx.y;
     // decode the own block pair number blockIdx.x (pairs are numbered I-major from (own_lo, own_lo))
@@ -2032,6 +2048,10 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restr
     const bool remote = d.sharded && J >= d.own_hi;
     const size_t hoff = remote ? (((size_t)(J - d.own_hi) * d.nblk_own + (I - d.own_lo)) * d.Q + a) * d.Q * 256 + t2 : 0;
     double reg = 0;
+    // group regulariser lambda_g sum_{i<j} sqrt(|J_ij|^2 + delta^2) (plm_hip.h PLM_GROUP_DELTA): gradient lambda_g J / norm
+    const float gnorm = (lambda_g > 0.f && valid) ? sqrtf(pair_n2[(size_t)blockIdx.x * 256 + threadIdx.x] +
+                                                          (float)(PLM_GROUP_DELTA * PLM_GROUP_DELTA)) : 1.f;
+    const float gcoef = (lambda_g > 0.f) ? lambda_g / gnorm : 0.f;
     for (int b = 0; b < d.Q; b++) {
         const size_t o1 = g_frag(d, ks_count, slab_stride, I, a, J * d.Q + b) + t1;
         const float v = g_value(G, o1, ks_count, kstride, d.nplanes);
@@ -2046,7 +2066,7 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restr
             }
             const float xv = x[xoff + (size_t)b * 256];
             const bool live = valid && !(d.gap_mode && (a == 0 || b == 0)) && a < d.Qc && b < d.Qc;
-            out = live ? fmaf(scale, v + v2, 2.f * lambda_j * xv) : 0.f;
+            out = live ? fmaf(scale, v + v2, (2.f * lambda_j + gcoef) * xv) : 0.f;
             if (live) reg += (double)xv * (double)xv;
         } else {
             out = valid ? scale * v : 0.f;
@@ -2054,8 +2074,9 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restr
         gout[xoff + (size_t)b * 256] = out;
     }
     if (mode == 0) {
-        const double t = block_reduce_sum(reg, red);
-        if (threadIdx.x == 0) reg_part[(size_t)blockIdx.x * d.Q + a] = (double)lambda_j * t;
+        // the group term of a site pair is counted once: by the block of state a = 0
+        const double t = block_reduce_sum((double)lambda_j * reg + ((lambda_g > 0.f && a == 0 && valid) ? (double)lambda_g * gnorm : 0.0), red);
+        if (threadIdx.x == 0) reg_part[(size_t)blockIdx.x * d.Q + a] = t;
     }
 }
 // field part: column sums of the residuals arrive through the "ones" row fragment
@@ -2095,14 +2116,14 @@ __global__ __launch_bounds__(256) void k_assemble_h(PlmDims d, const void *__res
 }
 hipError_t plm_launch_assemble(const PlmDims &d, const void *G, int ks_count, const float *ghalo, const float *x,
                                float *g, float lambda_h, float lambda_j, double *reg_part, int mode, float inv_neff,
-                               hipStream_t st) {
+                               const float *pair_n2, float lambda_g, hipStream_t st) {
     // replicated multi-shard mode reads the gathered float slabs (one per shard, ks_count = 0); otherwise G holds this
     // shard's own int32 plane / K-range partials
     const size_t slab_stride = (d.sharded || ks_count > 0) ? 0 : plm_slab_bytes(d) / 4;
     const float scale = d.gscale * (mode == 1 ? inv_neff : 1.f);
     if (d.np_own > 0)
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride,
-                           ghalo, x, g, lambda_j, reg_part, mode == 2 ? 0 : mode, scale);
+                           ghalo, x, g, lambda_j, reg_part, mode == 2 ? 0 : mode, scale, pair_n2, mode == 1 ? 0.f : lambda_g);
     hipLaunchKernelGGL(k_assemble_h, dim3((unsigned)(d.nh_pad_l / 256)), dim3(256), 0, st, d, G, ks_count, slab_stride, x, g, lambda_h,
                        reg_part, mode, scale);
     return hipGetLastError();

@@ -287,13 +287,14 @@ def _strip_gaps(x, L, q):
 
 
 def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m, n_shards, shard,
-             ignore_gaps=False, sharded_state=False, precond=False, joint=False, conventions=0):
+             ignore_gaps=False, sharded_state=False, precond=False, joint=False, conventions=0, lambda_group=0.0):
     N, L = msa.shape
     p = PlmProblem()
     p.n_seqs, p.n_sites, p.n_states = N, L, q
     p.msa = msa.ctypes.data
     p.theta_id, p.scale = float(theta_id), float(scale)
     p.lambda_h, p.lambda_j = float(lambda_h), float(lambda_j)
+    p.lambda_group = float(lambda_group or 0.0)
     p.max_iter, p.epsilon, p.lbfgs_m = int(max_iter), float(epsilon), int(lbfgs_m)
     p.n_shards, p.shard = int(n_shards), int(shard)
     p.flags = ((FLAG_IGNORE_GAPS if ignore_gaps else 0) | (FLAG_SHARDED_STATE if sharded_state else 0) |
@@ -304,7 +305,7 @@ def _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbf
 def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_iter=100,
         epsilon=1e-3, lbfgs_m=6, device=0, stream=0, callback=None, n_shards=1, shard=0,
         exchange=None, want_fij=True, ignore_gaps=False, collective=None, precond=False, joint=False, conventions=0,
-        rccl_id=None):
+        rccl_id=None, lambda_group=0.0):
     """
     Whole couplings inference: reweight -> marginals -> L-BFGS -> scores.
 
@@ -321,6 +322,7 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     (PLM_FLAG_JOINT_LBFGS) instead of the default variable projection (fields solved by Newton for every trial
     couplings, ~10-20x fewer iterations to the same optimum); precond=True gives L-BFGS a diagonal initial Hessian
     (PLM_FLAG_PRECOND).  conventions: PLM_CONV_* bits (CONV_* above), the selectable conventions of plmc.
+    lambda_group: run_plmc's lambda_g (plmc -lg), the group regulariser lambda_group * sum_{i<j} sqrt(|J_ij|^2 + 1e-8).
     Returns a dict of numpy arrays and scalars.
     """
     lib = _lib.load()
@@ -345,7 +347,7 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
         xcb = C.cast(None, _lib.EXCHANGE_CB)
     prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
                     n_shards, shard, ignore_gaps, sharded_state=collective is not None or rccl_id is not None,
-                    precond=precond, joint=joint, conventions=conventions)
+                    precond=precond, joint=joint, conventions=conventions, lambda_group=lambda_group)
     if rccl_id is not None:
         idbuf = C.create_string_buffer(bytes(rccl_id), RCCL_ID_BYTES)
         check(lib.plm_fit_sharded_rccl(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
@@ -397,7 +399,7 @@ class PlmContext:
 
     def __init__(self, msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None,
                  max_iter=100, epsilon=1e-3, lbfgs_m=6, device=0, stream=0, n_shards=1, shard=0,
-                 ignore_gaps=False, sharded_state=False, precond=False, joint=False, conventions=0):
+                 ignore_gaps=False, sharded_state=False, precond=False, joint=False, conventions=0, lambda_group=0.0):
         self.lib = _lib.load()
         msa = _msa(msa)
         self.N, self.L = msa.shape
@@ -406,7 +408,7 @@ class PlmContext:
         self.qm = q - 1 if ignore_gaps else q      # model states (layout of x, g, fi, fij at this API)
         self.lambda_j = default_lambda_j(self.L, self.qm) if lambda_j is None else lambda_j
         prob = _problem(msa, q, theta_id, scale, lambda_h, self.lambda_j, max_iter, epsilon, lbfgs_m,
-                        n_shards, shard, ignore_gaps, sharded_state, precond, joint, conventions)
+                        n_shards, shard, ignore_gaps, sharded_state, precond, joint, conventions, lambda_group)
         self._h = C.c_void_p()
         check(self.lib.plm_ctx_create(C.byref(prob), int(device), C.c_void_p(int(stream) or None),
                                       C.byref(self._h)))

@@ -114,8 +114,6 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
     if not _valid_file(alignment):
         raise ResourceError("Alignment file does not exist: {}".format(alignment))
-    if lambda_g not in (None, 0, 0.0):
-        raise ExternalToolError("group-L1 regularisation (lambda_group != 0) is not supported by the HIP solver")
     for path in (couplings_file, param_file):
         if path:
             os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -124,6 +122,12 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
     scale = DEFAULTS["scale"] if scale is None else float(scale)
     lambda_h = DEFAULTS["lambda_h"] if lambda_h is None else float(lambda_h)
     lambda_J = DEFAULTS["lambda_J"] if lambda_J is None else float(lambda_J)
+    try:
+        lambda_g = DEFAULTS["lambda_g"] if lambda_g is None else float(lambda_g)  # plmc -lg (tools.py:252-253)
+    except (TypeError, ValueError):
+        raise ExternalToolError("lambda_g must be a number, got {!r}".format(lambda_g))
+    if lambda_g < 0:
+        raise ExternalToolError("lambda_g must not be negative, got {!r}".format(lambda_g))
     if iterations is None:
         iterations = DEFAULTS["iterations"]
     elif isinstance(iterations, str):
@@ -157,7 +161,7 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
     fit_kwargs = dict(q=q, ignore_gaps=bool(ignore_gaps), theta_id=theta, scale=scale, lambda_h=lambda_h, lambda_j=lambda_J,
                       max_iter=iterations, epsilon=DEFAULTS["epsilon"] if epsilon is None else float(epsilon),
-                      lbfgs_m=lbfgs_m, callback=callback, joint=(solver == "joint"),
+                      lbfgs_m=lbfgs_m, callback=callback, joint=(solver == "joint"), lambda_group=lambda_g,
                       # PLM_CONV_* switches: explicit, or the environment variable PLM_HIP_CONVENTIONS
                       conventions=plm.conventions_from_env(conventions))
     try:
@@ -190,7 +194,7 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
             n_invalid=enc.n_total_seqs - enc.n_valid_seqs,
             # plmc stores its iteration setting here (SURVEY.md App. A field 1); "max" (0 = until converged) is
             # recorded as the number of iterations actually taken
-            num_iter=iterations if iterations > 0 else int(res["iters"]), theta=1.0 - theta, lambda_h=lambda_h, lambda_j=lambda_J, lambda_group=0.0,
+            num_iter=iterations if iterations > 0 else int(res["iters"]), theta=1.0 - theta, lambda_h=lambda_h, lambda_j=lambda_J, lambda_group=lambda_g,
             n_eff=res["n_eff"], alphabet=model_alphabet, weights=weights, target_seq=enc.target_seq,
             index_list=enc.index_list, fi=res["fi"], hi=res["hi"], fij=res["fij"], jij=res["jij"])
     if not _valid_file(couplings_file):

@@ -62,7 +62,11 @@ typedef struct {
     int32_t n_shards;    /* site shards (GPUs); 1 = single GPU */
     int32_t shard;       /* this process' shard index */
     int32_t flags;       /* PLM_FLAG_* */
+    double lambda_group; /* run_plmc's lambda_g (plmc -lg, tools.py:252-253): group regulariser on the coupling blocks,
+                            lambda_group * sum_{i<j} sqrt(|J_ij|_F^2 + PLM_GROUP_DELTA^2); 0 = none */
 } plm_problem_t;
+/* smoothing of the group norm at the origin (the start point is J = 0, where the bare norm has no gradient) */
+#define PLM_GROUP_DELTA 1e-4
 
 #define PLM_FLAG_NONE 0
 #define PLM_FLAG_VERBOSE 1

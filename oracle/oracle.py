@@ -76,6 +76,13 @@ class Oracle:
         f.restype = None
         f(int(conv))
 
+    def set_lambda_group(self, lg):
+        """group regulariser lambda_g * sum_{i<j} sqrt(|J_ij|^2 + 1e-8) of every later eval / fit (process-global; 0 = off)"""
+        f = self._f("set_lambda_group")
+        f.argtypes = [C.c_double]
+        f.restype = None
+        f(float(lg))
+
     def threshold(self, L, theta_id):
         f = self._f("threshold")
         f.argtypes = [C.c_int, C.c_double]

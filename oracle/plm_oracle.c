@@ -96,6 +96,29 @@ int PLMO_NAME(num_threads)(void) {
  * length, 256 -g frequencies normalised by N_eff, 512 Frobenius norm without the gap state. */
 static int g_conv = 0;
 void PLMO_NAME(set_conventions)(int conv) { g_conv = conv; }
+/* Group regulariser (run_plmc's lambda_g -> plmc -lg, evcouplings/couplings/tools.py:252-253): process-global like the
+ * conventions, 0 = off.  PARITY UNPINNED: plmc's implementation cannot be read here; the term restated is the group
+ * lasso its option text names, smoothed at the origin so that L-BFGS can run on it:
+ *     R_g = lambda_g * sum_{i<j} sqrt(|J_ij|_F^2 + delta^2),  delta = 1e-4      (PLM_GROUP_DELTA in include/plm_hip.h)
+ * dR_g/dJ_ij(a,b) = lambda_g J_ij(a,b) / sqrt(|J_ij|_F^2 + delta^2). */
+static double g_lambda_group = 0.0;
+#define PLMO_GROUP_DELTA 1e-4
+void PLMO_NAME(set_lambda_group)(double lg) { g_lambda_group = lg; }
+/* adds the group term of every pair block to the gradient (blocks of qm x qm at J, gradient at gj) and returns its value */
+static double group_term(const real *J, real *gj, int L, int qm) {
+    if (!(g_lambda_group > 0)) return 0.0;
+    const size_t qq = (size_t)qm * qm;
+    double tot = 0;
+#pragma omp parallel for schedule(static) reduction(+ : tot)
+    for (long p = 0; p < (long)L * (L - 1) / 2; p++) {
+        double n2 = 0;
+        for (size_t k = 0; k < qq; k++) n2 += (double)J[(size_t)p * qq + k] * (double)J[(size_t)p * qq + k];
+        const double nrm = sqrt(n2 + PLMO_GROUP_DELTA * PLMO_GROUP_DELTA);
+        tot += g_lambda_group * nrm;
+        for (size_t k = 0; k < qq; k++) gj[(size_t)p * qq + k] += (real)(g_lambda_group * (double)J[(size_t)p * qq + k] / nrm);
+    }
+    return tot;
+}
 int PLMO_NAME(get_conventions)(void) { return g_conv; }
 
 int PLMO_NAME(threshold)(int L, double theta_id) {
@@ -232,6 +255,7 @@ int PLMO_NAME(eval)(const int8_t *msa, const real *w, int N, int L, int q, doubl
         }
     (void)npair;
     free(slab);
+    regj += group_term(J, g + nh, L, q);
     if (fx_out) *fx_out = nll + reg + regj;
     if (nll_out) *nll_out = nll;
     return PLMO_OK;
@@ -388,6 +412,7 @@ int PLMO_NAME(eval_gaps)(const int8_t *msa, const real *w, int N, int L, int q, 
                 }
         }
     free(slab);
+    regj += group_term(J, g + nh, L, qn);
     if (fx_out) *fx_out = nll + reg + regj;
     if (nll_out) *nll_out = nll;
     return PLMO_OK;

@@ -1187,3 +1187,52 @@ def test_stop_rule_below_1e4_rebuilds_the_backward_operand_with_four_digit_plane
         w, _, _ = ctx.weights()
     _, _, go = oracle64.eval(msa, w.astype(np.float64), Q, 0.01, plm.default_lambda_j(30, Q), x.astype(np.float64))
     assert np.linalg.norm(go) / max(1.0, np.linalg.norm(x)) < 3e-5
+
+
+# ---------------------------------------------------------------- group regulariser (run_plmc lambda_g -> plmc -lg)
+@pytest.mark.parametrize("gaps", [False, True])
+def test_group_regulariser_evaluation_matches_the_oracle(plm, oracle64, gaps):
+    """couplings/tools.py:252-253 passes lambda_g as plmc -lg.  Stated spec (PARITY UNPINNED like the rest of the
+    objective): lambda_g * sum_{i<j} sqrt(|J_ij|_F^2 + 1e-8), implemented identically by the oracle and the HIP path."""
+    N, L, lg = 700, 45, 7.5
+    msa, _ = synthetic_msa(N, L, seed=8)
+    qm = Q - 1 if gaps else Q
+    rng = np.random.default_rng(2)
+    x = (0.05 * rng.normal(size=plm.n_params(L, qm))).astype(np.float32)
+    npair = L * (L - 1) // 2
+    blocks = x[L * qm:].reshape(npair, qm * qm)
+    blocks[::3] = 0.0                                  # a third of the blocks exactly zero: the smoothed norm's origin
+    w = (1.0 / (oracle64.reweight_gaps if gaps else oracle64.reweight)(msa, 0.8)).astype(np.float32)
+    with plm.PlmContext(msa, Q, ignore_gaps=gaps, lambda_h=0.01, lambda_j=1.7, lambda_group=lg) as ctx:
+        ctx.set_weights(w)
+        ctx.set_x(x)
+        fx, nll = ctx.eval()
+        g = ctx.get_g()
+    oracle64.set_lambda_group(lg)
+    try:
+        fo, nllo, go = (oracle64.eval_gaps if gaps else oracle64.eval)(msa, w.astype(np.float64), Q, 0.01, 1.7, x.astype(np.float64))
+        oracle64.set_lambda_group(0.0)
+        f0, _, g0 = (oracle64.eval_gaps if gaps else oracle64.eval)(msa, w.astype(np.float64), Q, 0.01, 1.7, x.astype(np.float64))
+    finally:
+        oracle64.set_lambda_group(0.0)
+    assert fo - f0 > 10.0 and np.abs(go - g0).max() > 0.1          # the term is there
+    assert fx == pytest.approx(fo, rel=2e-6) and nll == pytest.approx(nllo, rel=2e-6)
+    np.testing.assert_allclose(g, go, atol=3e-5 * np.abs(go).max(), rtol=3e-5)
+
+
+def test_group_regulariser_fit_reaches_the_oracle_optimum_and_shrinks_weak_blocks(plm, oracle64):
+    N, L, lg = 500, 20, 4.0
+    msa, planted = synthetic_msa(N, L, seed=12)
+    lj = plm.default_lambda_j(L, Q)
+    oracle64.set_lambda_group(lg)
+    try:
+        ref = oracle64.fit(msa, Q, lambda_j=lj, max_iter=4000, epsilon=1e-6)
+    finally:
+        oracle64.set_lambda_group(0.0)
+    res = plm.fit(msa, Q, lambda_j=lj, max_iter=4000, epsilon=2e-5, lambda_group=lg)
+    plain = plm.fit(msa, Q, lambda_j=lj, max_iter=4000, epsilon=2e-5)
+    assert res["status"] == 0, res["status_msg"]
+    assert res["fx"] == pytest.approx(ref["fx"], rel=1e-6)
+    assert np.abs(res["cn"] - ref["cn"]).max() < 2e-4
+    nrm = lambda r: np.sqrt((r["jij"].reshape(len(r["jij"]), -1) ** 2).sum(1))
+    assert np.median(nrm(res)) < 0.8 * np.median(nrm(plain))        # the typical (uncoupled) pair is pulled towards zero

@@ -148,7 +148,7 @@ def test_run_plmc_hip_error_conventions(tmp_path):
     msa, _ = synthetic_msa(20, 12, seed=1)
     ali = msa_to_a2m(msa, str(tmp_path / "s.a2m"))
     with pytest.raises(tools.ExternalToolError):
-        tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), lambda_g=0.5)
+        tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), lambda_g=-0.5)
     with pytest.raises(tools.ExternalToolError):
         tools.run_plmc_hip(ali, str(tmp_path / "e.txt"), iterations="lots")
     from evcouplings_amd import _lib
