@@ -293,7 +293,7 @@ def main():
             "frac": achieved / PEAK_F32_VALU_TFLOPS,
             "definition": "SURVEY 8(d) primary: flops_alg/2 = N*L*(L-1)*q gathered adds per launch / HIP-event time "
                           "/ 157.3 TFLOP/s f32 vector peak",
-            "traffic": pmc_traffic_bytes("k_fwd<21_3_1_0>" if dom == "forward" else "k_bwd<21"),
+            "traffic": pmc_traffic_bytes("k_fwd<21_3_1>" if dom == "forward" else "k_bwd<21"),
             "traffic_note": "HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/*pmc_counters.csv:"
                             " 2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); "
                             "not re-collected by this run",

@@ -1,4 +1,7 @@
 set -u
-OUT=gpurun_out/r4c22; mkdir -p $OUT
+OUT=gpurun_out/r4c25; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-( timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_host_layer.py -m gpu -q -k "group_regulariser or error_conventions or end_to_end or sharded_state_eval or eval_matches" 2>&1 | tail -30 ) > $OUT/pytest1.log 2>&1; tail -30 $OUT/pytest1.log | cut -c1-220
+python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -3 $OUT/bench.err; python -c "
+import json; d=json.load(open('$OUT/bench.json')); print({k: d[k] for k in ('value','ms_per_step','joint_lbfgs_iterations_per_s')}); print(d['roofline']['frac'], d['roofline'].get('traffic'), d['roofline'].get('traffic_eval_total'), d['roofline'].get('traffic_eval_over_alg')); print(d['cpu_baseline']['value'], d['cpu_baseline']['cores']); print(d['fit']['to_epsilon_1e-3']['seconds_total'], d['fit']['ignore_gaps']['seconds_optimize'])"
+python bench.py --steps 30 --warmup 5 --no-cpu --no-fit > $OUT/bench30.json 2>/dev/null; python -c "
+import json; d=json.load(open('$OUT/bench30.json')); print('steps30', {k: d[k] for k in ('value','ms_per_step')})"

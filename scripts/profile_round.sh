@@ -3,7 +3,7 @@
 # no kernels) + the PMC passes (each counter set is its own run, never combined with trace domains other than
 # --kernel-trace); summaries left under gpurun_out/prof_TAG for copying into profiles/ (run through gpurun).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
