@@ -92,6 +92,7 @@ PlmOptions plm_options_from_env() {
     if (const char *e = getenv("PLM_BWD_PLANES")) o.bwd_planes = atoi(e) == 4 ? 4 : 3;
     if (const char *e = getenv("PLM_KSPLIT")) o.ksplit = std::max(1, atoi(e));
     if (const char *e = getenv("PLM_JEXP_BIAS")) o.jexp_bias = atoi(e);
+    if (const char *e = getenv("PLM_BWD_KERNEL")) o.bwd_kernel = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
     o.debug = getenv("PLM_DEBUG") != nullptr;
@@ -170,6 +171,8 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     d.nnfl = d.blk_per_shard * d.Q;
     d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
     d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
+    d.bwd_w = (d.Q == 21 && opt.bwd_kernel == 1) ? 1 : 0;
+    if (d.bwd_w) d.ncol_tiles = (d.nnfl + PLM_BWDW_COLS - 1) / PLM_BWDW_COLS;
     PLM_TRY(pick_ksplit(d, opt, d.nplanes, &d.ksplit));
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;
     d.nh_pad = ((int64_t)d.L * d.Q + 255) / 256 * 256;

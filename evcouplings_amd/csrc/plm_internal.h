@@ -40,6 +40,7 @@
 #define PLM_R_QMAX3 8355000.0f          // < 127 * (65536 + 256 + 1)
 #define PLM_R_QMAX4 2138000000.0f       // < 127 * (16777216 + 65536 + 256 + 1) = 2 139 062 143
 #define PLM_BWD_KSTEP 128     // sequences per K step of k_bwd (two v_mfma_i32_16x16x64_i8 sub-steps)
+#define PLM_BWDW_COLS 9        // column fragments of a k_bwd_w workgroup tile (= PLM_BWDW_FN of plm_bwd_asm.inc)
 #define PLM_BWD_ONEHOT_VALUE (-128)   // the one-hot operand of k_bwd holds -128 for a match (two VALU ops per 4 sites)
 
 // Forward GEMM on the 2:4 sparse MFMA (v_smfmac_f32_16x16x64_f16): the K index is ordered (site, state) with the
@@ -82,6 +83,7 @@ struct PlmDims {
     int nnfl;      // local col fragments = blk_per_shard * Q (slab width, padded)
     int ksplit;    // split-K factor of the backward GEMM
     int nrow_tiles, ncol_tiles; // backward workgroup grid
+    int bwd_w;         // backward GEMM by k_bwd_w (wave tile 7 x 9 in AccVGPRs, K step in assembly) instead of k_bwd
     int64_t nbp;       // block pairs I<=J
     int64_t nh_pad;    // L*Q rounded up to 256
     int64_t n_native;  // nh_pad + nbp*Q*Q*256
@@ -110,6 +112,7 @@ struct PlmDims {
 struct PlmOptions {
     int bwd_planes = 0;     // PLM_BWD_PLANES = 3 | 4: digit planes of the backward GEMM (0: chosen from epsilon)
     int ksplit = 0;         // PLM_KSPLIT: K split of the backward GEMM (0: cost model); results are identical for every value
+    int bwd_kernel = -1;    // PLM_BWD_KERNEL: 0 = k_bwd, 1 = k_bwd_w (21-state problems), -1 = the default for the size
     int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
     int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)

@@ -263,7 +263,10 @@ static inline const float *bt_cref32(const PlmDims &d, const void *Bt) {
 static inline const double *bt_cref64(const PlmDims &d, const void *Bt) {
     return (const double *)(bt_cref32(d, Bt) + (size_t)d.blk_per_shard * 16 * d.Q);
 }
-size_t plm_rt_bytes(const PlmDims &d) { return (size_t)d.nplanes * d.nst128 * d.nnfl * 2 * 1024; }
+// (+ slack: k_bwd_w copies whole tiles of PLM_BWDW_COLS column fragments, also where the last tile of a row is narrower)
+size_t plm_rt_bytes(const PlmDims &d) {
+    return (size_t)d.nplanes * d.nst128 * d.nnfl * 2 * 1024 + (size_t)PLM_BWDW_COLS * 2 * 1024;
+}
 size_t plm_g_bytes(const PlmDims &d) { return (size_t)d.nplanes * d.ksplit * d.nmf * d.nnfl * 1024; }
 size_t plm_slab_bytes(const PlmDims &d) { return (size_t)d.nmf * d.nnfl * 1024 + 256; }
 int plm_reg_parts(const PlmDims &d) { return (int)(d.np_own * d.Q) + (int)((d.nh_pad_l + 255) / 256); }
@@ -1935,9 +1938,148 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
 #endif
 }
 
+// ---- k_bwd_w: the same GEMM with the accumulator tile in a[0:251] and the K step in assembly --------------------
+// Workgroup = 4 waves (one per SIMD, 7 row fragments each), wave tile 7 x 9 accumulator fragments = 252 AccVGPRs;
+// the whole K step -- 126 MFMAs, the LDS reads one fragment ahead, the one-hot expansion of the NEXT half step
+// interleaved into the MFMA stream (2 VALU between MFMAs, hidden behind their 16 cycles) -- is one asm block from
+// plm_bwd_asm.inc (scripts/gen_bwd_asm.py has the register map and the reason).  A wave issues 63 MFMAs per 56 VALU
+// operations of expansion (k_bwd: 49), and the expansion no longer sits in front of the MFMAs of its own half step.
+// The alignment bytes run one step further ahead than the digit tile (ring of three 8 KB slots) so that the first
+// half of step s + 1 can be expanded during step s.  Results are bit-identical to k_bwd's (exact integer sums).
+#ifndef PLM_BWDW_INC
+#define PLM_BWDW_INC "plm_bwd_asm.inc"
+#endif
+#include PLM_BWDW_INC
+template <int IDX> __device__ __forceinline__ i32x4 bwdw_acc_read() {
+    i32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\t"
+                 "v_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3])
+                 : "n"(IDX), "n"(IDX + 1), "n"(IDX + 2), "n"(IDX + 3));
+    return v;
+}
+template <int F, int C>
+__device__ __forceinline__ void bwdw_store(int *Gp, const PlmDims &d, int mf0, int nfl0, int lane) {
+    const int nfl = nfl0 + C;
+    const i32x4 v = bwdw_acc_read<(F * PLM_BWDW_FN + C) * 4>();
+    if (nfl < d.nnfl) *(i32x4 *)(Gp + (((size_t)(mf0 + F) * d.nnfl + nfl) * 64 + lane) * 4) = v;
+}
+template <int F, int... C>
+__device__ __forceinline__ void bwdw_store_row(int *Gp, const PlmDims &d, int mf0, int nfl0, int lane,
+                                               std::integer_sequence<int, C...>) {
+    (bwdw_store<F, C>(Gp, d, mf0, nfl0, lane), ...);
+}
+template <int... F>
+__device__ __forceinline__ void bwdw_store_all(int *Gp, const PlmDims &d, int mf0, int nfl0, int lane,
+                                               std::integer_sequence<int, F...>) {
+    (bwdw_store_row<F>(Gp, d, mf0, nfl0, lane, std::make_integer_sequence<int, PLM_BWDW_FN>{}), ...);
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void k_bwd_w(PlmDims d, const int8_t *__restrict__ msa_cm,
+                                              const char *__restrict__ Rt, int *__restrict__ G,
+                                              const int *__restrict__ run) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (run && !*run) return;
+    constexpr int FM = PLM_BWDW_FM, FNW = PLM_BWDW_FN;
+    static_assert(Q % FM == 0, "the row fragments of a wave are states of one site block");
+    static_assert(FNW == PLM_BWDW_COLS, "plm_internal.h and plm_bwd_asm.inc disagree");
+    constexpr int TILE = FNW * 2 * 1024, ASLOT = 4 * 2 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u32 k7f = 0x7f7f7f7fu;
+    asm volatile("" : "+v"(k7f));
+    const u32 k80 = 0x80808080u;
+    const int ngroups = d.ncol_tiles * d.nplanes * d.ksplit;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = (slot / d.nrow_tiles) * 8 + xcd;
+    if (grp >= ngroups) return;
+    const int row_tile = slot % d.nrow_tiles;
+    const int col_tile = grp % d.ncol_tiles, pk = grp / d.ncol_tiles;
+    const int plane = pk % d.nplanes, ks = pk / d.nplanes;
+    const int per = (d.nst128 + d.ksplit - 1) / d.ksplit;
+    const int k0 = ks * per, k1 = min(d.nst128, k0 + per);
+    if (k0 >= k1) return;
+
+    // waves past the last row fragment run on row 0 (the K loop has no branches) and store nothing
+    const int mf0 = (row_tile * 4 + wm) * FM;
+    const bool row_ok = mf0 < d.nmf;
+    const int j16 = row_ok ? mf0 / Q : 0, b0 = row_ok ? mf0 % Q : 0;
+    const u32 b0x = (u32)b0 * 0x01010101u;
+    const int nfl0 = col_tile * FNW;
+    const int r = lane & 15, g = lane >> 4;
+    const u32 acol = (u32)(j16 * 16 + r) * (u32)d.Np + 16 * g;
+
+    // LDS: a ring of four digit tiles (FNW column fragments x 2 halves each), then a ring of four slots of alignment
+    // bytes ([row group][half] x 1 KB; a wave copies and reads its own row group only).  Step s computes on slot
+    // s % 4 while the copies of step s + 3 are issued.  A step ends with vmcnt(7) + barrier: everything issued BEFORE
+    // that step has landed for every wave -- so during step s the tile and the alignment bytes of step s + 1 are
+    // complete as well, and its first fragments are read at the end of step s (no LDS latency in front of a step, no
+    // wait for copies that were only just issued).
+    // A wave copies pieces wm, wm + 4, ... of a tile: 5 copies, the last one repeating a piece for the waves that own
+    // four; a tile past the last column fragment reads on into the next rows (Rt has that much slack behind it), a
+    // step past the K range reads the last step again: every wave issues exactly PLM_BWDW_NVMEM copies per step.
+    char *aring = smem + 4 * TILE;
+    const char *rt0 = Rt + ((size_t)plane * d.nst128 * d.nnfl + nfl0) * 2048 + wm * 1024;
+    const size_t rt_step = (size_t)d.nnfl * 2048;
+    const char *a_src = (const char *)msa_cm;
+    const u32 l16 = (u32)lane * 16;
+    const u32 last = wm < (2 * FNW) % 4 || (2 * FNW) % 4 == 0 ? 4 : 3;       // the fifth copy: piece wm + 16, or wm + 12 again
+    const u32 vo0 = l16, vo1 = l16 + 4096, vo2 = l16 + 8192, vo3 = l16 + 12288, vo4 = l16 + last * 4096, d4 = last * 4096;
+    const u32 lw = lds_addr(smem + lane * 16);
+    const u32 lw_base = __builtin_amdgcn_readfirstlane(lw - l16);
+    const u32 la0 = lds_addr(aring + (wm * 2) * 1024 + lane * 16);
+    const u32 m0t0 = lw_base + wm * 1024, m0a0 = lw_base + 4 * TILE + wm * 2048;
+    u32 st;
+    asm volatile(PLM_BWDW_ZERO_ASM ::: PLM_BWDW_CLOBBERS);
+    for (int i = 0; i < 3; i++) {
+        const int stepc = min(k0 + i, k1 - 1);
+        asm volatile(PLM_BWDW_ISSUE_ASM
+                     :
+                     : [tsrc] "s"(rt0 + (size_t)stepc * rt_step), [vo0] "v"(vo0), [vo1] "v"(vo1), [vo2] "v"(vo2),
+                       [vo3] "v"(vo3), [vo4] "v"(vo4), [m0t] "s"(m0t0 + i * TILE), [d4] "s"(d4),
+                       [asrc] "s"(a_src + (size_t)PLM_BWD_KSTEP * stepc), [acol] "v"(acol), [acol1] "v"(acol + 64), [m0a] "s"(m0a0 + i * ASLOT)
+                     : "m0", "scc", "memory");
+    }
+    vm_wait<0>();
+    __syncthreads();
+    asm volatile(PLM_BWDW_PRIME_ASM
+                 : [st] "=&s"(st)
+                 : [lan] "v"(la0), [lbn] "v"(lw), [b0x] "s"(b0x), [k7f] "v"(k7f), [k80] "s"(k80)
+                 : PLM_BWDW_CLOBBERS);
+    int sc = 0;                                  // ring slot of step ss
+    for (int ss = k0; ss < k1; ++ss) {
+        const int sn = (sc + 1) & 3, snn = (sc + 3) & 3;
+        const int stepc = min(ss + 3, k1 - 1);
+        asm volatile(PLM_BWDW_STEP_ASM
+                     : [st] "=&s"(st)
+                     : [lb] "v"(lw + sc * TILE), [lbn] "v"(lw + sn * TILE), [lan] "v"(la0 + sn * ASLOT), [b0x] "s"(b0x),
+                       [k7f] "v"(k7f), [k80] "s"(k80), [tsrc] "s"(rt0 + (size_t)stepc * rt_step), [vo0] "v"(vo0),
+                       [vo1] "v"(vo1), [vo2] "v"(vo2), [vo3] "v"(vo3), [vo4] "v"(vo4), [m0t] "s"(m0t0 + snn * TILE),
+                       [d4] "s"(d4), [asrc] "s"(a_src + (size_t)PLM_BWD_KSTEP * stepc), [acol] "v"(acol),
+                       [acol1] "v"(acol + 64), [m0a] "s"(m0a0 + snn * ASLOT)
+                     : PLM_BWDW_CLOBBERS);
+        sc = sn;
+    }
+    // the copies still in flight land before the workgroup gives up its LDS; the last MFMAs have written a[..]
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    if (!row_ok) return;
+    int *Gp = G + (size_t)(plane * d.ksplit + ks) * d.nmf * d.nnfl * 256;
+    bwdw_store_all(Gp, d, mf0, nfl0, lane, std::make_integer_sequence<int, FM>{});
+}
+
 hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const void *Rt, int32_t *G, const int *run,
                                hipStream_t st) {
     const int ngroups = d.ncol_tiles * d.nplanes * d.ksplit;
+    if (d.bwd_w) {
+        if (d.Q != 21) return hipErrorInvalidValue;
+        const size_t lds = (size_t)4 * PLM_BWDW_FN * 2 * 1024 + 4 * 4 * 2 * 1024;
+        hipError_t e = plm_allow_lds<k_bwd_w<21>>(lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_bwd_w<21>), dim3(8 * ((ngroups + 7) / 8) * d.nrow_tiles), dim3(256), lds, st, d, msa_cm,
+                           (const char *)Rt, (int *)G, run);
+        return hipGetLastError();
+    }
     const dim3 grid(8 * ((ngroups + 7) / 8) * d.nrow_tiles), block(512);
 #define BWD_CASE(QQ, M, N)                                                                             \
     case QQ: {                                                                                         \
