@@ -171,7 +171,7 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     d.nnfl = d.blk_per_shard * d.Q;
     d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
     d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
-    d.bwd_w = (d.Q == 21 && opt.bwd_kernel == 1) ? 1 : 0;
+    d.bwd_w = (d.Q == 21 && opt.bwd_kernel != 0) ? 1 : 0;   // PLM_BWD_KERNEL=0: the compiler-allocated k_bwd (A/B runs)
     if (d.bwd_w) d.ncol_tiles = (d.nnfl + PLM_BWDW_COLS - 1) / PLM_BWDW_COLS;
     PLM_TRY(pick_ksplit(d, opt, d.nplanes, &d.ksplit));
     d.nbp = (int64_t)d.nb16 * (d.nb16 + 1) / 2;

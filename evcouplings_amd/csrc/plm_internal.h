@@ -112,7 +112,7 @@ struct PlmDims {
 struct PlmOptions {
     int bwd_planes = 0;     // PLM_BWD_PLANES = 3 | 4: digit planes of the backward GEMM (0: chosen from epsilon)
     int ksplit = 0;         // PLM_KSPLIT: K split of the backward GEMM (0: cost model); results are identical for every value
-    int bwd_kernel = -1;    // PLM_BWD_KERNEL: 0 = k_bwd, 1 = k_bwd_w (21-state problems), -1 = the default for the size
+    int bwd_kernel = -1;    // PLM_BWD_KERNEL: 0 = k_bwd everywhere, otherwise k_bwd_w where it exists (21 states)
     int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
     int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)

@@ -2047,19 +2047,23 @@ __global__ __launch_bounds__(256) void k_bwd_w(PlmDims d, const int8_t *__restri
                  : [st] "=&s"(st)
                  : [lan] "v"(la0), [lbn] "v"(lw), [b0x] "s"(b0x), [k7f] "v"(k7f), [k80] "s"(k80)
                  : PLM_BWDW_CLOBBERS);
-    int sc = 0;                                  // ring slot of step ss
+    // loop state in scalar registers, advanced by additions: ring slot of step ss, sources of the copies of step ss + 3
+    int sc = 0;
+    const char *tsrc = rt0 + (size_t)min(k0 + 3, k1 - 1) * rt_step;
+    const char *asrc = a_src + (size_t)PLM_BWD_KSTEP * min(k0 + 3, k1 - 1);
     for (int ss = k0; ss < k1; ++ss) {
         const int sn = (sc + 1) & 3, snn = (sc + 3) & 3;
-        const int stepc = min(ss + 3, k1 - 1);
         asm volatile(PLM_BWDW_STEP_ASM
                      : [st] "=&s"(st)
                      : [lb] "v"(lw + sc * TILE), [lbn] "v"(lw + sn * TILE), [lan] "v"(la0 + sn * ASLOT), [b0x] "s"(b0x),
-                       [k7f] "v"(k7f), [k80] "s"(k80), [tsrc] "s"(rt0 + (size_t)stepc * rt_step), [vo0] "v"(vo0),
-                       [vo1] "v"(vo1), [vo2] "v"(vo2), [vo3] "v"(vo3), [vo4] "v"(vo4), [m0t] "s"(m0t0 + snn * TILE),
-                       [d4] "s"(d4), [asrc] "s"(a_src + (size_t)PLM_BWD_KSTEP * stepc), [acol] "v"(acol),
-                       [acol1] "v"(acol + 64), [m0a] "s"(m0a0 + snn * ASLOT)
+                       [k7f] "v"(k7f), [k80] "s"(k80), [tsrc] "s"(tsrc), [vo0] "v"(vo0), [vo1] "v"(vo1), [vo2] "v"(vo2),
+                       [vo3] "v"(vo3), [vo4] "v"(vo4), [m0t] "s"(m0t0 + snn * TILE), [d4] "s"(d4), [asrc] "s"(asrc),
+                       [acol] "v"(acol), [acol1] "v"(acol + 64), [m0a] "s"(m0a0 + snn * ASLOT)
                      : PLM_BWDW_CLOBBERS);
         sc = sn;
+        const bool more = ss + 4 < k1;           // past the K range the last step is copied again
+        tsrc += more ? rt_step : 0;
+        asrc += more ? PLM_BWD_KSTEP : 0;
     }
     // the copies still in flight land before the workgroup gives up its LDS; the last MFMAs have written a[..]
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");

@@ -1236,3 +1236,59 @@ def test_group_regulariser_fit_reaches_the_oracle_optimum_and_shrinks_weak_block
     assert np.abs(res["cn"] - ref["cn"]).max() < 2e-4
     nrm = lambda r: np.sqrt((r["jij"].reshape(len(r["jij"]), -1) ** 2).sum(1))
     assert np.median(nrm(res)) < 0.8 * np.median(nrm(plain))        # the typical (uncoupled) pair is pulled towards zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,L,gaps,planes,ksplit", [(1, 2, False, "3", None), (130, 17, False, "3", None), (3000, 300, False, "3", None),
+                                                     (2000, 130, True, "3", "3"), (700, 47, False, "4", None),
+                                                     (5000, 33, False, "4", "5"), (40000, 60, False, "3", None)])
+def test_both_backward_kernels_give_the_same_bits(plm, monkeypatch, N, L, gaps, planes, ksplit):
+    """21-state problems run the backward GEMM through k_bwd_w (accumulator tile in AccVGPRs, the K step a generated
+    assembly block -- DESIGN.md 4.4); PLM_BWD_KERNEL=0 (read once per context) keeps the compiler-allocated k_bwd.  Both
+    sum the same integers: gradients and objective must be identical bit for bit, for ragged shapes (fewer sequences
+    than a K step, a last column tile of 3 of 9 fragments, row tiles past the last fragment), three and four digit
+    planes, and any K split."""
+    msa, _ = synthetic_msa(N, L, seed=N + L, q=Q)
+    qm = Q - 1 if gaps else Q
+    rng = np.random.default_rng(N)
+    x = (0.1 * rng.normal(size=plm.n_params(L, qm))).astype(np.float32)
+    w = rng.uniform(0.05, 1.0, N).astype(np.float32)
+    monkeypatch.setenv("PLM_BWD_PLANES", planes)
+    if ksplit:
+        monkeypatch.setenv("PLM_KSPLIT", ksplit)
+    got = {}
+    for kern in ("0", "1"):
+        monkeypatch.setenv("PLM_BWD_KERNEL", kern)
+        with plm.PlmContext(msa, q=Q, ignore_gaps=gaps, lambda_h=0.01, lambda_j=3.0) as ctx:
+            ctx.set_weights(w)
+            ctx.set_x(x)
+            got[kern] = ctx.eval() + (ctx.get_g(),)
+    assert got["0"][0] == got["1"][0] and got["0"][1] == got["1"][1]
+    np.testing.assert_array_equal(got["0"][2], got["1"][2])
+    assert np.isfinite(got["1"][2]).all() and np.abs(got["1"][2]).max() > 0
+
+
+@pytest.mark.gpu
+def test_backward_kernels_agree_on_every_shard(plm, oracle64, monkeypatch):
+    """the same comparison for sharded state (a shard's column range is its own site blocks: 3 shards of L = 100 give
+    column tiles that end inside a tile of 9 fragments)"""
+    from evcouplings_amd.dist import ThreadedShards
+    N, L, n_shards = 400, 100, 3
+    msa, _ = synthetic_msa(N, L, seed=11)
+    w = (1.0 / oracle64.reweight(msa, 0.8)).astype(np.float32)
+    x = (0.1 * np.random.default_rng(7).normal(size=plm.n_params(L, Q))).astype(np.float32)
+
+    def work(r, coll):
+        with plm.PlmContext(msa, q=Q, lambda_h=0.01, lambda_j=4.2, n_shards=n_shards, shard=r, sharded_state=True) as ctx:
+            ctx.set_collective(coll)
+            ctx.set_weights(w)
+            ctx.set_x(x)
+            return ctx.eval() + (ctx.get_g(),)
+
+    outs = {}
+    for kern in ("0", "1"):
+        monkeypatch.setenv("PLM_BWD_KERNEL", kern)
+        outs[kern] = ThreadedShards(n_shards).run(work)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert a[0] == b[0]
+        np.testing.assert_array_equal(a[2], b[2])
