@@ -2012,10 +2012,11 @@ __global__ __launch_bounds__(256) void k_bwd_w(PlmDims d, const int8_t *__restri
 
     // LDS: a ring of four digit tiles (FNW column fragments x 2 halves each), then a ring of four slots of alignment
     // bytes ([row group][half] x 1 KB; a wave copies and reads its own row group only).  Step s computes on slot
-    // s % 4 while the copies of step s + 3 are issued.  A step ends with vmcnt(7) + barrier: everything issued BEFORE
-    // that step has landed for every wave -- so during step s the tile and the alignment bytes of step s + 1 are
-    // complete as well, and its first fragments are read at the end of step s (no LDS latency in front of a step, no
-    // wait for copies that were only just issued).
+    // s % 4 and issues the copies of step s + 3 in its second half.  A wave ends a step with vmcnt(7) -- its copies
+    // issued BEFORE this step have landed -- and an arrival on an LDS counter; in the middle of the next step it checks
+    // that all four waves have arrived (scripts/gen_bwd_asm.py): then the tile of step s + 2 is complete (its first
+    // fragments are read at the end of step s + 1: no LDS latency in front of a step) and the slot of step s may be
+    // overwritten.  There is no s_barrier in the loop.
     // A wave copies pieces wm, wm + 4, ... of a tile: 5 copies, the last one repeating a piece for the waves that own
     // four; a tile past the last column fragment reads on into the next rows (Rt has that much slack behind it), a
     // step past the K range reads the last step again: every wave issues exactly PLM_BWDW_NVMEM copies per step.
@@ -2030,7 +2031,11 @@ __global__ __launch_bounds__(256) void k_bwd_w(PlmDims d, const int8_t *__restri
     const u32 lw_base = __builtin_amdgcn_readfirstlane(lw - l16);
     const u32 la0 = lds_addr(aring + (wm * 2) * 1024 + lane * 16);
     const u32 m0t0 = lw_base + wm * 1024, m0a0 = lw_base + 4 * TILE + wm * 2048;
-    u32 st;
+    // arrival counter of the K loop (see the step block): behind the rings
+    const u32 cnt = lw_base + 4 * TILE + 4 * ASLOT;
+    if (tid == 0) *(u32 *)(smem + 4 * TILE + 4 * ASLOT) = 0;
+    const u32 one = 1;
+    u32 st, sp;
     asm volatile(PLM_BWDW_ZERO_ASM ::: PLM_BWDW_CLOBBERS);
     for (int i = 0; i < 3; i++) {
         const int stepc = min(k0 + i, k1 - 1);
@@ -2051,16 +2056,19 @@ __global__ __launch_bounds__(256) void k_bwd_w(PlmDims d, const int8_t *__restri
     int sc = 0;
     const char *tsrc = rt0 + (size_t)min(k0 + 3, k1 - 1) * rt_step;
     const char *asrc = a_src + (size_t)PLM_BWD_KSTEP * min(k0 + 3, k1 - 1);
+    u32 tgt = 0;                                 // arrivals of the steps before ss: one per wave and step
     for (int ss = k0; ss < k1; ++ss) {
         const int sn = (sc + 1) & 3, snn = (sc + 3) & 3;
         asm volatile(PLM_BWDW_STEP_ASM
-                     : [st] "=&s"(st)
+                     : [st] "=&s"(st), [sp] "=&s"(sp)
                      : [lb] "v"(lw + sc * TILE), [lbn] "v"(lw + sn * TILE), [lan] "v"(la0 + sn * ASLOT), [b0x] "s"(b0x),
                        [k7f] "v"(k7f), [k80] "s"(k80), [tsrc] "s"(tsrc), [vo0] "v"(vo0), [vo1] "v"(vo1), [vo2] "v"(vo2),
                        [vo3] "v"(vo3), [vo4] "v"(vo4), [m0t] "s"(m0t0 + snn * TILE), [d4] "s"(d4), [asrc] "s"(asrc),
-                       [acol] "v"(acol), [acol1] "v"(acol + 64), [m0a] "s"(m0a0 + snn * ASLOT)
+                       [acol] "v"(acol), [acol1] "v"(acol + 64), [m0a] "s"(m0a0 + snn * ASLOT), [cnt] "v"(cnt),
+                       [one] "v"(one), [tgt] "s"(tgt)
                      : PLM_BWDW_CLOBBERS);
         sc = sn;
+        tgt += 4;
         const bool more = ss + 4 < k1;           // past the K range the last step is copied again
         tsrc += more ? rt_step : 0;
         asrc += more ? PLM_BWD_KSTEP : 0;
@@ -2077,7 +2085,7 @@ hipError_t plm_launch_backward(const PlmDims &d, const int8_t *msa_cm, const voi
     const int ngroups = d.ncol_tiles * d.nplanes * d.ksplit;
     if (d.bwd_w) {
         if (d.Q != 21) return hipErrorInvalidValue;
-        const size_t lds = (size_t)4 * PLM_BWDW_FN * 2 * 1024 + 4 * 4 * 2 * 1024;
+        const size_t lds = (size_t)4 * PLM_BWDW_FN * 2 * 1024 + 4 * 4 * 2 * 1024 + 16;
         hipError_t e = plm_allow_lds<k_bwd_w<21>>(lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_bwd_w<21>), dim3(8 * ((ngroups + 7) / 8) * d.nrow_tiles), dim3(256), lds, st, d, msa_cm,

@@ -22,13 +22,14 @@ import os
 FM, FNW = 7, 9
 V_LO = 176
 AF_A, AF_B = 176, 204
-XA1, XN0, T0, T1 = 232, 236, 240, 241
+XA1, XN0, T0, T1, VCNT = 232, 236, 240, 241, 242
 BF = (244, 248, 252)          # ring of three digit fragments: the LDS read runs two fragments ahead of its MFMAs
 V_HI = 255
 NOVALU = int(os.environ.get("BWDW_NOVALU", "0"))    # timing experiments only (wrong results)
 NOLDS = int(os.environ.get("BWDW_NOLDS", "0"))
 NODMA = int(os.environ.get("BWDW_NODMA", "0"))
 NOBAR = int(os.environ.get("BWDW_NOBAR", "0"))
+NOCHECK = int(os.environ.get("BWDW_NOCHECK", "0"))
 NACC = FM * FNW * 4
 
 
@@ -54,7 +55,8 @@ def expand(state, xa, af, lines_out):
 
 NPIECE = 5                    # digit-tile pieces of a wave per K step (waves with 4 repeat one), + 2 alignment pieces
 NVMEM = NPIECE + 2
-DMA_FRAGS = (0, 2, 4, 6, 9, 11, 13)      # fragments whose gaps 4 / 5 carry one LDS-DMA instruction
+DMA_FRAGS = tuple(int(v) for v in os.environ.get("BWDW_DMAF", "8,9,10,11,12,13,14").split(","))   # fragments whose gaps 4 / 5 carry one LDS-DMA instruction (behind the check)
+CNT_READ_FRAG, CNT_CHECK_FRAG = 5, 7     # the arrival counter is read at gap 4 of the first, tested in the second
 
 
 def dma_ops():
@@ -89,13 +91,17 @@ def step_block():
         gap 5     the state constant of the next fragment's expansion; the LDS-DMA instruction
         gap 6     the wait for the next fragment's digits
     The last two fragments read the first two fragments of step s + 1 (its tile landed a step ago), so the next block
-    starts without an exposed LDS latency; then vmcnt(7) + s_barrier: the copies issued before this step have landed
-    for every wave, i.e. the data of step s + 2 is complete when step s + 1 begins."""
+    starts without an exposed LDS latency.
+    No s_barrier in the loop (measured: 0.20 of 3.57 ms -- with one wave per SIMD nothing runs while a wave waits): a
+    wave ARRIVES at the end of a step (vmcnt(7): its copies issued before this step have landed; ds_add on an LDS
+    counter) and CHECKS in the middle of the next step that all four have arrived, before it issues the copies that
+    overwrite the slot of the step before and before it reads the next tile: half a step of skew costs nothing."""
     L = []
     NF = 2 * FNW
     dma = dma_ops() if not NODMA else []
     L.append(f"ds_read_b128 {vr(XN0)}, %[lan]")
-    L.append("s_waitcnt lgkmcnt(2)")          # XA1 and fragment 0 (fragment 1 and XN0 may still be in flight)
+    # XA1 and fragment 0; fragment 1, the arrival add of the previous block and XN0 may still be in flight
+    L.append("s_waitcnt lgkmcnt(%d)" % (2 if NOBAR else 3))
     for F in range(NF):
         C, H = F % FNW, F // FNW
         me = BF[F % 3]
@@ -106,6 +112,18 @@ def step_block():
         gaps = [[] for _ in range(FM)]
         for j, pr in enumerate(pairs):
             gaps[j].extend(pr)
+        if F == CNT_READ_FRAG and not NOBAR:
+            # in front of this fragment's digit read: the counted wait of gap 6 covers it (LDS returns in order)
+            gaps[4].append(f"ds_read_b32 v{VCNT}, %[cnt]")
+        if F == CNT_CHECK_FRAG and not NOBAR and not NOCHECK:
+            # every wave has finished step s - 1 (its reads of the slot this step's copies overwrite, its own copies of
+            # step s + 2 landed)?  Normally yes at the first look; otherwise poll.
+            gaps[0] += [f"v_readfirstlane_b32 %[st], v{VCNT}", "s_cmp_ge_u32 %[st], %[tgt]"]
+            # (the poll is bounded: a workgroup that lost a wave traps instead of spinning forever)
+            gaps[1] += ["s_cbranch_scc1 .Lbwdw_go_%=", "s_mov_b32 %[sp], 0x400000", ".Lbwdw_poll_%=:",
+                        f"ds_read_b32 v{VCNT}, %[cnt]", "s_waitcnt lgkmcnt(0)", f"v_readfirstlane_b32 %[st], v{VCNT}",
+                        "s_cmp_ge_u32 %[st], %[tgt]", "s_cbranch_scc1 .Lbwdw_go_%=", "s_sub_u32 %[sp], %[sp], 1",
+                        "s_cmp_lg_u32 %[sp], 0", "s_cbranch_scc1 .Lbwdw_poll_%=", "s_trap 2", ".Lbwdw_go_%=:"]
         if not NOLDS:
             if F + 2 < NF:
                 gaps[4].append(f"ds_read_b128 {vr(BF[(F + 2) % 3])}, %[lb] offset:{frag_off(F + 2)}")
@@ -127,8 +145,11 @@ def step_block():
             L.append(f"v_mfma_i32_16x16x64_i8 {acc(f, C)}, {vr(af + 4 * f)}, {vr(me)}, {acc(f, C)}")
             L.extend(gaps[f])
     if not NOBAR:
+        # arrival: my copies issued before this step have landed, my LDS reads of this step are ahead of the add in the
+        # LDS queue.  One lane adds (64 lanes on one address serialise in the LDS and hold up the reads queued behind
+        # them: measured +0.4 ms); the kernel runs with full waves, so EXEC goes back to all ones.
         L.append(f"s_waitcnt vmcnt({NVMEM if dma else 0})")
-        L.append("s_barrier")
+        L += ["s_mov_b64 exec, 1", "ds_add_u32 %[cnt], %[one]", "s_mov_b64 exec, -1"]
     return L
 
 

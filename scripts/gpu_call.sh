@@ -1,5 +1,7 @@
 set -u
-OUT=gpurun_out/r4c30; mkdir -p $OUT
+OUT=gpurun_out/r4c34; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 300 python tests/probes/bwd_kernel_ab.py 2>&1 | tail -3 | tee $OUT/ab.txt
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "backward_kernel or both_backward or sharded_state or edge_shapes or eval_matches_oracle or stop_rule" 2>&1 | tail -8 | tee $OUT/tests.txt
+timeout 120 python tests/probes/bwd_kernel_ab.py 2>&1 | tail -3 | tee $OUT/ab.txt
+for v in A B; do
+PLM_HIP_LIB=$PWD/evcouplings_amd/libplm_$v.so timeout 120 python tests/probes/bwd_kernel_ab.py 2>&1 | grep "KERNEL=1" | sed "s/^/$v /" | tee -a $OUT/variants.txt
+done
