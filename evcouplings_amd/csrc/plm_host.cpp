@@ -93,6 +93,7 @@ PlmOptions plm_options_from_env() {
     if (const char *e = getenv("PLM_KSPLIT")) o.ksplit = std::max(1, atoi(e));
     if (const char *e = getenv("PLM_JEXP_BIAS")) o.jexp_bias = atoi(e);
     if (const char *e = getenv("PLM_BWD_KERNEL")) o.bwd_kernel = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("PLM_FWD_KERNEL")) o.fwd_kernel = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
     o.debug = getenv("PLM_DEBUG") != nullptr;
@@ -171,6 +172,7 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     d.nnfl = d.blk_per_shard * d.Q;
     d.nrow_tiles = (d.nmf + 4 * d.FM - 1) / (4 * d.FM);
     d.ncol_tiles = (d.nnfl + 2 * d.FN - 1) / (2 * d.FN);
+    d.fwd_w = (d.Q == 21 && opt.fwd_kernel != 0) ? 1 : 0;   // PLM_FWD_KERNEL=0: k_fwd (A/B runs)
     d.bwd_w = (d.Q == 21 && opt.bwd_kernel != 0) ? 1 : 0;   // PLM_BWD_KERNEL=0: the compiler-allocated k_bwd (A/B runs)
     if (d.bwd_w) d.ncol_tiles = (d.nnfl + PLM_BWDW_COLS - 1) / PLM_BWDW_COLS;
     PLM_TRY(pick_ksplit(d, opt, d.nplanes, &d.ksplit));

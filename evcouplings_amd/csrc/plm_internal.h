@@ -83,6 +83,7 @@ struct PlmDims {
     int nnfl;      // local col fragments = blk_per_shard * Q (slab width, padded)
     int ksplit;    // split-K factor of the backward GEMM
     int nrow_tiles, ncol_tiles; // backward workgroup grid
+    int fwd_w;         // plain forward GEMM of the fit by k_fwd_w (512 sequences per workgroup, K loop in assembly)
     int bwd_w;         // backward GEMM by k_bwd_w (wave tile 7 x 9 in AccVGPRs, K step in assembly) instead of k_bwd
     int64_t nbp;       // block pairs I<=J
     int64_t nh_pad;    // L*Q rounded up to 256
@@ -112,6 +113,7 @@ struct PlmDims {
 struct PlmOptions {
     int bwd_planes = 0;     // PLM_BWD_PLANES = 3 | 4: digit planes of the backward GEMM (0: chosen from epsilon)
     int ksplit = 0;         // PLM_KSPLIT: K split of the backward GEMM (0: cost model); results are identical for every value
+    int fwd_kernel = -1;    // PLM_FWD_KERNEL: 0 = k_fwd everywhere, otherwise k_fwd_w where it exists (21 states, the fit's store mode)
     int bwd_kernel = -1;    // PLM_BWD_KERNEL: 0 = k_bwd everywhere, otherwise k_bwd_w where it exists (21 states)
     int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
     int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)

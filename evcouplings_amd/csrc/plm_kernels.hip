@@ -575,7 +575,9 @@ __device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__
 // (the two ds_read_b128 of k_fwd).  Which (site j, state b) a slot holds follows from the instruction's operand
 // pairing (profiles/r02_smfmac_probe.txt): pair p of A lane (row, ga) multiplies B lane (n, gb = 2 (ga % 2) + p / 2),
 // slots 8 (ga / 2) + 4 (p % 2) + e, and k_fwd gives pair p of slice ci the (site, state group)
-//     gl = 4 ci + p,  site 32 u + 8 ga + gl / NG,  states 1 + 4 (gl % NG) + e  (as differences to state 0).
+//     gl = 4 ci + p,  site 32 u + 8 ga + gl % 8,  states 1 + 4 (gl / 8) + e  (as differences to state 0):
+// a slice is four neighbouring sites (one dword of a lane's 8 alignment bytes) against ONE group of four states, so the
+// 2-bit positions of a slice depend on the dword only and its values are four byte compares with one constant (k_fwd_w).
 // k_fwd_ref: the constant the differences leave out, C[i][a] = sum_{j != i} J_ij(a, 0) (zero in gap mode, where state 0
 // is not a model state), unscaled, behind the tiles.
 __global__ __launch_bounds__(64) void k_fwd_ref(PlmDims d, const float *__restrict__ x, const float *__restrict__ xhalo,
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
 #pragma unroll
             for (int e8 = 0; e8 < 8; e8++) {
                 const int ga = 2 * half + (gb >> 1), pp = 2 * (gb & 1) + (e8 >> 2), e = e8 & 3;
-                const int gl = 4 * ci + pp, s8 = gl / NG, sg = gl % NG;
+                const int gl = 4 * ci + pp, s8 = gl & 7, sg = gl >> 3;
                 const int b = 4 * sg + e + 1, j = 32 * u + 8 * ga + s8;     // state 0 has no slot (reference state)
                 // the difference to the reference state, scaled by a power of two and split hi = f16(v), lo = f16(v - hi):
                 // 22 significant bits of the DIFFERENCE (the evaluations that need more run the exact kernel, k_fwd_x)
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                 const int ci = b >> 1;
 #pragma unroll
                 for (int pp = 0; pp < 4; pp++) {
-                    const int gl = 4 * ci + pp, s8 = gl / NG, kg = gl - s8 * NG;
+                    const int gl = 4 * ci + pp, s8 = gl & 7, kg = gl >> 3;
                     const u32 x0 = (u32)(xa0 >> (8 * s8)) & 0xffu, x1 = (u32)(xa1 >> (8 * s8)) & 0xffu;
                     // state x > 0 sits in slot (x - 1); x = 0 (the reference state) wraps to a group that does not exist
                     ((u32 *)&a0)[pp] = (((x0 - 1u) >> 2) == (u32)kg) ? 0x3C00u : 0u;
@@ -1118,6 +1120,143 @@ template <auto KERNEL> static hipError_t plm_allow_lds(size_t lds) {
     return result[dev];
 }
 
+// ---- k_fwd_w: the plain forward GEMM of the fit with 512 sequences per workgroup, K loop in assembly ----------------
+// Workgroup = 4 waves (one per SIMD) x 128 sequences (8 row fragments) x one 16-site block x ONE group of 7 states; the
+// wave's 8 x 7 accumulator fragments live in a[0:223], the slice blocks of plm_fwd_asm.inc (scripts/gen_fwd_asm.py:
+// register map, schedule, synchronisation) do everything between the prologue and the store.  Same instruction, same
+// operands and the same K order per accumulator as k_fwd: the stored potentials are bit-identical to k_fwd<21, STORE>'s,
+// and HJ keeps its layout (a wave here = four (wave, row fragment pair) slots of k_fwd's two 256-sequence tiles).
+#include "plm_fwd_asm.inc"
+template <int IDX> __device__ __forceinline__ f32x4 fwdw_acc_read() {
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\t"
+                 "v_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3])
+                 : "n"(IDX), "n"(IDX + 1), "n"(IDX + 2), "n"(IDX + 3));
+    return v;
+}
+template <int M, int A>
+__device__ __forceinline__ void fwdw_store(float4 *hj, const double *cref, double sc64) {
+    const f32x4 v = fwdw_acc_read<(M * PLM_FWDW_QG + A) * 4>();
+    const double c = cref[A];
+    hj[(size_t)((M & 1) * 21 + A) * 64 + (size_t)(M >> 1) * 2 * 21 * 64] =
+        make_float4((float)__builtin_fma((double)v[0], sc64, c), (float)__builtin_fma((double)v[1], sc64, c),
+                    (float)__builtin_fma((double)v[2], sc64, c), (float)__builtin_fma((double)v[3], sc64, c));
+}
+template <int M, int... A>
+__device__ __forceinline__ void fwdw_store_row(float4 *hj, const double *cref, double sc64, std::integer_sequence<int, A...>) {
+    (fwdw_store<M, A>(hj, cref, sc64), ...);
+}
+template <int... M>
+__device__ __forceinline__ void fwdw_store_all(float4 *hj, const double *cref, double sc64, std::integer_sequence<int, M...>) {
+    (fwdw_store_row<M>(hj, cref, sc64, std::make_integer_sequence<int, PLM_FWDW_QG>{}), ...);
+}
+
+__global__ __launch_bounds__(256) void k_fwd_w(PlmDims d, FwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Q = 21, QG = PLM_FWDW_QG, NSG = Q / QG, NM = PLM_FWDW_NM, SLOT = PLM_FWDW_SLOT;
+    constexpr int TILE_G = 2 * Q * 1024, NG = PLM_FWD_NG(Q), SPU = 2 * NG;      // slices of a 32-site block
+    static_assert(NG == 5 && 2 * 2 * QG * 1024 == SLOT, "plm_fwd_asm.inc is generated for 21 states in groups of 7");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // work list as in k_fwd (site-block major, XCD x takes a contiguous eighth), over PAIRS of 256-sequence tiles
+    const int npair = (d.nstiles + 1) >> 1;
+    const int nwork = npair * (d.b16_hi - d.b16_lo) * NSG, per_xcd = (nwork + 7) >> 3;
+    const int wk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || wk >= nwork) return;
+    const int spair = wk % npair, sg = (wk / npair) % NSG, b16l = wk / (npair * NSG);
+    const int a_lo = sg * QG;
+    const int r = lane & 15, g = lane >> 4;
+    const int stile = 2 * spair + (wv >> 1);                  // k_fwd's 256-sequence tile of this wave
+    const bool tile_ok = stile < d.nstiles;                   // an odd tile count leaves the last pair's second half empty
+    const int s_wave = tile_ok ? stile * PLM_SEQ_TILE + (wv & 1) * 128 : 0;
+    const int nsteps = d.nu * SPU;                            // one step = one slice = both planes
+    const char *bt = A.Bt + (size_t)b16l * nsteps * 2 * TILE_G + (size_t)a_lo * 1024 + wv * 1024;
+    const u32 arow = (u32)(s_wave + r) * (u32)d.Lp32 + 8 * g, rstride = 16 * (u32)d.Lp32;
+
+    // a step's tile in Bt is two planes x [2 halves][Q states][1 KB]; the group's fragments are four runs of QG KB.
+    // LDS slot = those runs back to back ([plane][half][QG]); piece p of the slot = run p / QG, fragment p % QG; wave wv
+    // copies pieces wv, wv + 4, ... (28 pieces: 7 each)
+    const u32 l16 = (u32)lane * 16;
+    u32 vo[PLM_FWDW_NVMEM];
+#pragma unroll
+    for (int k = 0; k < PLM_FWDW_NVMEM; k++) {
+        const int p = wv + 4 * k, run = p / QG, f = p - run * QG;
+        vo[k] = l16 + (u32)((run >> 1) * TILE_G + (run & 1) * Q * 1024 + f * 1024) - (u32)wv * 1024;
+    }
+    const u32 lw = lds_addr(smem + lane * 16);
+    const u32 lw_base = __builtin_amdgcn_readfirstlane(lw - l16);
+    const u32 m0t0 = lw_base + wv * 1024;
+    const u32 cnt = lw_base + 4 * SLOT;
+    if (tid == 0) *(u32 *)(smem + 4 * SLOT) = 0;
+    const u32 one = 1, sel = 0x0c0c0200u;
+    u32 st, sp;
+    asm volatile(PLM_FWDW_ZERO_ASM ::: PLM_FWDW_CLOBBERS);
+    for (int i = 0; i < 3; i++) {
+        const int stepc = min(i, nsteps - 1);
+        asm volatile(PLM_FWDW_ISSUE_ASM
+                     :
+                     : [tsrc] "s"(bt + (size_t)stepc * 2 * TILE_G), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]),
+                       [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [m0t] "s"(m0t0 + i * SLOT)
+                     : "m0", "scc", "memory");
+    }
+    // alignment bytes of u = 0 -> the per-u operands; the loads of u = 1 go out
+    asm volatile(PLM_FWDW_LOADS_ASM : : [arow] "v"(arow), [rstride] "s"(rstride), [xsrc] "s"(A.msa_rm) : PLM_FWDW_CLOBBERS);
+    asm volatile(PLM_FWDW_UPREP_ASM
+                 :
+                 : [arow] "v"(arow), [rstride] "s"(rstride), [xsrc] "s"(A.msa_rm + 32 * min(1, d.nu - 1)), [sel] "s"(sel)
+                 : PLM_FWDW_CLOBBERS);
+    vm_wait<0>();
+    __syncthreads();
+    asm volatile(PLM_FWDW_PRIME_ASM : : [kg] "s"(0), [lbn] "v"(lw) : PLM_FWDW_CLOBBERS);
+
+    int sc = 0;
+    u32 tgt = 0;
+    const char *tsrc = bt + (size_t)min(3, nsteps - 1) * 2 * TILE_G;
+    int step = 0;
+#define FWDW_SLICE(WHICH, KG)                                                                                          \
+    {                                                                                                                  \
+        const int sn = (sc + 1) & 3, snn = (sc + 3) & 3;                                                               \
+        asm volatile(WHICH                                                                                             \
+                     : [st] "=&s"(st), [sp] "=&s"(sp)                                                                  \
+                     : [lb] "v"(lw + sc * SLOT), [lbn] "v"(lw + sn * SLOT), [kg] "s"(KG), [tsrc] "s"(tsrc),          \
+                       [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]),       \
+                       [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [m0t] "s"(m0t0 + snn * SLOT), [cnt] "v"(cnt),               \
+                       [one] "v"(one), [tgt] "s"(tgt)                                                                  \
+                     : PLM_FWDW_CLOBBERS);                                                                             \
+        sc = sn;                                                                                                       \
+        tgt += 4;                                                                                                      \
+        tsrc += (step + 4 < nsteps) ? (size_t)2 * TILE_G : 0;      /* past the last step it is copied again */         \
+        ++step;                                                                                                        \
+    }
+    for (int u = 0; u < d.nu; ++u) {
+#pragma unroll 1
+        for (int k = 0; k < NG; ++k) {
+            // slice 2k on set 0 builds slice 2k + 1 (second dword of the lane's sites, same state group) ...
+            FWDW_SLICE(PLM_FWDW_EVEN_ASM, k)
+            if (k == NG - 1)      // ... the per-u operands are free now: those of u + 1 (the loads of u + 2 go out)
+                asm volatile(PLM_FWDW_UPREP_ASM
+                             :
+                             : [arow] "v"(arow), [rstride] "s"(rstride),
+                               [xsrc] "s"(A.msa_rm + 32 * min(u + 2, d.nu - 1)), [sel] "s"(sel)
+                             : PLM_FWDW_CLOBBERS);
+            // ... slice 2k + 1 on set 1 builds slice 2k + 2: first dword, next state group (of the next u behind the last)
+            FWDW_SLICE(PLM_FWDW_ODD_ASM, k + 1 < NG ? k + 1 : 0)
+        }
+    }
+#undef FWDW_SLICE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    if (!tile_ok) return;
+    const int je = *A.jexp;
+    const double sc64 = ldexp(1.0, -je);
+    const double *cref = (const double *)((const float *)(A.Bt + (size_t)d.blk_per_shard * d.nksteps * TILE_G) +
+                                          (size_t)d.blk_per_shard * 16 * Q) + ((size_t)b16l * 16 + r) * Q + a_lo;
+    // k_fwd's layout: [tile][wave of 32 sequences][row fragment pair][state][lane]; this wave's row fragment M is row
+    // fragment M & 1 of wave 4 (wv & 1) + M / 2 there
+    float4 *hj = (float4 *)A.out + ((size_t)(b16l * d.nstiles + stile) * 8 + (wv & 1) * 4) * 2 * Q * 64 + (size_t)a_lo * 64 + lane;
+    fwdw_store_all(hj, cref, sc64, std::make_integer_sequence<int, NM>{});
+}
+
 // state groups per workgroup of the exact forward GEMM (56 + 112 registers of accumulators and f64 sums at 7 states)
 int plm_fwd_groups(int q, int exact) {
     if (!exact) return q == 32 ? 2 : 1;
@@ -1139,6 +1278,14 @@ static hipError_t fwd_launch(const PlmDims &d, const FwdArgs &A, hipStream_t st)
     }
     return hipGetLastError();
 }
+static hipError_t fwdw_launch(const PlmDims &d, const FwdArgs &A, hipStream_t st) {
+    const int nwork = ((d.nstiles + 1) / 2) * (d.b16_hi - d.b16_lo) * (21 / PLM_FWDW_QG);
+    const size_t lds = (size_t)4 * PLM_FWDW_SLOT + 16;   // ring of four tiles + the arrival counter
+    hipError_t e = plm_allow_lds<k_fwd_w>(lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fwd_w, dim3(8 * ((nwork + 7) / 8)), dim3(256), lds, st, d, A);
+    return hipGetLastError();
+}
 static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mode, int exact, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
 #define FWD_CASE(QQ, NP, NX)      /* NP / NX: state groups per workgroup of the plain / the exact kernel (plm_fwd_groups) */ \
@@ -1147,6 +1294,7 @@ static hipError_t launch_forward_mode(const PlmDims &d, const FwdArgs &A, int mo
         if (mode == FWD_POTENTIALS && exact) return fwd_launch<QQ, FWD_POTENTIALS, NX, true>(d, A, st); \
         if (mode == FWD_POTENTIALS) return fwd_launch<QQ, FWD_POTENTIALS, NP, false>(d, A, st);        \
         if (exact) return fwd_launch<QQ, FWD_STORE, NX, true>(d, A, st);                               \
+        if (QQ == 21 && d.fwd_w) return fwdw_launch(d, A, st);                                         \
         return fwd_launch<QQ, FWD_STORE, NP, false>(d, A, st);
     switch (d.Q) {
         FWD_CASE(32, 2, 8)

@@ -36,7 +36,7 @@ def model(L, Q, N=16, seed=0):
                                 pp = 2 * (gb & 1) + (e8 >> 2)
                                 e = e8 & 3
                                 gl = 4 * ci + pp
-                                s8, sg = gl // NG, gl % NG
+                                s8, sg = gl % 8, gl // 8
                                 b, j = 4 * sg + e + 1, 32 * u + 8 * ga + s8
                                 if b < Q and i < L and j < L and i != j:
                                     tile[a, lane, 8 * half + e8] = J[i, a, j, b] - J[i, a, j, 0]
@@ -45,7 +45,7 @@ def model(L, Q, N=16, seed=0):
                     for ga in range(4):
                         for pp in range(4):
                             gl = 4 * ci + pp
-                            s8, sg = gl // NG, gl - (gl // NG) * NG
+                            s8, sg = gl % 8, gl // 8
                             xs = xpad[s, 32 * u + 8 * ga + s8]
                             if ((xs - 1) & 0xffffffff) >> 2 != sg:
                                 continue                                   # compressed value 0 (incl. x = 0 and padding)
