@@ -1126,7 +1126,10 @@ template <auto KERNEL> static hipError_t plm_allow_lds(size_t lds) {
 // register map, schedule, synchronisation) do everything between the prologue and the store.  Same instruction, same
 // operands and the same K order per accumulator as k_fwd: the stored potentials are bit-identical to k_fwd<21, STORE>'s,
 // and HJ keeps its layout (a wave here = four (wave, row fragment pair) slots of k_fwd's two 256-sequence tiles).
-#include "plm_fwd_asm.inc"
+#ifndef PLM_FWDW_INC
+#define PLM_FWDW_INC "plm_fwd_asm.inc"
+#endif
+#include PLM_FWDW_INC
 template <int IDX> __device__ __forceinline__ f32x4 fwdw_acc_read() {
     f32x4 v;
     asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\t"

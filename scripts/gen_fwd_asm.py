@@ -42,6 +42,12 @@ NVMEM = 7
 CNT_READ_FRAG, CNT_CHECK_FRAG = 4, 6
 DMA_FRAGS = (7, 8, 9, 10, 11, 12, 13)
 SLOT = 2 * NF * 1024          # LDS bytes of a step's tile: [plane][half][state] x 1 KB
+NOBUILD = int(os.environ.get("FWDW_NOBUILD", "0"))      # timing experiments only (wrong results)
+NOLDS = int(os.environ.get("FWDW_NOLDS", "0"))
+NODMA = int(os.environ.get("FWDW_NODMA", "0"))
+NOSYNC = int(os.environ.get("FWDW_NOSYNC", "0"))
+RD_GAPS = tuple(int(v) for v in os.environ.get("FWDW_RDGAPS", "5,6").split(","))
+DMA_GAPS = tuple(int(v) for v in os.environ.get("FWDW_DMAGAPS", "3,4").split(","))
 
 
 def vr(b, n):
@@ -90,18 +96,18 @@ def dma_ops():
 def slice_block(cur):
     """slice on set `cur`; builds set 1 - cur for the next slice (dword 1 - cur ... the next slice's parity)"""
     nxt = 1 - cur
-    L = ["s_waitcnt lgkmcnt(3)"]          # fragment 0 is in; fragment 1 (2 reads) and the arrival add may be in flight
+    L = ["s_waitcnt lgkmcnt(%d)" % (2 if NOSYNC else 3)]          # fragment 0 is in; fragment 1 (2 reads) and the arrival add may be in flight
     dma = dma_ops()
     for F in range(NF):
         a = F % QG
         gaps = [[] for _ in range(NM)]
-        if F < NM:
+        if F < NM and not NOBUILD:
             ops = build_ops(nxt, F, nxt)
             for j, o in enumerate(ops):       # cmp / cndmask pairs in order, one operation per gap; the move rides along
                 gaps[j if j < NM else NM - 2].append(o)
-        if F == CNT_READ_FRAG:
-            gaps[5].append(f"ds_read_b32 v{VCNT}, %[cnt]")
-        if F == CNT_CHECK_FRAG:
+        if F == CNT_READ_FRAG and not NOSYNC:
+            gaps[RD_GAPS[0]].append(f"ds_read_b32 v{VCNT}, %[cnt]")
+        if F == CNT_CHECK_FRAG and not NOSYNC:
             gaps[0] += [f"v_readfirstlane_b32 %[st], v{VCNT}", "s_cmp_ge_u32 %[st], %[tgt]"]
             gaps[1] += ["s_cbranch_scc1 .Lfwdw_go_%=", "s_mov_b32 %[sp], 0x400000", ".Lfwdw_poll_%=:",
                         f"ds_read_b32 v{VCNT}, %[cnt]", "s_waitcnt lgkmcnt(0)", f"v_readfirstlane_b32 %[st], v{VCNT}",
@@ -109,20 +115,22 @@ def slice_block(cur):
                         "s_cmp_lg_u32 %[sp], 0", "s_cbranch_scc1 .Lfwdw_poll_%=", "s_trap 2", ".Lfwdw_go_%=:"]
         # the reads of fragment F + 2 (the last two fragments read the first two of the next step's tile)
         rd = b_reads(F + 2, "%[lb]") if F + 2 < NF else b_reads(F + 2 - NF, "%[lbn]")
-        gaps[5].append(rd[0])
-        gaps[6].append(rd[1])
-        if F in DMA_FRAGS:
+        if not NOLDS:
+            gaps[RD_GAPS[0]].append(rd[0])
+            gaps[RD_GAPS[1]].append(rd[1])
+        if F in DMA_FRAGS and not NODMA:
             m0, ld = dma[DMA_FRAGS.index(F)]
-            gaps[3].append(m0)
-            gaps[4].append(ld)
-        if F + 1 < NF:
+            gaps[DMA_GAPS[0]].append(m0)
+            gaps[DMA_GAPS[1]].append(ld)
+        if F + 1 < NF and not NOLDS:
             gaps[7].append("s_waitcnt lgkmcnt(2)")       # all but the two newest reads: fragment F + 1 is in
         for m in range(NM):
             L.append(f"v_smfmac_f32_16x16x64_f16 {acc(m, a)}, {vr(a_set(cur, m), 4)}, {vr(BR[RING[F]], 8)}, "
                      f"v{a_idx(cur, m)}")
             L.extend(gaps[m])
-    L.append(f"s_waitcnt vmcnt({NVMEM})")
-    L += ["s_mov_b64 exec, 1", "ds_add_u32 %[cnt], %[one]", "s_mov_b64 exec, -1"]
+    L.append(f"s_waitcnt vmcnt({0 if NODMA else NVMEM})")
+    if not NOSYNC:
+        L += ["s_mov_b64 exec, 1", "ds_add_u32 %[cnt], %[one]", "s_mov_b64 exec, -1"]
     return L
 
 

@@ -1292,3 +1292,66 @@ def test_backward_kernels_agree_on_every_shard(plm, oracle64, monkeypatch):
     for a, b in zip(outs["0"], outs["1"]):
         assert a[0] == b[0]
         np.testing.assert_array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,L,gaps", [(1, 2, False), (130, 17, False), (300, 47, True), (3000, 300, False), (700, 33, False),
+                                      (40000, 60, False), (2000, 130, True)])
+def test_both_forward_kernels_give_the_same_bits(plm, monkeypatch, N, L, gaps):
+    """The plain forward GEMM of 21-state problems in store mode (every evaluation of a fit before the precision switch)
+    runs through k_fwd_w: 512 sequences x 7 states per workgroup, accumulators in AccVGPRs, the K loop generated assembly
+    (DESIGN.md 4.3c); PLM_FWD_KERNEL=0 keeps k_fwd.  Same instruction, same operands, same K order per accumulator:
+    objective and gradient must be identical bit for bit -- one 32-site block, an odd number of 256-sequence tiles (the
+    second half of the last workgroup is empty), gap mode.  PLM_FWD_ACCURATE=0: plm_eval would run the exact kernel."""
+    msa, _ = synthetic_msa(N, L, seed=N + L, q=Q)
+    qm = Q - 1 if gaps else Q
+    rng = np.random.default_rng(N)
+    x = (0.1 * rng.normal(size=plm.n_params(L, qm))).astype(np.float32)
+    w = rng.uniform(0.05, 1.0, N).astype(np.float32)
+    monkeypatch.setenv("PLM_FWD_ACCURATE", "0")
+    got = {}
+    for kern in ("0", "1"):
+        monkeypatch.setenv("PLM_FWD_KERNEL", kern)
+        with plm.PlmContext(msa, q=Q, ignore_gaps=gaps, lambda_h=0.01, lambda_j=3.0) as ctx:
+            ctx.set_weights(w)
+            ctx.set_x(x)
+            got[kern] = ctx.eval() + (ctx.get_g(),)
+    assert got["0"][0] == got["1"][0] and got["0"][1] == got["1"][1]
+    np.testing.assert_array_equal(got["0"][2], got["1"][2])
+    assert np.isfinite(got["1"][2]).all() and np.abs(got["1"][2]).max() > 0
+
+
+@pytest.mark.gpu
+def test_forward_kernels_agree_on_every_shard_and_in_a_fit(plm, oracle64, monkeypatch):
+    """sharded state (a shard runs the forward GEMM over its own site blocks), and a whole variable-projection fit: the
+    iteration tables of the two kernels must be the same line for line"""
+    from evcouplings_amd.dist import ThreadedShards
+    N, L, n_shards = 400, 100, 3
+    msa, _ = synthetic_msa(N, L, seed=11)
+    w = (1.0 / oracle64.reweight(msa, 0.8)).astype(np.float32)
+    x = (0.1 * np.random.default_rng(7).normal(size=plm.n_params(L, Q))).astype(np.float32)
+    monkeypatch.setenv("PLM_FWD_ACCURATE", "0")
+
+    def work(r, coll):
+        with plm.PlmContext(msa, q=Q, lambda_h=0.01, lambda_j=4.2, n_shards=n_shards, shard=r, sharded_state=True) as ctx:
+            ctx.set_collective(coll)
+            ctx.set_weights(w)
+            ctx.set_x(x)
+            return ctx.eval() + (ctx.get_g(),)
+
+    outs, fits = {}, {}
+    for kern in ("0", "1"):
+        monkeypatch.setenv("PLM_FWD_KERNEL", kern)
+        outs[kern] = ThreadedShards(n_shards).run(work)
+        with plm.PlmContext(msa, q=Q, max_iter=25, epsilon=1e-3) as ctx:
+            ctx.set_weights(w)
+            ctx.marginals(pairs=False)
+            ctx.set_x(None)
+            r = ctx.optimize()
+            fits[kern] = (r["table"], ctx.get_x())
+    for a, b in zip(outs["0"], outs["1"]):
+        assert a[0] == b[0]
+        np.testing.assert_array_equal(a[2], b[2])
+    strip = lambda table: [row[:1] + row[2:] for row in table]      # column 1 is the elapsed time
+    assert strip(fits["0"][0]) == strip(fits["1"][0])
+    np.testing.assert_array_equal(fits["0"][1], fits["1"][1])
