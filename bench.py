@@ -277,13 +277,14 @@ def main():
             flops_exec = 2.0 * 2 * ((N + 255) // 256 * 256) * (nu * 32 * q) * (nb16 * 16 * q)
         else:
             # backward: three int8 digit planes of the 24-bit fixed-point residuals, M and N padded to the tile grid
+            # (k_bwd_w: workgroup tile 28 x 9 fragments)
             flops_exec = 2.0 * 3 * ((N + 255) // 256 * 256) * ((nb16 * q + 7 + 27) // 28 * 28 * 16) * (
-                (nb16 * q + 13) // 14 * 14 * 16)
+                (nb16 * q + 8) // 9 * 9 * 16)
         P = L * q + L * (L - 1) // 2 * q * q
         bytes_alg = N * L + 4 * N + 8 * P
         achieved = flops_alg / t_dom / 1e12
         out["roofline"] = {
-            "kernel": "k_fwd" if dom == "forward" else "k_bwd",
+            "kernel": "k_fwd_w" if dom == "forward" else "k_bwd_w",
             "bound": "mfma",
             # SURVEY.md 8(d) primary figure: useful gathered adds of this half of the evaluation against the f32
             # vector peak (the one-hot GEMM formulation does q x redundant flops on the matrix cores to get there)
@@ -293,7 +294,7 @@ def main():
             "frac": achieved / PEAK_F32_VALU_TFLOPS,
             "definition": "SURVEY 8(d) primary: flops_alg/2 = N*L*(L-1)*q gathered adds per launch / HIP-event time "
                           "/ 157.3 TFLOP/s f32 vector peak",
-            "traffic": pmc_traffic_bytes("k_fwd<21_3_1>" if dom == "forward" else "k_bwd<21"),
+            "traffic": pmc_traffic_bytes("k_fwd_w" if dom == "forward" else "k_bwd_w"),
             "traffic_note": "HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/*pmc_counters.csv:"
                             " 2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); "
                             "not re-collected by this run",

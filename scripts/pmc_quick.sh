@@ -18,7 +18,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")
-        if k in ("k_fwd", "k_bwd"):
+        if k in ("k_fwd", "k_bwd", "k_fwd_w", "k_bwd_w"):
             acc[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
     print("%s,%s,%.6g,%d" % (k, c, sum(v) / len(v), len(v)))
