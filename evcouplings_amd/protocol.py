@@ -41,44 +41,42 @@ def uninstall():
 
 
 def infer_plmc(**kwargs):
-    """``evcouplings.couplings.protocol.infer_plmc`` with the HIP solver installed for the call."""
+    """``evcouplings.couplings.protocol.infer_plmc`` with the HIP solver bound for the call (a hook that was already
+    installed stays installed)."""
     import evcouplings.couplings.protocol as cp
-    install()
+    import evcouplings.couplings.tools as ct
+    before = ct.run_plmc
+    ct.run_plmc = tools.run_plmc_hip
     try:
         return cp.infer_plmc(**kwargs)
     finally:
-        uninstall()
+        ct.run_plmc = before
 
 
 # ---- protocol registry entries ------------------------------------------------------------------------------------
 # `couplings/protocol.py:922-931` keeps its inference protocols in the dict PROTOCOLS and `run()` (:934-974) looks the
 # config key `protocol` up there.  register_protocols() adds "standard_hip" and "complex_hip": the reference's own
-# `standard` / `complex` functions with the HIP solver installed for the duration of the call, so a pipeline config
-# selects the GPU path with `protocol: standard_hip` -- and may carry three keys plmc does not have, `hip_solver`
-# ("vp" | "joint"), `hip_gpus` (N | "max") and `hip_conventions` (PLM_CONV_* bits), which travel to run_plmc_hip
-# through the environment variables it reads (the reference's infer_plmc passes a fixed argument list on).
-_ENV_KEYS = {"hip_solver": "PLM_HIP_SOLVER", "hip_gpus": "PLM_HIP_GPUS", "hip_conventions": "PLM_HIP_CONVENTIONS"}
+# `standard` / `complex` functions with the HIP solver bound to `ct.run_plmc` for the duration of the call, so a
+# pipeline config selects the GPU path with `protocol: standard_hip` -- and may carry three keys plmc does not have,
+# `hip_solver` ("vp" | "joint"), `hip_gpus` (N | "max") and `hip_conventions` (PLM_CONV_* bits).  They are bound into
+# the callable the call installs (the reference's infer_plmc passes a fixed argument list on); nothing process-wide
+# changes: the environment is not touched, and whatever `ct.run_plmc` was before the call -- the subprocess path or a
+# hook somebody installed with install() -- is what it is afterwards.
+_OPTION_KEYS = {"hip_solver": "solver", "hip_gpus": "gpus", "hip_conventions": "conventions"}
 
 
 def _wrapped(name):
     def protocol(**kwargs):
-        import os
+        import functools
         import evcouplings.couplings.protocol as cp
-        saved = {}
-        for key, env in _ENV_KEYS.items():
-            if kwargs.get(key) is not None:
-                saved[env] = os.environ.get(env)
-                os.environ[env] = str(kwargs[key])
-        install()
+        import evcouplings.couplings.tools as ct
+        options = {arg: kwargs[key] for key, arg in _OPTION_KEYS.items() if kwargs.get(key) is not None}
+        before = ct.run_plmc
+        ct.run_plmc = functools.partial(tools.run_plmc_hip, **options) if options else tools.run_plmc_hip
         try:
             return cp.PROTOCOLS[name](**kwargs)
         finally:
-            uninstall()
-            for env, old in saved.items():
-                if old is None:
-                    os.environ.pop(env, None)
-                else:
-                    os.environ[env] = old
+            ct.run_plmc = before
     protocol.__name__ = name + "_hip"
     protocol.__doc__ = "evcouplings.couplings.protocol.%s on the MI355X solver (evcouplings_amd.tools.run_plmc_hip)" % name
     return protocol

@@ -217,17 +217,18 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
 
 def run_plmc_hip(alignment, couplings_file, param_file=None, focus_seq=None, alphabet=None, theta=None,
                  scale=None, ignore_gaps=False, iterations=None, lambda_h=None, lambda_J=None,
-                 lambda_g=None, cpu=None, binary=None, solver=None, gpus=None):
+                 lambda_g=None, cpu=None, binary=None, solver=None, gpus=None, conventions=None):
     """
     Drop-in for ``run_plmc`` (evcouplings/couplings/tools.py:126-130): same parameters (``theta``
     is the identity threshold, e.g. 0.8 -- no 1-theta round trip, tools.py:236-239; ``binary``
     is ignored; ``cpu``, plmc's thread count, is validated and ignored), same ``PlmcResult``, ``ResourceError`` for
-    missing inputs/outputs and ``ExternalToolError`` for solver failures.  Two keyword extensions, both also
-    selectable from the environment of an unmodified pipeline: ``solver`` ("vp" | "joint"; PLM_HIP_SOLVER) and
-    ``gpus`` (GPUs of this node to shard the fit over; PLM_HIP_GPUS).
+    missing inputs/outputs and ``ExternalToolError`` for solver failures.  Three keyword extensions, all also
+    selectable from the environment of an unmodified pipeline: ``solver`` ("vp" | "joint"; PLM_HIP_SOLVER),
+    ``gpus`` (GPUs of this node to shard the fit over; PLM_HIP_GPUS) and ``conventions`` (PLM_CONV_* bits;
+    PLM_HIP_CONVENTIONS).
     """
     result, _, _ = infer_to_files(alignment, couplings_file, param_file, focus_seq=focus_seq, alphabet=alphabet,
                                   theta=theta, scale=scale, ignore_gaps=ignore_gaps, iterations=iterations,
                                   lambda_h=lambda_h, lambda_J=lambda_J, lambda_g=lambda_g, cpu=cpu, solver=solver,
-                                  gpus=gpus)
+                                  gpus=gpus, conventions=conventions)
     return result

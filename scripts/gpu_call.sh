@@ -1,6 +1,4 @@
 set -u
-OUT=gpurun_out/r4c40; mkdir -p $OUT
+OUT=gpurun_out/r4c41; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-python bench.py --steps 30 --warmup 5 --no-cpu > $OUT/bench.json 2> $OUT/bench.err; tail -3 $OUT/bench.err; python -c "
-import json; d=json.load(open('$OUT/bench.json')); print({k: d[k] for k in ('value','ms_per_step')}); print(d['roofline']); print(d['fit'])"
-python scripts/time_kernels.py | tee $OUT/kernels.txt
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=15 > $OUT/full.txt 2>&1; echo "exit $?" >> $OUT/full.txt; tail -40 $OUT/full.txt

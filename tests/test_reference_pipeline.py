@@ -145,6 +145,15 @@ def test_registered_protocol_selects_the_gpu_path_and_carries_the_solver_options
         assert shape == (500, 24) and kw["joint"] is True and kw["conventions"] == 512
         assert "PLM_HIP_SOLVER" not in os.environ and "PLM_HIP_CONVENTIONS" not in os.environ
         assert outcfg["num_sites"] == 24 and os.path.getsize(outcfg["ec_file"]) > 0
+        # a hook somebody installed process-wide survives a *_hip protocol call
+        hip_protocol.install()
+        try:
+            kwargs["prefix"] = str(tmp_path / "d" / "job")
+            cp.run(protocol="standard_hip", **kwargs)
+            assert ref["ct"].run_plmc is hip_tools.run_plmc_hip and len(calls) == 2
+        finally:
+            hip_protocol.uninstall()
+        assert ref["ct"].run_plmc is not hip_tools.run_plmc_hip
     finally:
         hip_protocol.unregister_protocols()
     assert "standard_hip" not in cp.PROTOCOLS
