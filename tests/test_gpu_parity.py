@@ -685,7 +685,9 @@ def test_meanfield_rejects_bad_input(plm):
     with pytest.raises(PlmError):
         plm.mean_field(msa, 21, pseudo_count=0.0)            # pseudo-count outside (0, 1)
     with pytest.raises(PlmError):
-        plm.mean_field(msa, 22)                              # alphabets above 21 symbols
+        plm.mean_field(msa, 33)                              # alphabets above 32 symbols
+    out = plm.mean_field(np.random.default_rng(1).integers(0, 22, size=(200, 8)).astype(np.int8), 22)   # 22..32: the padded kernels
+    assert np.isfinite(out["di"]).all() and out["di"].shape == (8, 8)
 
 
 def test_resumed_optimisation_skips_the_known_start_point(plm):
