@@ -291,6 +291,7 @@ struct plm_ctx {
     // changes x, the weights or the scratch use of g -- lets a follow-up plm_ctx_optimize (a resumed fit)
     // start from the known point instead of re-evaluating it
     bool eval_valid = false;
+    bool hj_at_x = false;    // ... and the stored potentials HJ are those of that point (not of a rejected trial)
     double last_fx = 0, last_nll = 0, last_gh2 = 0;
     bool eval_vp = false;      // ... and g is the gradient of the reduced (variable-projection) objective
     // Forward GEMM of the next evaluation: the plain instantiation (f32 accumulation over the whole K range) or the
@@ -1321,7 +1322,9 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     // so that the difference is taken over a longer baseline, where H s outgrows the evaluation error again.
     bool anchored = false;
     double last_cond = std::sqrt(gg + gh2) / std::max(1.0, std::sqrt(xx));   // |g|/max(1,|x|) at the last accepted point
-    if (last_cond <= eps && vp && !resume) {   // a start point that meets the rule must meet it as it ships, too
+    // (a resumed fit as well -- its previous run certified the point for ITS epsilon -- when the potentials of the
+    // point are still there)
+    if (last_cond <= eps && vp && (!resume || c->hj_at_x)) {   // a start point that meets the rule must meet it as it ships, too
         double cj = 0;
         PLM_TRY(shipped_cond(&cj));
         const double r2 = std::max(0.0, cj * cj - last_cond * last_cond);
@@ -1557,6 +1560,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     }
     HIP_TRY(hipStreamSynchronize(c->st));
     c->eval_valid = true;   // every exit path above leaves the last accepted point in (x, g)
+    c->hj_at_x = vp && status != PLM_STATUS_LINESEARCH;   // a failed line search ends on a rejected trial's potentials
     c->eval_vp = vp;
     c->eval_accurate = c->fwd_accurate;
     c->last_fx = fx;
