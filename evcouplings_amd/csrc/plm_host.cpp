@@ -1316,6 +1316,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     double eps_eff = eps;      // target of the reduced gradient: the stop rule minus what the f32 rounding of the fields costs
     double rounding_note = 0;  // > 0: the rule was met on the f64-field point only; what rounding the fields to f32 adds
     int n_cert = 0;
+    double best_cond = 1e300;  // stagnation watch (see the end of the iteration)
+    int best_k = 0, stag_resets = 0;
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
     // The next pair is (x - anchor, g - g(anchor)).  The anchor is the previous accepted point (xp, gp) -- unless the
     // pair(s) since were skipped as noise (below): then it stays where the last STORED pair ended, in its own buffers,
@@ -1556,6 +1558,24 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 anchored = false;
             }
             step = 1.0;
+            // Stagnation next to the stop rule.  Config 3 (N = 100 000) reached |g|/|x| = 1.13e-3 after 264 iterations and
+            // then walked between 1.2e-3 and 4e-3 for 120 more -- curvature pairs taken over steps this short are mostly
+            // differences of evaluation errors (they pass the cosine test above one by one and still add up to a poor
+            // model) -- until a failed line search dropped the history: the preconditioned gradient step that followed
+            // met the rule in three iterations (gpurun_out/r4c45).  So: no new best |g|/|x| for 12 iterations while within
+            // a decade of the rule -> the history is dropped and the next step starts from the preconditioned gradient, at
+            // most three times per fit.
+            if (last_cond < 0.97 * best_cond) {
+                best_cond = last_cond;
+                best_k = k;
+            } else if (vp && k - best_k >= 12 && last_cond < 10.0 * eps && stag_resets < 3 && stored > 0) {
+                stored = 0;
+                end = 0;
+                anchored = false;
+                step = first_step();
+                stag_resets++;
+                best_k = k;
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(c->st));
