@@ -61,3 +61,30 @@ def test_compiler_code_stays_out_of_the_blocks_registers(tmp_path):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_bwd_asm.py"), asm], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "k_bwd_w<21>" in run.stdout and "k_fwd_w" in run.stdout
+
+
+def test_fragment_build_bit_tricks_equal_the_plain_formula():
+    """k_fwd builds the compressed one-hot fragment of a slice from four alignment bytes with compares and shifts per pair
+    (plm_kernels.hip: value 1.0 where (x - 1) >> 2 equals the slice's state group, index nibble (x - 1) & 3); k_fwd_w's
+    assembly does the same with word-wide tricks: a byte-wise decrement without carries, (x + 0x7f7f7f7f) ^ 0x80808080,
+    the groups as (y >> 2) & 0x3f3f3f3f compared byte by byte, the positions packed from bytes to nibbles with
+    t = p | p >> 4 and a byte permute.  Restated here in integer arithmetic for every state byte 0..127."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    m32 = 0xFFFFFFFF
+    cases = [np.arange(4 * k, 4 * k + 4) for k in range(32)] + [rng.integers(0, 128, 4) for _ in range(2000)]
+    for xs in cases:
+        xs = [int(v) for v in xs]
+        word = sum(x << (8 * p) for p, x in enumerate(xs))
+        y = ((word + 0x7F7F7F7F) & m32) ^ 0x80808080
+        for p, x in enumerate(xs):                      # byte-wise x - 1, with 0 -> 0xff
+            assert (y >> (8 * p)) & 0xFF == (x - 1) & 0xFF
+        grp = (y >> 2) & 0x3F3F3F3F
+        pos = y & 0x03030303
+        t = (pos | (pos >> 4)) & m32
+        idx = (t & 0xFF) | (((t >> 16) & 0xFF) << 8)    # v_perm_b32 selector 0x0c0c0200: byte 0, byte 2, zero, zero
+        for p, x in enumerate(xs):
+            u = (x - 1) & m32
+            assert (idx >> (4 * p)) & 0xF == u & 3      # the kernel's `((x - 1) & 3) << (4 * pp)`; upper index bits 0
+            for kg in range(5):
+                assert (((grp >> (8 * p)) & 0xFF) == kg) == ((u >> 2) == kg)
