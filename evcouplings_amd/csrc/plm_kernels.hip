@@ -2091,12 +2091,13 @@ __global__ __launch_bounds__(512) void k_bwd(PlmDims d, const int8_t *__restrict
 
 // ---- k_bwd_w: the same GEMM with the accumulator tile in a[0:251] and the K step in assembly --------------------
 // Workgroup = 4 waves (one per SIMD, 7 row fragments each), wave tile 7 x 9 accumulator fragments = 252 AccVGPRs;
-// the whole K step -- 126 MFMAs, the LDS reads one fragment ahead, the one-hot expansion of the NEXT half step
-// interleaved into the MFMA stream (2 VALU between MFMAs, hidden behind their 16 cycles) -- is one asm block from
-// plm_bwd_asm.inc (scripts/gen_bwd_asm.py has the register map and the reason).  A wave issues 63 MFMAs per 56 VALU
+// the whole K step -- 126 MFMAs, the LDS reads two fragments ahead, the one-hot expansion of the NEXT half step
+// interleaved into the MFMA stream (2 VALU between MFMAs, hidden behind their 16 cycles), the LDS-DMA copies of the
+// step three ahead, the arrival / check protocol that replaces the barrier -- is one asm block from plm_bwd_asm.inc
+// (scripts/gen_bwd_asm.py has the register map, the schedule and the reasons).  A wave issues 63 MFMAs per 56 VALU
 // operations of expansion (k_bwd: 49), and the expansion no longer sits in front of the MFMAs of its own half step.
-// The alignment bytes run one step further ahead than the digit tile (ring of three 8 KB slots) so that the first
-// half of step s + 1 can be expanded during step s.  Results are bit-identical to k_bwd's (exact integer sums).
+// Digit tiles and alignment bytes live in rings of four LDS slots.  Results are bit-identical to k_bwd's (exact
+// integer sums).
 #ifndef PLM_BWDW_INC
 #define PLM_BWDW_INC "plm_bwd_asm.inc"
 #endif

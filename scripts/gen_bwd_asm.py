@@ -15,7 +15,9 @@ Register map of a wave (arch VGPRs; everything below V_LO belongs to the compile
                   the generated ISA for any use of them outside the blocks -- scripts/check_bwd_asm.py)
     XA1, XN0      packed alignment bytes: second half of this step, first half of the next
     BF[0..2]      ring of three digit fragments (LDS -> register, two ahead of the MFMAs that consume them)
-    T0, T1        temporaries of the one-hot expansion
+    T0, T1        temporaries of the one-hot expansion; VCNT the arrival counter as last read
+LDS (set up by the kernel): rings of four digit tiles and four slots of alignment bytes, the arrival counter behind them.
+The docstrings of step_block / dma_ops describe the schedule of a step and the synchronisation without barriers.
 """
 import os
 
