@@ -242,9 +242,10 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 (forward: f16 hi/lo split couplings on the 2:4 sparse MFMA, f32 accumulation -- flushed into f64 "
-                 "sums every 5 K steps in the last iterations of a fit; backward: 24-bit fixed-point residuals as three "
-                 "int8 digit planes on the int8 MFMA, exact int32 accumulation; f64 reductions and field solves).  "
+        "dtype": "f32 (forward: f16 hi/lo split couplings on the 2:4 sparse MFMA, f32 accumulation -- in the last "
+                 "iterations of a fit 39-bit fixed-point couplings as five int8 digit planes, exact; backward: 24-bit "
+                 "fixed-point residuals as three int8 digit planes on the int8 MFMA (32-bit / four there), exact int32 "
+                 "accumulation; f64 reductions and field solves).  "
                  "tests/test_gpu_scale.py prints the error of a float32 CPU build beside the HIP error at every stop point",
         "data": "synthetic",
         "config": {"workload": "headline: synthetic MSA L=%d q=%d N=%d, theta=0.8, lambda_h=0.01, lambda_J=%.1f"
