@@ -1,6 +1,5 @@
 set -u
-OUT=gpurun_out/r4c50; mkdir -p $OUT
+OUT=gpurun_out/r4c51; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 120 python tests/probes/fwd_kernel_ab.py 2>&1 | tail -3 | tee $OUT/ab.txt
-PLM_HIP_LIB=$PWD/evcouplings_amd/libplm_fswar.so timeout 120 python tests/probes/fwd_kernel_ab.py 2>&1 | tail -3 | sed "s/^/swar /" | tee -a $OUT/ab.txt
-PLM_HIP_LIB=$PWD/evcouplings_amd/libplm_fswar.so timeout 120 python tests/probes/fwd_kernel_ab.py 3000 100 2>&1 | tail -3 | sed "s/^/swar-small /" | tee -a $OUT/ab.txt
+python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -2 $OUT/bench.err; python -c "
+import json; d=json.load(open('$OUT/bench.json')); print({k: d[k] for k in ('value','ms_per_step','joint_lbfgs_iterations_per_s')}); r=d['roofline']; print(r['kernel'], r['frac'], r['traffic']); print(r['kernel_ms']); print(d['fit']['to_epsilon_1e-3']['seconds_total'], d['fit']['ignore_gaps']['seconds_optimize']); print(d['cpu_baseline']['value'])"
