@@ -96,6 +96,8 @@ PlmOptions plm_options_from_env() {
     if (const char *e = getenv("PLM_FWD_KERNEL")) o.fwd_kernel = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
+    if (const char *e = getenv("PLM_STAG_ITERS")) o.stag_iters = std::max(2, atoi(e));
+    if (const char *e = getenv("PLM_STAG_DECADES")) o.stag_range = atof(e);
     o.debug = getenv("PLM_DEBUG") != nullptr;
     o.debug_vp = getenv("PLM_DEBUG_VP") != nullptr;
     return o;
@@ -1568,7 +1570,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             if (last_cond < 0.97 * best_cond) {
                 best_cond = last_cond;
                 best_k = k;
-            } else if (vp && k - best_k >= 12 && last_cond < 10.0 * eps && stag_resets < 3 && stored > 0) {
+            } else if (vp && k - best_k >= c->opt.stag_iters && last_cond < c->opt.stag_range * eps && stag_resets < 3 && stored > 0) {
                 stored = 0;
                 end = 0;
                 anchored = false;

@@ -117,6 +117,8 @@ struct PlmOptions {
     int bwd_kernel = -1;    // PLM_BWD_KERNEL: 0 = k_bwd everywhere, otherwise k_bwd_w where it exists (21 states)
     int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
     int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)
+    int stag_iters = 12;       // PLM_STAG_ITERS / PLM_STAG_DECADES: the stagnation watch of plm_ctx_optimize (iterations without
+    double stag_range = 10.0;  // a new best |g|/|x|, and how far above epsilon it starts watching)
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)
     bool debug = false;     // PLM_DEBUG: line-search failures are traced to stderr
     bool debug_vp = false;  // PLM_DEBUG_VP: every round of the field solver is traced to stderr
