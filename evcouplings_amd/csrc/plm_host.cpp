@@ -96,6 +96,7 @@ PlmOptions plm_options_from_env() {
     if (const char *e = getenv("PLM_FWD_KERNEL")) o.fwd_kernel = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
+    if (const char *e = getenv("PLM_ACC_FACTOR")) o.acc_factor = atof(e);
     if (const char *e = getenv("PLM_STAG_ITERS")) o.stag_iters = std::max(2, atoi(e));
     if (const char *e = getenv("PLM_STAG_DECADES")) o.stag_range = atof(e);
     o.debug = getenv("PLM_DEBUG") != nullptr;
@@ -1256,7 +1257,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     // stop rule is decided on a gradient whose error is several times smaller.  The switch happens at an accepted point,
     // which is evaluated once more so that f, g, the pair of the step and the Gram rows all come from one arithmetic.
     const double fwd_noise = 3e-11 * (double)d.N * (double)d.L;
-    const double acc_thr = std::max(3.0 * eps, 8.0 * fwd_noise);
+    const double acc_thr = std::max(3.0 * eps, c->opt.acc_factor * fwd_noise);
     // (a problem whose plain-kernel error is below a twentieth of the stop rule never needs the switch)
     auto want_accurate = [&](double cond) {
         return c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && fwd_noise > 0.05 * eps && cond < acc_thr);

@@ -117,6 +117,7 @@ struct PlmOptions {
     int bwd_kernel = -1;    // PLM_BWD_KERNEL: 0 = k_bwd everywhere, otherwise k_bwd_w where it exists (21 states)
     int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
     int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)
+    double acc_factor = 8.0;   // PLM_ACC_FACTOR: the fit switches to the accurate evaluation below max(3 eps, this x 3e-11 N L)
     int stag_iters = 12;       // PLM_STAG_ITERS / PLM_STAG_DECADES: the stagnation watch of plm_ctx_optimize (iterations without
     double stag_range = 10.0;  // a new best |g|/|x|, and how far above epsilon it starts watching)
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)
