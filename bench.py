@@ -175,6 +175,7 @@ def main():
 
     # --- set-up (untimed): upload, reweight, marginals, start point ------------------------
     t_setup = time.time()
+    native = False
     # epsilon = the production stop rule (it also selects the 24-bit residual planes; a fit asked to go below 1e-4 would
     # run 32-bit ones): far from reachable within warm-up + timed iterations, asserted below
     ctx1 = plm.PlmContext(msa, q=q, lambda_h=0.01, lambda_j=lam_j, device=local_rank, max_iter=args.warmup,
@@ -185,13 +186,14 @@ def main():
     if world > 1:
         # sharded-state mode: parameters, gradient and L-BFGS state split by owning site block; per
         # evaluation two all-to-alls of neighbour blocks + scalar all-reduces over RCCL
-        from evcouplings_amd.dist import (make_torch_collective, make_host_staged_collective, native_rccl_requested,
+        from evcouplings_amd.dist import (make_torch_collective, make_host_staged_collective, negotiate_native_rccl,
                                           share_rccl_id)
         x0 = ctx1.get_x()
         ctx1.close()
         ctx = plm.PlmContext(msa, q=q, lambda_h=0.01, lambda_j=lam_j, device=local_rank, n_shards=world,
                              shard=rank, max_iter=args.warmup, epsilon=1e-3, sharded_state=True)
-        if native_rccl_requested():
+        native = backend == "nccl" and negotiate_native_rccl(device=local_rank)
+        if native:
             ctx.attach_rccl(share_rccl_id())       # collectives issued by the library on its own stream
         else:
             ctx.set_collective(make_torch_collective() if backend == "nccl" else
@@ -224,6 +226,7 @@ def main():
     res = run_iters(args.steps)
     sync()
     dt = time.perf_counter() - t0
+    solver = ctx.solver_stats()          # field solver of the timed window (HIP events inside the library)
     if dist is not None:
         tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -256,8 +259,8 @@ def main():
                    # (4 planes, tighter field solves): their `value` is not like-for-like with r03+.
                    "epsilon": 1e-3, "bwd_digit_planes": 3,
                    "parallelism": "single GPU" if world == 1 else "sites + state sharded x%d (%s)" % (
-                       world, ("RCCL all-to-all, issued by the library" if os.environ.get("PLM_NATIVE_RCCL", "0") not in ("", "0")
-                               else "RCCL all-to-all via torch.distributed") if backend == "nccl"
+                       world, ("RCCL all-to-all, issued by the library on its stream" if native
+                               else "RCCL all-to-all via torch.distributed callbacks") if backend == "nccl"
                        else "gloo, host-staged: flow test only"),
                    "evals_per_iteration": res["n_evals"] / max(1, res["iters"]),
                    "solver": "variable projection (default): one step = one L-BFGS iteration over the couplings with the "
@@ -268,6 +271,14 @@ def main():
     if rank == 0 and world == 1:
         # --- roofline of the dominant kernel (HIP events on the library's stream) ----------
         km = ctx.time_kernels(reps=5)
+        # `fields`: what the field solver of an evaluation REALLY cost in the timed window (its whole chain of passes,
+        # HIP events around it in every evaluation); time_kernels' own figure -- one Newton step + the residual pass --
+        # is kept as fields_one_step.  `total` = the evaluation as the timed window ran it.
+        km["fields_one_step"] = km["fields"]
+        if solver["evaluations"] > 0:
+            km["fields"] = solver["field_ms_per_evaluation"]
+            km["total"] = km["expand"] + km["forward"] + km["fields"] + km["backward"] + km["assemble"]
+        km["field_passes_per_evaluation"] = solver["passes_per_evaluation"]
         dom = "forward" if km["forward"] >= km["backward"] else "backward"
         t_dom = km[dom] * 1e-3
         flops_dense = 2.0 * N * (L * q) ** 2            # one one-hot GEMM (flops_dense / 2)
@@ -293,6 +304,10 @@ def main():
             "peak": PEAK_F32_VALU_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_F32_VALU_TFLOPS,
+            # the same accounting for a whole STEP: both halves of every evaluation the step made (flops_alg x
+            # evaluations per iteration) over the measured ms_per_step -- what is left of `frac` once the field solver,
+            # the L-BFGS vector kernels and the host are counted
+            "frac_per_step": 2.0 * flops_alg * (res["n_evals"] / max(1, res["iters"])) / (dt / args.steps) / 1e12 / PEAK_F32_VALU_TFLOPS,
             "definition": "SURVEY 8(d) primary: flops_alg/2 = N*L*(L-1)*q gathered adds per launch / HIP-event time "
                           "/ 157.3 TFLOP/s f32 vector peak",
             "traffic": pmc_traffic_bytes("k_fwd_w" if dom == "forward" else "k_bwd_w"),

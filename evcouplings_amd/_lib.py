@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("PLM_HIP_LIB") or os.path.join(_HERE, "libplm_hip.so")
 PLM_OK = 0
 STATUS_CONVERGED, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_INTERRUPTED = 0, 1, 2, 3
 ABI_VERSION = 2
-K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_FIELDS, K_FORWARD_ACCURATE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
+K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_FIELDS, K_FORWARD_ACCURATE, K_LBFGS_VECTOR, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+S_COUNT = 4
 
 ITER_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                       C.c_double, C.c_double, C.c_void_p)
@@ -102,6 +103,8 @@ SYMBOLS = [
     ("plm_ctx_optimize", C.c_int, [_P, ITER_CB, _P, C.POINTER(PlmResult)]),
     ("plm_ctx_scores", C.c_int, [_P, _P, _P]),
     ("plm_ctx_time_kernels", C.c_int, [_P, C.c_int32, _P]),
+    ("plm_ctx_solver_stats", C.c_int, [_P, _P]),
+    ("plm_rccl_probe", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int, _P]),
     ("plm_lbfgs_coefficients", None, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]

@@ -96,6 +96,8 @@ PlmOptions plm_options_from_env() {
     if (const char *e = getenv("PLM_FWD_KERNEL")) o.fwd_kernel = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
+    if (const char *e = getenv("PLM_VP_HESS_POS")) o.vp_hess_pos = atoi(e);
+    if (const char *e = getenv("PLM_VP_REL")) o.vp_rel = atof(e);
     if (const char *e = getenv("PLM_ACC_FACTOR")) o.acc_factor = atof(e);
     if (const char *e = getenv("PLM_STAG_ITERS")) o.stag_iters = std::max(2, atoi(e));
     if (const char *e = getenv("PLM_STAG_DECADES")) o.stag_range = atof(e);
@@ -281,11 +283,20 @@ struct plm_ctx {
     // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
     float *hj = nullptr, *hpart = nullptr;
     double *gpart = nullptr;
-    double *hg2 = nullptr, *hinv = nullptr, *h64 = nullptr;   // h64: the field solver's f64 copy of the fields
-    bool vp_refresh_next = false;
-    int *vp_flag = nullptr;    // device-side convergence flag (kept zero: see vp_stage2)
-    int vp_newton_total = 0;   // Newton steps on the fields taken by the current optimisation
-    int vp_hess_age = -1;      // field-solver passes since the cached inverse Hessians were refreshed (-1: none yet)
+    double *hg2 = nullptr, *hinv = nullptr, *h64 = nullptr;   // h64: the field solver's f64 copies of the fields (two buffers)
+    int *vp_flag = nullptr;    // device-side state of the field solver's chain (PlmVpState)
+    int vp_hess_age = -1;      // evaluations since the cached inverse Hessians were refreshed (-1: none exist yet)
+    // host side of the chain (ctx_eval_vp_enqueue / ctx_eval_vp_finish)
+    int vp_c_prev = 3;         // Newton steps the previous evaluation's chain took before it converged
+    int vp_pos = 0;            // chain positions enqueued for the current evaluation
+    int vp_extra = 0;          // continuations of the current evaluation (a chain that ran out of positions)
+    double vp_last_gh2 = 0;    // squared field-gradient norm when the current evaluation's chain was last looked at
+    double vp_floor2 = 0;      // squared noise floor of the field gradient's f32 sums (set by plm_ctx_optimize)
+    hipEvent_t vp_ev[2] = {nullptr, nullptr};   // around the field solver of the last enqueued evaluation
+    bool vp_ev_pending = false;
+    // statistics of the field solver since the last plm_ctx_optimize began (plm_ctx_solver_stats)
+    double stat_field_ms = 0, stat_passes = 0;
+    int stat_field_evals = 0, stat_chain_short = 0;
     int hist_m = 0;
     double *h_scal = nullptr;  // pinned host scalars
     bool have_weights = false;
@@ -387,7 +398,7 @@ int forward_at_x(plm_ctx *c) {
     PLM_TRY(vp_alloc(c));
     HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->fwd_accurate, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr, PLM_VP_ALWAYS, c->st));
     return PLM_OK;
 }
 
@@ -471,8 +482,10 @@ int vp_alloc(plm_ctx *c) {
     PLM_TRY(dalloc((char **)&c->gpart, plm_gpart_bytes(c->d)));
     PLM_TRY(dalloc(&c->hg2, nsites));
     PLM_TRY(dalloc(&c->hinv, nsites * c->d.Q * c->d.Q));
-    PLM_TRY(dalloc(&c->h64, nsites * c->d.Q));
-    PLM_TRY(dalloc(&c->vp_flag, (size_t)1));
+    PLM_TRY(dalloc(&c->h64, 2 * plm_h64_stride(c->d)));
+    PLM_TRY(dalloc((char **)&c->vp_flag, sizeof(PlmVpState)));
+    HIP_TRY(hipMemsetAsync(c->vp_flag, 0, sizeof(PlmVpState), c->st));
+    for (auto &e : c->vp_ev) HIP_TRY(hipEventCreate(&e));
     c->vp_hess_age = -1;
     return PLM_OK;
 }
@@ -493,39 +506,47 @@ int vp_stage1(plm_ctx *c) {
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
     return PLM_OK;
 }
-// stage 2: `newton` Newton steps on the fields from their current values, then the residual pass at the result
-// (Rt, -log P partials; only with write_rt) with the gradient norm of the field subproblems -> scal[5].  refresh: the first step
-// recomputes the per-site Hessians (a pass with more arithmetic), otherwise the cached inverses are reused.
-// reuse: hpart still holds the gradient sums of the residual pass at the current fields (a previous stage 2 that did
-// not meet the tolerance), so the first step needs no pass of its own.
-//
-// A variant that enqueues the whole iteration as one chain with a device-side convergence flag (kernels behind a
-// raised flag return at once, per-site convergence, the backward GEMM conditional on the flag) was built and
-// measured: no host round trips, but it needs more passes per evaluation (3.2 s vs 2.95 s for the headline fit).
-// The kernels keep the hooks (skip / run flags); this host logic does not use them.
-int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse, bool write_rt) {
+// One Newton step on the fields with the cached (or, refresh: recomputed) inverse Hessians + the residual pass at the
+// result: the "fields" leg of plm_ctx_time_kernels.  (The fit's evaluations run the chain below.)
+int vp_step_and_residuals(plm_ctx *c, bool refresh) {
     const PlmDims &d = c->d;
-    HIP_TRY(hipMemsetAsync(c->vp_flag, 0, sizeof(int), c->st));
-    // slots 6, 7 (pass counter and verdict of k_vp_check) lie inside the all-reduced scalar range: a counter that is
-    // never reset is multiplied by the shard count at every all-reduce and overflows after a few hundred of them
-    HIP_TRY(hipMemsetAsync(c->scal + 6, 0, 2 * sizeof(double), c->st));
-    for (int it = 0; it < newton; it++) {
-        const int full = (it == 0 && (refresh || c->vp_hess_age < 0)) ? 1 : 0;
-        if (full || !(it == 0 && reuse))
-            HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, c->fwd_accurate, nullptr, nullptr, c->hpart,
-                                     c->gpart, nullptr, c->st));
-        HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
-                                  c->vp_flag, c->st));
-        c->vp_hess_age = full ? 0 : c->vp_hess_age + 1;
-    }
-    c->vp_newton_total += newton;
-    // the pass at the result: gradient sums for the convergence check (and for the next round's first step); with
-    // write_rt also the residual fragments and -log P partials -- 1.29 GB of writes that only the LAST round's pass
-    // needs to make (ctx_eval_vp decides which rounds write speculatively)
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, write_rt ? 1 : 0, 1, c->fwd_accurate, write_rt ? c->Rt : nullptr,
-                             write_rt ? c->fx_part : nullptr, c->hpart, c->gpart, nullptr, c->st));
+    const int full = (refresh || c->vp_hess_age < 0) ? 1 : 0;
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, c->fwd_accurate, nullptr, nullptr, c->hpart,
+                             c->gpart, nullptr, PLM_VP_ALWAYS, c->st));
+    HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
+                              0.0, nullptr, 0, c->st));
+    if (full) c->vp_hess_age = 0;
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
+                             nullptr, PLM_VP_ALWAYS, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
-                              c->vp_flag, c->st));
+                              0.0, nullptr, 0, c->st));
+    return PLM_OK;
+}
+// stage 2: the field solver as ONE chain of launches (round 5; rounds 2-4 ran it in rounds with a host round trip
+// between them).  A chain position = a pass over the stored potentials in one of two roles -- statistics (gradient
+// sums, at the positions `hess` says also the sampled Hessian sums), or, when the chain predicts that this pass will be
+// the last, gradient sums + residual planes + -log P partials -- then the per-site Newton step (k_hsolve: sites within
+// their share of the tolerance stay where they are) and k_vp_check (chain done? role of the next pass?).  Launches
+// behind the end of the chain return at once (~2 us each).  What the CPU lab (tests/probes/field_solver_lab.py) and the
+// PLM_DEBUG_VP traces of round 4 showed: with the Hessians refreshed only at the first step of a round the early
+// evaluations of a fit needed 9-13 passes and a third of them ended stalled far from the tolerance; a fresh (sampled)
+// Hessian at EVERY step converges at ~0.04 per step from anywhere the cap allows, and a Hessian pass costs 0.41 ms
+// against 0.33 ms.
+int vp_chain(plm_ctx *c, int npos, int hess_upto, int expected_last, double tol2) {
+    const PlmDims &d = c->d;
+    for (int k = 0; k < npos; k++) {
+        const int pos = c->vp_pos++;
+        // Hessian sums: while the previous evaluation says the solver is still far (pos < hess_upto), whenever no
+        // inverse exists yet, and at every position past the expected end (the cached inverses were not good enough)
+        const bool hess = pos < hess_upto || pos > expected_last || c->vp_hess_age < 0;
+        HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, hess ? 2 : 1, c->fwd_accurate, nullptr, nullptr, c->hpart,
+                                 c->gpart, c->vp_flag, PLM_VP_PASS, c->st));
+        HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
+                                 c->vp_flag, PLM_VP_PASS_RT, c->st));
+        HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, hess ? 2 : 0, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2,
+                                  c->scal + 5, tol2, c->vp_floor2, c->vp_flag, 1, c->st));
+        if (hess) c->vp_hess_age = 0;
+    }
     return PLM_OK;
 }
 // stage 3: backward GEMM, gradient of the reduced objective, objective value
@@ -534,9 +555,9 @@ int vp_stage2(plm_ctx *c, int newton, bool refresh, bool reuse, bool write_rt) {
 int vp_stage3(plm_ctx *c, bool conditional, float *gout = nullptr, int mode = 2) {
     const PlmDims &d = c->d;
     if (!gout) gout = c->g;
-    // conditional: the backward GEMM runs only if the chain in front of it converged -- the host sees the same
-    // gradient norm and repeats stage 3 after finishing the fields.  Not when sharded: a shard judges its own sites
-    // only, the host the all-reduced norm, and the two can disagree.
+    // conditional: the backward GEMM runs only if the chain in front of it is done (PlmVpState::done is the first int
+    // of the state) -- otherwise the host continues the chain and enqueues stage 3 again.  Not when sharded: every rank
+    // takes part in the gradient-halo exchange of every stage 3, and the ranks' chains end independently.
     if (d.nblk_own > 0 || !d.sharded)
         HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, (conditional && !d.sharded) ? c->vp_flag : nullptr, c->st));
     if (d.sharded) {
@@ -552,54 +573,101 @@ int vp_stage3(plm_ctx *c, bool conditional, float *gout = nullptr, int mode = 2)
                                      c->st));
     return PLM_OK;
 }
-// the whole evaluation: the field solver iterates until the subproblem gradient is below tol2 (or stalls at its
-// f32 summation floor); the check costs one extra host synchronisation per evaluation (sharded: one scalar all-reduce)
-int ctx_allreduce_scalars(plm_ctx *c, int first, int count);
-int fetch_scalars(plm_ctx *c, int first, int count);
-// the whole evaluation: the field solver iterates until the subproblem gradient is below tol2 (or stalls at its
-// f32 floor); the check costs one extra host synchronisation per evaluation (sharded: one scalar all-reduce)
-int ctx_eval_vp(plm_ctx *c, int *newton_io, double tol2, double *gh2_out) {
+// The whole evaluation, enqueued without a host round trip: forward GEMM, the field solver's chain, the residual pass
+// (skipped on the device when the pass that ended the chain wrote the planes), backward GEMM (only if the chain is
+// done), assemble.  The caller appends what it needs of the result (dot products, Gram rows), synchronises ONCE with
+// scalar slots 5..7 among the values it fetches (sharded: all-reduces them), and calls ctx_eval_vp_finish.
+int ctx_eval_vp_enqueue(plm_ctx *c, double tol2) {
+    const PlmDims &d = c->d;
     PLM_TRY(vp_stage1(c));
-    double prev = INFINITY, gh2 = INFINITY;
-    int newton = *newton_io, rounds = 0;
-    bool rt_current = false;   // Rt / fx_part were written at the fields the solver stopped at
-    const bool debug_vp = c->opt.debug_vp;
-    for (int round = 0;; round++) {
-        // Hessians: refreshed when none exist, periodically, and whenever a round with the cached ones fell short
-        const bool refresh = c->vp_hess_age < 0 ||
-                             (round == 0 ? (c->vp_hess_age >= 64 || c->vp_refresh_next) : c->vp_hess_age > 0);
-        // Only the last round's pass has to write the residual fragments.  Rounds 0 and 1 write them speculatively (late
-        // in a fit round 0 is the only round; round 1 converges more often than not: measured, 353 of 632 evaluations of
-        // a headline bench run ended on a round that a contraction estimate had written off); a later round does so when
-        // the contraction seen so far says it will meet the tolerance, else its pass is the cheaper statistics-only one
-        // and the fragments are written once, after the loop.
-        const double rate = (round > 1 && prev < INFINITY && gh2 < prev) ? std::max(1e-6, gh2 / prev) : 1e-6;
-        const bool write_rt = round <= 1 || gh2 * rate <= tol2;
-        prev = gh2;
-        PLM_TRY(vp_stage2(c, newton, refresh && newton > 0, round > 0, write_rt));
-        PLM_TRY(ctx_allreduce_scalars(c, 5, 1));
-        PLM_TRY(fetch_scalars(c, 5, 1));
-        gh2 = c->h_scal[5];
-        *gh2_out = gh2;
-        rounds = round;
-        rt_current = write_rt;
-        if (debug_vp)
-            fprintf(stderr, "[plm vp] eval %d round %d: newton=%d hess_age=%d |g_h|=%.3e tol=%.3e rt=%d\n", c->n_evals, round,
-                    newton, c->vp_hess_age, std::sqrt(gh2), std::sqrt(tol2), (int)write_rt);
-        // done: converged, or not finite (the line search deals with that), or no longer improving (f32 floor)
-        if (!(gh2 > tol2) || round >= 8 || (round > 1 && gh2 > 0.25 * prev)) break;
-        newton = 2;
-    }
-    if (!rt_current)   // the last round ended on a statistics-only pass: residual fragments and -log P at its fields
-        HIP_TRY(plm_launch_hpass(c->d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr,
-                                 c->st));
-    // steps to try first at the next trial point: one more if this one needed extra rounds, one fewer (down to
-    // none: the L-BFGS extrapolation of the fields is then good enough) if it met the tolerance with room to spare
-    c->vp_refresh_next = rounds > 0;   // the cached Hessians were too stale for this step size: start fresh next time
-    if (rounds > 0) *newton_io = std::min(3, *newton_io + 1);
-    else if (*gh2_out < 0.25 * tol2) *newton_io = std::max(0, *newton_io - 1);
-    PLM_TRY(vp_stage3(c, false));
+    if (c->vp_ev_pending) c->vp_ev_pending = false;     // (an evaluation nobody waited for: its events are re-recorded)
+    HIP_TRY(hipEventRecord(c->vp_ev[0], c->st));
+    // a chain expected to end on its first pass (late in a fit: the L-BFGS extrapolation of the fields is within the
+    // tolerance) starts in the residual-writing role
+    const int c_prev = c->vp_c_prev;
+    HIP_TRY(plm_launch_vp_reset(c->vp_flag, (c_prev == 0 && c->vp_hess_age >= 0) ? 1 : 0, c->st));
+    HIP_TRY(hipMemsetAsync(c->scal + 5, 0, 3 * sizeof(double), c->st));
+    c->vp_pos = 0;
+    c->vp_extra = 0;
+    c->vp_last_gh2 = INFINITY;
+    if (c->vp_hess_age >= 0) c->vp_hess_age++;
+    int hess_upto = c_prev >= 2 ? c_prev : ((c->vp_hess_age < 0 || c->vp_hess_age >= 32) ? 1 : 0);
+    if (c->opt.vp_hess_pos >= 0 && c_prev >= 2) hess_upto = std::min(hess_upto, c->opt.vp_hess_pos);
+    PLM_TRY(vp_chain(c, std::min(14, c_prev + 3), hess_upto, c_prev, tol2));
+    HIP_TRY(plm_launch_fields_to_x(d, c->h64, c->vp_flag, c->x, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr,
+                             c->vp_flag, PLM_VP_FINAL, c->st));
+    HIP_TRY(hipEventRecord(c->vp_ev[1], c->st));
+    c->vp_ev_pending = true;
+    PLM_TRY(vp_stage3(c, true));
     c->n_evals++;
+    return PLM_OK;
+}
+// After the caller's synchronisation (h_scal[5..7]: squared field-gradient norm, passes, verdict -- summed over the
+// shards).  *again = false: the evaluation is complete, *gh2_out = the norm left by the solver.  *again = true: the chain
+// ran out of positions before it was done (or, sharded, some rank's did): more of it, the residual pass and stage 3 have
+// been enqueued again -- the caller repeats its own launches and synchronises once more.
+int ctx_eval_vp_finish(plm_ctx *c, double tol2, bool *again, double *gh2_out) {
+    const PlmDims &d = c->d;
+    const int nsh = d.sharded ? d.nshards : 1;
+    const double gh2 = c->h_scal[5];
+    const int passes = (int)std::lround(c->h_scal[6] / nsh);
+    const bool done = c->h_scal[7] > nsh - 0.5;
+    if (c->vp_ev_pending) {      // both events lie in front of the synchronisation the caller just made
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->vp_ev[0], c->vp_ev[1]) == hipSuccess) {
+            c->stat_field_ms += ms;
+            if (c->vp_extra == 0) c->stat_field_evals++;
+        }
+        c->vp_ev_pending = false;
+    }
+    *gh2_out = gh2;
+    *again = false;
+    if (c->opt.debug_vp) {
+        fprintf(stderr, "[plm vp] eval %d%s: %d passes (expected %d steps), done=%d |g_h|=%.3e tol=%.3e |", c->n_evals - 1,
+                c->vp_extra ? " (continued)" : "", passes, c->vp_c_prev, (int)done, std::sqrt(gh2), std::sqrt(tol2));
+        PlmVpState S;      // per-pass history (debug only: one more small copy)
+        if (hipMemcpy(&S, c->vp_flag, sizeof S, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < std::min(S.passes, PLM_VP_HIST); k++) {
+                const double open_sites = std::floor(S.hist[k] / 1e9);
+                fprintf(stderr, " %.2e/%d", std::sqrt(S.hist[k] - open_sites * 1e9), (int)open_sites);
+            }
+        fprintf(stderr, "\n");
+    }
+    if (c->vp_extra == 0) c->stat_passes += passes;
+    if (done && c->vp_extra == 0) {
+        c->vp_c_prev = std::max(0, passes - 1);
+        return PLM_OK;
+    }
+    if (c->vp_extra > 0) {
+        // a continuation always ends with an unconditional residual pass + stage 3: the evaluation is complete.  Go on
+        // only while the solver still makes progress towards a tolerance it has not met (bounded)
+        const bool stalled = !(gh2 > tol2) || gh2 > 0.25 * c->vp_last_gh2 || c->vp_extra >= 3 || !std::isfinite(gh2);
+        if (done || stalled) {
+            c->vp_c_prev = std::min(11, std::max(c->vp_pos - 1, 0));
+            return PLM_OK;
+        }
+    } else {
+        c->stat_chain_short++;
+    }
+    // the chain ran out of positions: six more with fresh Hessians, then the residual pass with the gradient norm at its
+    // fields (unconditional) and stage 3 (unconditional)
+    c->vp_last_gh2 = gh2;
+    c->vp_extra++;
+    HIP_TRY(hipEventRecord(c->vp_ev[0], c->st));
+    HIP_TRY(hipMemsetAsync(c->scal + 5, 0, 3 * sizeof(double), c->st));
+    if (gh2 > tol2) PLM_TRY(vp_chain(c, 6, 1 << 30, -1, tol2));
+    HIP_TRY(plm_launch_fields_to_x(d, c->h64, c->vp_flag, c->x, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
+                             c->vp_flag, PLM_VP_ALWAYS, c->st));
+    // norm only (update = 0, not a chain position: k_vp_check writes the sum alone -- passes / verdict of the continued
+    // chain stay), at the chain's current fields
+    HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
+                              0.0, c->vp_flag, 0, c->st));
+    HIP_TRY(hipEventRecord(c->vp_ev[1], c->st));
+    c->vp_ev_pending = true;
+    PLM_TRY(vp_stage3(c, false));
+    *again = true;
     return PLM_OK;
 }
 int fetch_scalars(plm_ctx *c, int first, int count) {
@@ -755,6 +823,8 @@ const char *plm_last_error(void) { return g_err.c_str(); }
 void plm_ctx_destroy(plm_ctx_t *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    for (auto &e : c->vp_ev)
+        if (e) (void)hipEventDestroy(e);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
                     c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->vp_flag,
@@ -928,6 +998,45 @@ int plm_rccl_selftest(int device, void *stream) {
                 break;
             }
     if (buf) hipFree(buf);
+    plm_rccl_destroy(r);
+    return rc;
+}
+
+// A communicator of `nranks` formed from `rccl_id`, one all-reduce and one all-to-all (1 KB to every peer) across it, the
+// communicator destroyed again: every rank calls this before a multi-GPU job commits to the library-issued transport
+// (evcouplings_amd/dist.py negotiates the outcome over torch.distributed and falls back to host callbacks otherwise).
+int plm_rccl_probe(const void *rccl_id, int32_t nranks, int32_t rank, int device, void *stream) {
+    if (!rccl_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(PLM_EINVAL, "bad communicator shape");
+    PLM_TRY(check_device(device));
+    hipStream_t st = (hipStream_t)stream;
+    PlmRccl *r = nullptr;
+    if (plm_rccl_init(rccl_id, nranks, rank, &r) != 0)
+        return fail(PLM_ECALLBACK, "RCCL communicator of %d ranks: %s", nranks, plm_rccl_error());
+    const int per = 128;                                   // doubles per peer message
+    double *buf = nullptr;
+    int rc = dalloc(&buf, (size_t)(2 * nranks + 1) * per);
+    std::vector<double> h((size_t)(2 * nranks + 1) * per, 0.0);
+    for (int k = 0; k < nranks; k++)
+        for (int j = 0; j < per; j++) h[(size_t)k * per + j] = 1000.0 * rank + k;          // message to rank k
+    h[(size_t)2 * nranks * per] = 1.0 + rank;
+    const std::vector<int64_t> counts((size_t)nranks, (int64_t)sizeof(double) * per);
+    const int64_t one = sizeof(double);
+    if (rc == PLM_OK && hipMemcpyAsync(buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = fail(PLM_EDEVICE, "upload failed");
+    if (rc == PLM_OK && plm_rccl_collective(r, PLM_COLL_ALLTOALL, buf, buf + (size_t)nranks * per, counts.data(), counts.data(), st) != 0)
+        rc = fail(PLM_ECALLBACK, "all-to-all: %s", plm_rccl_error());
+    if (rc == PLM_OK && plm_rccl_collective(r, PLM_COLL_ALLREDUCE_F64, buf + (size_t)2 * nranks * per, nullptr, &one, &one, st) != 0)
+        rc = fail(PLM_ECALLBACK, "all-reduce: %s", plm_rccl_error());
+    if (rc == PLM_OK && (hipMemcpyAsync(h.data(), buf, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                         hipStreamSynchronize(st) != hipSuccess))
+        rc = fail(PLM_EDEVICE, "download failed");
+    if (rc == PLM_OK) {
+        if (h[(size_t)2 * nranks * per] != 0.5 * nranks * (nranks + 1)) rc = fail(PLM_ECALLBACK, "all-reduce returned a wrong sum");
+        for (int k = 0; k < nranks && rc == PLM_OK; k++)
+            if (h[(size_t)(nranks + k) * per] != 1000.0 * k + rank) rc = fail(PLM_ECALLBACK, "all-to-all delivered a wrong message from rank %d", k);
+    }
+    if (buf) hipFree(buf);
+    hipStreamSynchronize(st);
     plm_rccl_destroy(r);
     return rc;
 }
@@ -1231,24 +1340,36 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         return PLM_OK;
     };
 
-    // variable projection: the fields are solved exactly for every trial couplings (vp_stage2); L-BFGS then only
-    // sees the couplings (field part of g is zero, field part of s = the change of the optimal fields)
+    // variable projection: the fields are solved exactly for every trial couplings (the chain of ctx_eval_vp_enqueue);
+    // L-BFGS then only sees the couplings (field part of g is zero, field part of s = the change of the optimal fields)
     const bool vp = vp_enabled(c);
     if (vp) PLM_TRY(vp_alloc(c));
-    c->vp_newton_total = 0;
-    int vp_newton = 2;                       // Newton steps per evaluation (warm start: the L-BFGS extrapolation)
+    c->stat_field_ms = c->stat_passes = 0;
+    c->stat_field_evals = c->stat_chain_short = 0;
     double gh2 = 0;                          // |grad_h|^2 left by the field solver at the current point
     // field-solver tolerance: a fraction of what the stop rule allows the whole gradient, and never below what the
     // solver can reach.  The fields themselves are iterated in f64 (k_hsolve); what is left is the random f32
     // rounding of the stored potentials and of the softmax, ~1e-7 per (sequence, site) term, i.e.
     // ~sqrt(N_eff) per entry (measured with scripts/vp_floor_probe.py: 3e-8 ... 3e-7 sqrt(N_eff L q) in norm).  Below
-    // it an evaluation only burns rounds until the stall test of ctx_eval_vp ends it.
+    // it an evaluation only burns passes until the stall test of ctx_eval_vp_finish ends it.
     // (A tolerance relative to the current gradient of the couplings -- inexact field solves far from the optimum --
     // was measured: 0.3 % of |g| costs 15 % more iterations at the headline and stalls config 2 at |g|/|x| = 0.1.)
     const double vp_floor = c->opt.vp_floor;   // 2e-7 unless a probe set PLM_VP_FLOOR
+    // Far from the optimum that absolute tolerance is ~1e-7 of the gradient the fields are solved FOR: the solve may stop
+    // at vp_rel (1e-4) of the norm of the reduced gradient at the last accepted point -- the error it leaves in a trial's
+    // gradient is of that relative size, far below what a quasi-Newton step notices, and it only binds while
+    // |g|/|x| > 0.1 eps / vp_rel (= 1 at the default stop rule).  What it saves is the tail of every early chain: a
+    // handful of sites whose sampled Hessians are poor converge at 0.6 per pass and kept the chain going for 5-9 passes
+    // between |g_h| = 0.5 and the absolute tolerance (PLM_DEBUG_VP traces of round 5).  Rounds 2-4 ended those
+    // evaluations by a stall rule instead, at |g_h| up to 1e5; a tolerance of 3e-3 |g| was measured then (15 % more
+    // iterations, config 2 stalling at |g|/|x| = 0.1) -- 30 times looser than this one.
+    // The floor itself is not part of the tolerance any more (round 5): the chain ends ON the pass that meets the
+    // tolerance, so a tolerance of the floor's size would leave |g_h| at that size -- 2e-6 |x| on a small problem, the
+    // whole of a tight stop rule; the chain goes below the floor while a pass still gains a factor 2 (k_vp_check).
+    const double vp_rel = c->opt.vp_rel;
+    c->vp_floor2 = vp_floor * vp_floor * c->n_eff * (double)d.L * d.Q;
     auto vp_tol2 = [&](double xnorm2) {
-        const double t = std::max(0.1 * eps * std::max(1.0, std::sqrt(xnorm2)),
-                                  vp_floor * std::sqrt(c->n_eff * (double)d.L * d.Q));
+        const double t = std::max(0.1 * eps * std::max(1.0, std::sqrt(xnorm2)), vp_rel * std::sqrt(gg));
         return t * t;
     };
     // Forward-GEMM mode.  The plain instantiation's f32 accumulation leaves an error of ~3e-11 N L |x| in the gradient
@@ -1266,20 +1387,23 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     const bool resume = c->eval_valid && c->eval_vp == vp;
     ctx_set_accurate(c, c->opt.fwd_mode == 1 || (c->opt.fwd_mode != 0 && resume && c->eval_accurate));
     auto start_eval = [&](bool have) -> int {
+        const double tol2 = vp_tol2((double)d.L);
         if (!have) {
             if (!vp) PLM_TRY(ctx_eval_enqueue(c));
-            else {
-                int first = 3;   // J = 0 typically: the start fields are near the independent-site optimum
-                PLM_TRY(ctx_eval_vp(c, &first, vp_tol2((double)d.L), &gh2));
-            }
+            else PLM_TRY(ctx_eval_vp_enqueue(c, tol2));
         }
-        PlmVecList Qg, Bg;
-        Qg.n = 1; Qg.v[0] = c->g;
-        Bg.n = 2; Bg.v[0] = c->g; Bg.v[1] = c->g;
-        HIP_TRY(plm_launch_multidot(Qg, Bg, n, c->dot_scratch, c->scal + SL_MD, dinv, 1u, 1ull, c->st));   // gDg, gg
-        PLM_TRY(norm_dots());
-        PLM_TRY(ctx_allreduce_scalars(c, have ? SL_DG : 0, (have ? 8 - SL_DG : 8) + 2));
-        PLM_TRY(fetch_scalars(c, 0, 10));
+        for (;;) {
+            PlmVecList Qg, Bg;
+            Qg.n = 1; Qg.v[0] = c->g;
+            Bg.n = 2; Bg.v[0] = c->g; Bg.v[1] = c->g;
+            HIP_TRY(plm_launch_multidot(Qg, Bg, n, c->dot_scratch, c->scal + SL_MD, dinv, 1u, 1ull, c->st));   // gDg, gg
+            PLM_TRY(norm_dots());
+            PLM_TRY(ctx_allreduce_scalars(c, have ? SL_DG : 0, (have ? 8 - SL_DG : 8) + 2));
+            PLM_TRY(fetch_scalars(c, 0, 10));
+            bool again = false;
+            if (vp && !have) PLM_TRY(ctx_eval_vp_finish(c, tol2, &again, &gh2));
+            if (!again) break;
+        }
         gDg = c->h_scal[SL_MD];
         gg = c->h_scal[SL_MD + 1];
         xx = c->h_scal[SL_XX];
@@ -1307,7 +1431,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     auto shipped_cond = [&](double *out) -> int {
         HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
         HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr,
-                                 nullptr, c->st));
+                                 nullptr, PLM_VP_ALWAYS, c->st));
         PLM_TRY(vp_stage3(c, false, c->dir, 0));
         const float *a[1] = {c->dir};
         PLM_TRY(dots(c, 1, a, a, n, SL_DG));
@@ -1366,8 +1490,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             double gh2_trial = 0;
             // objective + gradient at the trial point c->x, and with it everything the NEXT direction needs
             auto evaluate_trial = [&]() -> int {
+                const double tol2 = vp_tol2(xx);
                 if (!vp) PLM_TRY(ctx_eval_enqueue(c));
-                else PLM_TRY(ctx_eval_vp(c, &vp_newton, vp_tol2(xx), &gh2_trial));
+                else PLM_TRY(ctx_eval_vp_enqueue(c, tol2));
+              for (;;) {
                 const float *a[1] = {c->g}, *b[1] = {c->dir};
                 PLM_TRY(dots(c, 1, a, b, n, SL_DG));
                 // Speculate that this trial point is accepted (it is, 97 % of the time): form its (s, y) pair
@@ -1380,6 +1506,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 PLM_TRY(norm_dots());
                 PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
                 PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
+                bool again = false;      // the field solver's chain ran out of positions: more was enqueued (rare)
+                if (vp) PLM_TRY(ctx_eval_vp_finish(c, tol2, &again, &gh2_trial));
+                if (!again) break;
+              }
                 return PLM_OK;
             };
             int brackt = 0, stage1 = 1, count = 0, uinfo = 0, lsrc = 1;
@@ -1662,7 +1792,9 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
 int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     if (!c || !out_ms || reps <= 0) return fail(PLM_EINVAL, "bad argument");
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
-    if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "kernel timing runs on 1-shard contexts");
+    // one shard of the sharded-state mode can be timed alone (its kernels over its own site blocks; the halo buffers are
+    // read as they are -- the collectives that fill them are not part of this measurement): scripts/shard_compute.py
+    if (c->d.nshards > 1 && !c->d.sharded) return fail(PLM_EUNSUPPORTED, "kernel timing runs on 1-shard or sharded-state contexts");
     HIP_TRY(hipSetDevice(c->device));
     c->eval_valid = false;
     ctx_set_accurate(c, false);   // the evaluation pipeline is timed with the plain arithmetic (the exact forward GEMM separately)
@@ -1679,22 +1811,29 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     for (int r = 0; r < reps; r++) {
         float ms;
         HIP_TRY(hipEventRecord(ev[0], c->st));
-        HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
-        HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
+        if (d.sharded) {
+            HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
+                                       d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, d.jexp_bias, c->st));
+            HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
+        } else {
+            HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
+            HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
+        }
         HIP_TRY(hipEventRecord(ev[1], c->st));
         if (vp) {   // the fit's pipeline: forward GEMM -> HJ, 2 Newton steps on the fields, residual pass
             HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, 0, c->st));
             HIP_TRY(hipEventRecord(ev[2], c->st));
-            PLM_TRY(vp_stage2(c, 1, r == 0, false, true));   // one Newton step + the residual pass
+            PLM_TRY(vp_step_and_residuals(c, r == 0));   // one Newton step + the residual pass
             HIP_TRY(hipEventRecord(ev[5], c->st));
         } else {
             PLM_TRY(forward_at_x(c));
             HIP_TRY(hipEventRecord(ev[2], c->st));
             HIP_TRY(hipEventRecord(ev[5], c->st));
         }
-        HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
+        if (d.nblk_own > 0 || !d.sharded) HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, nullptr, c->st));
         HIP_TRY(hipEventRecord(ev[3], c->st));
-        HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
+        if (d.sharded) HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
+        HIP_TRY(plm_launch_assemble(d, c->G, d.ksplit, d.sharded ? c->ghalo : nullptr, c->x, c->g, c->prob.lambda_h, c->prob.lambda_j,
                                     c->reg_part, vp ? 2 : 0, 0.f, nullptr, 0.f, c->st));
         HIP_TRY(plm_launch_finish_fx(d, c->fx_part, c->n_fx_part(), nullptr, 0, c->reg_part, plm_reg_parts(d),
                                      c->scal, c->st));
@@ -1707,7 +1846,45 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); acc[PLM_K_ASSEMBLE] += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[4])); acc[PLM_K_TOTAL] += ms;
     }
-    if (vp) {   // the exact forward GEMM (last iterations of a fit, plm_eval), on its own operand
+    {   // the L-BFGS vector kernels of one iteration with a full history of m = 6: trial point, pair + Gram pass, direction
+        const int m = 6;
+        PLM_TRY(ctx_alloc_lbfgs(c, m));
+        const int64_t n = d.n_local;
+        float *S = c->hist, *Y = c->hist + (size_t)m * n;
+        PlmVecList Qv, B;
+        PlmCoefList C;
+        Qv.n = 3; Qv.v[0] = S; Qv.v[1] = Y; Qv.v[2] = c->g;
+        B.n = 0;
+        for (int i = 0; i < m; i++) B.v[B.n++] = S + (size_t)i * n;
+        for (int i = 0; i < m; i++) B.v[B.n++] = Y + (size_t)i * n;
+        B.v[B.n++] = c->g;
+        B.v[B.n++] = c->g;
+        for (int i = 0; i < B.n; i++) C.c[i] = 0.f;
+        HIP_TRY(hipMemsetAsync(c->hist, 0, sizeof(float) * 2 * (size_t)m * n, c->st));
+        HIP_TRY(hipMemsetAsync(c->dir, 0, sizeof(float) * n, c->st));
+        HIP_TRY(hipMemcpyAsync(c->xp, c->x, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+        HIP_TRY(hipMemcpyAsync(c->gp, c->g, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
+        HIP_TRY(hipEventRecord(ev[0], c->st));
+        for (int r = 0; r < reps; r++) {
+            const float *a[1] = {c->g}, *b[1] = {c->dir}, *xx[1] = {c->x};
+            HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, 0.f, c->dir, n, c->st));
+            HIP_TRY(plm_launch_dots(1, a, b, n, c->dot_scratch, c->scal + 2, c->st));
+            HIP_TRY(plm_launch_sy(S, Y, c->x, c->xp, c->g, c->gp, n, c->st));
+            HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + 8, nullptr, 6u, 0ull, c->st));
+            HIP_TRY(plm_launch_dots(1, xx, xx, n, c->dot_scratch, c->scal + 3, c->st));
+            HIP_TRY(plm_launch_dots(1, xx, xx, d.nh_pad_l, c->dot_scratch, c->scal + 4, c->st));
+            B.n -= 1;
+            HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, nullptr, m, c->st));
+            B.n += 1;
+        }
+        HIP_TRY(hipEventRecord(ev[1], c->st));
+        HIP_TRY(hipEventSynchronize(ev[1]));
+        float ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        acc[PLM_K_LBFGS_VECTOR] = ms;
+        HIP_TRY(hipMemsetAsync(c->hist, 0, sizeof(float) * 2 * (size_t)m * n, c->st));
+    }
+    if (vp && !d.sharded) {   // the exact forward GEMM (last iterations of a fit, plm_eval), on its own operand
         float ms;
         HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, 1, c->st));
         HIP_TRY(hipEventRecord(ev[0], c->st));
@@ -1728,6 +1905,15 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         acc[PLM_K_REWEIGHT] = ms * reps;
     }
     for (int k = 0; k < PLM_K_COUNT; k++) out_ms[k] = (float)(acc[k] / reps);
+    return PLM_OK;
+}
+
+int plm_ctx_solver_stats(plm_ctx_t *c, double *out) {
+    if (!c || !out) return fail(PLM_EINVAL, "NULL argument");
+    out[PLM_S_EVALS] = c->stat_field_evals;
+    out[PLM_S_FIELD_MS] = c->stat_field_ms;
+    out[PLM_S_PASSES] = c->stat_passes;
+    out[PLM_S_CHAIN_SHORT] = c->stat_chain_short;
     return PLM_OK;
 }
 

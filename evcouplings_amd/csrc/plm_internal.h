@@ -120,6 +120,8 @@ struct PlmOptions {
     double acc_factor = 8.0;   // PLM_ACC_FACTOR: the fit switches to the accurate evaluation below max(3 eps, this x 3e-11 N L)
     int stag_iters = 12;       // PLM_STAG_ITERS / PLM_STAG_DECADES: the stagnation watch of plm_ctx_optimize (iterations without
     double stag_range = 10.0;  // a new best |g|/|x|, and how far above epsilon it starts watching)
+    int vp_hess_pos = -1;   // PLM_VP_HESS_POS: chain positions that may carry fresh Hessian sums (-1: all before the expected last)
+    double vp_rel = 1e-4;   // PLM_VP_REL: field-solver tolerance relative to the reduced gradient of the last accepted point
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)
     bool debug = false;     // PLM_DEBUG: line-search failures are traced to stderr
     bool debug_vp = false;  // PLM_DEBUG_VP: every round of the field solver is traced to stderr
@@ -167,15 +169,40 @@ hipError_t plm_launch_forward_store(const PlmDims &d, const int8_t *msa_rm, cons
 int plm_fwd_groups(int q, int exact);
 // one pass over HJ with the fields of x: per-workgroup per-site sums for the field solver (stats 1: gradient sums
 // into gpart (f64), 2: also Hessian sums -- exact diagonal, sampled off-diagonal -- into hpart (f32)) and, with write_rt, the residual fragments (Rt) and -log P partials
-// (fx_part) of the solver's forward epilogue.  skip (device int, may be NULL): non-zero = do nothing.
+// (fx_part) of the solver's forward epilogue.  state / cond: the launch's role in the field solver's device-side chain
+// (PlmVpState below; NULL / PLM_VP_ALWAYS: unconditional).
 // exact: the passes of an accurate evaluation (exact-argument exponentials, see exp_softmax)
 hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w,
                             const double *h64, int write_rt, int stats, int exact, void *Rt, double *fx_part, float *hpart,
-                            double *gpart, const int *skip, hipStream_t st);
+                            double *gpart, const int *state, int cond, hipStream_t st);
+// The field solver of one evaluation is ONE chain of launches without host round trips: per chain
+// position a statistics pass over the stored potentials OR (when the chain predicts that this pass is the last) a pass
+// that also writes the residual planes, then the per-site Newton step, then k_vp_check.  The state lives in HBM; every
+// launch of the chain looks at it first and returns at once when its role is not wanted.
+#define PLM_VP_HIST 24
+struct PlmVpState {
+    int done;         // every site is within its share of the tolerance: the rest of the chain does nothing
+    int want_rt;      // the next pass is predicted to be the last: it runs in its residual-writing role
+    int final_skip;   // the pass that ended the chain wrote the residual planes: the separate last pass is not needed
+    int passes;       // passes executed
+    int cur;          // which of the two field buffers (h64 + cur * plm_h64_stride) holds the current fields: a step is
+                      // written to the other one and becomes current only if the chain goes on (k_vp_check)
+    int pad_;
+    double g2_prev;   // squared gradient norm of the previous pass (contraction estimate)
+    double hist[PLM_VP_HIST];   // squared gradient norm and open sites (x 1e-6 in the fraction... see k_vp_check) per pass: PLM_DEBUG_VP
+};
+#define PLM_VP_ALWAYS 0     // unconditional launch
+#define PLM_VP_PASS 1       // chain pass in its statistics role: runs while !done && !want_rt
+#define PLM_VP_PASS_RT 2    // chain pass in its residual-writing role: runs while !done && want_rt
+#define PLM_VP_FINAL 3      // residual pass after the chain: runs unless final_skip
+hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st);
 // Per-site gradient norms of the last pass (their sum -> g2_out[0]); update = 1: sites above their share of tol2 take a
-// Newton step on the field part of x (full = that pass carried Hessian sums: inverse recomputed and cached in hinv
-// [sites][Q][Q]; else the cached inverse).  *flag (device, required) is raised when no site is above its share and
-// makes later launches return at once; tol2 = 0 and a zeroed flag give the plain "step everywhere" behaviour.
+// Newton step on the field part of x (full = 1: that pass carried Hessian sums: inverse recomputed and cached in hinv
+// [sites][Q][Q]; 0: the cached inverse; 2: a chain position with Hessian sums -- fresh unless the pass ran in its
+// residual-writing role).  state (device PlmVpState, may be NULL): the chain's bookkeeping (k_vp_check: done, the
+// prediction for the next pass, g2_out[1] = passes, g2_out[2] = verdict): the chain ends when the squared norm over all
+// sites is within tol2, or when it is below floor2 (the noise floor of the f32 gradient sums) and no longer falls by 4x
+// per pass; tol2 = 0 and no state give the plain "step everywhere" behaviour.
 // plm_rccl.cpp: RCCL resolved at run time
 struct PlmRccl;
 int plm_rccl_id(void *id128);
@@ -186,9 +213,15 @@ int plm_rccl_collective(PlmRccl *p, int op, void *send, void *recv, const int64_
                         hipStream_t st);
 const char *plm_rccl_error();
 hipError_t plm_launch_h64_init(const PlmDims &d, const float *x, double *h64, hipStream_t st);
+// chain = 1: a position of the chain -- returns at once when the chain is done, the step goes to the OTHER field buffer
+// (committed by k_vp_check unless this pass ends the chain: the fields the pass -- and its residual planes -- saw stay
+// current), x is left alone (plm_launch_fields_to_x after the chain); chain = 0: in place.
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
-                             int *flag, hipStream_t st);
+                             double floor2, int *state, int chain, hipStream_t st);
+size_t plm_h64_stride(const PlmDims &d);       // doubles per field buffer (h64 holds two)
+// field part of x <- the chain's current fields, rounded to f32
+hipError_t plm_launch_fields_to_x(const PlmDims &d, const double *h64, const int *state, float *x, hipStream_t st);
 size_t plm_hj_bytes(const PlmDims &d);
 size_t plm_hpart_bytes(const PlmDims &d);   // Hessian sums (f32)
 size_t plm_gpart_bytes(const PlmDims &d);   // gradient sums (f64)

@@ -1385,20 +1385,31 @@ struct HpassArgs {
     const float4 *hj;
     const int8_t *msa_rm;
     const float *w;
-    const double *h;      // fields of the local sites in f64 (the solver's copy: see k_hsolve)
+    const double *h;      // fields of the local sites in f64 (the solver's copy: see k_hsolve); two buffers of hstride
+    int hstride;          // doubles, the chain state says which one is current
     char *Rt;
     double *fx_part;
     float *hpart;         // [workgroup][16 sites][NH]  Hessian sums, NH = Q (Q + 1) / 2 (STATS == 2 only)
     double *gpart;        // [workgroup][16 sites][Q]   gradient sums, f64: their f32 accumulation was the noise floor
     float rscale;         //                            of the field solver (|g_h| ~ 1e-2 at N = 50 000)
-    const int *skip;      // device flag (may be NULL): non-zero = the field solver has converged, do nothing
+    const int *state;     // chain state of the field solver (PlmVpState, may be NULL) and which role this launch has in
+    int cond;             // the chain (PLM_VP_*): a launch whose role is not wanted returns at once
     int sel;              // sequence tiles of this launch: 0 all, 1 the Hessian-sampled ones, 2 all the others
 };
+// does a launch with role `cond` run?  (wave-uniform: read through the scalar cache)
+__device__ __forceinline__ bool vp_runs(const int *state, int cond) {
+    if (!state || cond == PLM_VP_ALWAYS) return true;
+    const PlmVpState *S = (const PlmVpState *)state;
+    if (cond == PLM_VP_FINAL) return S->final_skip == 0;
+    if (S->done) return false;
+    return cond == PLM_VP_PASS_RT ? S->want_rt != 0 : S->want_rt == 0;
+}
 template <int Q, bool WRITE_RT, int STATS, bool XACT>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums; XACT: exact softmax arguments
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NH = (STATS == 2) ? Q * (Q + 1) / 2 : 0;
-    if (A.skip && *A.skip) return;
+    if (!vp_runs(A.state, A.cond)) return;
+    if (A.state) A.h += (size_t)((const PlmVpState *)A.state)->cur * A.hstride;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
     // a Hessian pass is two launches: the sampled tiles with the big LDS statistics area (one workgroup per CU), all
@@ -1652,12 +1663,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
 }
 hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w,
                             const double *h64, int write_rt, int stats, int exact, void *Rt, double *fx_part, float *hpart,
-                            double *gpart, const int *skip, hipStream_t st) {
+                            double *gpart, const int *state, int cond, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const int nb = d.b16_hi - d.b16_lo, ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
     const dim3 block(512);
-    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (char *)Rt, fx_part,
-                hpart, gpart, d.rscale, skip, 0};
+    HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (int)plm_h64_stride(d), (char *)Rt, fx_part,
+                hpart, gpart, d.rscale, state, cond, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
         const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
@@ -1700,6 +1711,12 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
 size_t plm_hpart_bytes(const PlmDims &d) {
     return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 16 * (d.Q * (d.Q + 1) / 2) * sizeof(float);
 }
+size_t plm_h64_stride(const PlmDims &d) {
+    // per-site buffers are indexed by i - h_site0 over the LOCAL FIELD PART: the shard's own sites in sharded-state
+    // mode, but all L sites in the replicated multi-shard mode (own_lo = 0, own_hi = nb16)
+    const size_t nsites = (size_t)std::max(std::max(1, (d.b16_hi - d.b16_lo) * 16), std::min(d.L, d.own_hi * 16) - d.h_site0);
+    return nsites * d.Q;
+}
 size_t plm_gpart_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 16 * d.Q * sizeof(double); }
 
 // Newton step on the fields of one site (one wave per site).  The workgroup partials of the last pass are summed
@@ -1713,11 +1730,20 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
                                               float *__restrict__ x, double *__restrict__ h64,
                                               double lambda_h, int update,
                                               double *__restrict__ hinv, double *__restrict__ g2_site,
-                                              double tol_site2, const int *__restrict__ skip) {
+                                              double tol_site2, const int *__restrict__ state, int chain, int hstride) {
     constexpr int NVF = PLM_HSTATS(Q);
-    if (skip && *skip) return;
+    const PlmVpState *S = (const PlmVpState *)state;
+    int cur = 0;
+    if (S) {
+        if (chain && S->done) return;
+        // chain position with Hessian sums: they exist only if the pass ran in its statistics role (a pass that the
+        // chain predicted to be the last wrote residual planes instead and steps with the cached inverses)
+        if (full == 2) full = S->want_rt ? 0 : 1;
+        cur = S->cur;
+    } else if (full == 2) full = 1;
     __shared__ double st[NVF];
     __shared__ double Hm[Q][2 * Q + 1];             // [H | I] -> [I | H^-1] (odd row stride: no bank conflicts)
+    __shared__ double Hi[Q][Q + 1];                 // the inverse the step is taken with
     __shared__ double gr[Q];
     const int il = blockIdx.x, t = threadIdx.x;     // local site index
     const int i = d.h_site0 + il;
@@ -1725,6 +1751,8 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
         if (t == 0) g2_site[il] = 0.0;
         return;
     }
+    const double *hc = h64 + (size_t)cur * hstride + (size_t)il * Q;                       // the fields the pass saw
+    double *hn = h64 + (size_t)((S && chain) ? (cur ^ 1) : cur) * hstride + (size_t)il * Q; // where the step goes
     const int b16l = il >> 4, r = il & 15;
     constexpr int NH = Q * (Q + 1) / 2;
     {
@@ -1756,7 +1784,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     }
     __syncthreads();
     const int a0 = d.gap_mode;                      // gap mode: state 0 is not a model state
-    if (t < Q) gr[t] = (t < a0) ? 0.0 : st[t] + 2.0 * lambda_h * h64[(size_t)il * Q + t];
+    if (t < Q) gr[t] = (t < a0) ? 0.0 : st[t] + 2.0 * lambda_h * hc[t];
     __syncthreads();
     double *inv = hinv + (size_t)il * Q * Q;
     if (full) {
@@ -1790,20 +1818,32 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
             }
             __syncthreads();
         }
-        for (int k = t; k < Q * Q; k += 64) inv[k] = Hm[k / Q][Q + k % Q];
-        __syncthreads();
     }
     double g2 = 0;
-    for (int a = 0; a < Q; a++) g2 += gr[a] * gr[a];       // every lane: the branch below must be uniform
+    for (int a = 0; a < Q; a++) g2 += gr[a] * gr[a];       // every lane: the branches below must be uniform
     if (t == 0) g2_site[il] = g2;
-    // the sites are independent problems: one that meets its share of the tolerance is left alone (its residuals of
-    // the pass just taken are final), the others take a Newton step
-    if (!update || !(g2 > tol_site2)) return;
+    const bool move = update && g2 > tol_site2;
+    if (!move && !full) {
+        // nothing to do for this site; inside a chain its fields still have to exist in the other buffer
+        if (S && chain && update && t < Q) hn[t] = hc[t];
+        return;
+    }
+    // the inverse the step is taken with: fresh (sampled Hessian sums of this pass) or cached
+    for (int k = t; k < Q * Q; k += 64) Hi[k / Q][k % Q] = full ? Hm[k / Q][Q + k % Q] : inv[k];
+    __syncthreads();
+    // (A per-site BFGS update of the inverse with the secant pair of the chain's previous step was built and measured
+    // in round 5: near the f32 noise floor of the gradient sums y = g - g_prev is mostly noise, the inverses got
+    // corrupted and the norm jumped between 3e-2 and 1e+1 from pass to pass -- gpurun_out/r5c4.  Removed.)
+    const bool dirty = full != 0;
+    if (dirty) for (int k = t; k < Q * Q; k += 64) inv[k] = Hi[k / Q][k % Q];
+    if (!move) {
+        if (S && chain && update && t < Q) hn[t] = hc[t];
+        return;
+    }
     // dh = H^-1 grad, one lane per state; cap far-away steps (a full Newton step can overshoot)
     double dh = 0;
     if (t < Q) {
-        if (full) { for (int b = 0; b < Q; b++) dh += Hm[t][Q + b] * gr[b]; }
-        else { for (int b = 0; b < Q; b++) dh += inv[t * Q + b] * gr[b]; }
+        for (int b = 0; b < Q; b++) dh += Hi[t][b] * gr[b];
         if (t < a0) dh = 0;
     }
     // far from the optimum a full Newton step overshoots (saturated softmax: tiny Hessian entries): the step is
@@ -1813,12 +1853,25 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     double mxs = fabs(dh);
     for (int o = 32; o > 0; o >>= 1) mxs = fmax(mxs, __shfl_xor(mxs, o, 64));
     const double cap = (mxs > PLM_NEWTON_CAP) ? PLM_NEWTON_CAP / mxs : 1.0;
-    if (t < Q && !(mxs != mxs)) {
+    if (t < Q) {
+        const bool bad = mxs != mxs;
         // the solver iterates on an f64 copy of the fields; the parameter vector gets the rounded value
-        const double hn = h64[(size_t)il * Q + t] - cap * dh;
-        h64[(size_t)il * Q + t] = hn;
-        x[(size_t)il * Q + t] = (float)hn;
+        const double hnew = bad ? hc[t] : hc[t] - cap * dh;
+        hn[t] = hnew;
+        if (!(S && chain)) x[(size_t)il * Q + t] = (float)hnew;
     }
+}
+__global__ __launch_bounds__(256) void k_fields_to_x(const double *__restrict__ h64, const int *__restrict__ state, int hstride,
+                                                    float *__restrict__ x, int n) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int cur = state ? ((const PlmVpState *)state)->cur : 0;
+    if (k < n) x[k] = (float)h64[(size_t)cur * hstride + k];
+}
+hipError_t plm_launch_fields_to_x(const PlmDims &d, const double *h64, const int *state, float *x, hipStream_t st) {
+    const int n = (std::min(d.L, d.own_hi * 16) - d.h_site0) * d.Q;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fields_to_x, dim3((n + 255) / 256), dim3(256), 0, st, h64, state, (int)plm_h64_stride(d), x, n);
+    return hipGetLastError();
 }
 // start of an evaluation: the solver's f64 fields <- the trial point's f32 fields
 __global__ __launch_bounds__(256) void k_h64_init(const float *__restrict__ x, double *__restrict__ h64, int n) {
@@ -1831,15 +1884,19 @@ hipError_t plm_launch_h64_init(const PlmDims &d, const float *x, double *h64, hi
     hipLaunchKernelGGL(k_h64_init, dim3((n + 255) / 256), dim3(256), 0, st, x, h64, n);
     return hipGetLastError();
 }
-// g2 = sum of the per-site squared gradient norms of the pass just taken; the device-side convergence flag of the
-// field solver is raised when EVERY site is within its share of the tolerance (then no site was moved by the
-// k_hsolve in front of this kernel and the residuals of that pass are final), or when g2 is not a number (the line
-// search deals with that); it stays raised
+// Bookkeeping of the field solver's chain after a pass + step (k_hpass, k_hsolve): g2 = sum of the per-site squared
+// gradient norms of the pass just taken.  The chain is DONE when every site is within its share of the tolerance (then
+// no site was moved by the k_hsolve in front of this kernel and the statistics -- and residual planes, if the pass wrote
+// them -- of that pass are final), or when g2 is not a number (the line search deals with that); later launches of the
+// chain return at once.  Otherwise it predicts from the contraction seen so far whether the NEXT pass will be the last
+// one, i.e. should write the residual planes (1.0 GB of stores that only the last pass has to make): the host's rule of
+// rounds 2-4 (`gh2 * rate <= tol2`) evaluated where the numbers are, one pass earlier than a host round trip could.
 __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_site, int n, double *g2_out,
-                                                 double tol_site2, int *flag) {
+                                                 double tol_site2, double tol2, double floor2, int *state) {
     __shared__ double red[4];
     __shared__ int bad[4];
-    if (*flag) return;
+    PlmVpState *S = (PlmVpState *)state;
+    if (S && S->done) return;
     double s = 0;
     int open_sites = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -1852,34 +1909,67 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
     const double t = block_reduce_sum(s, red);     // contains the barrier that publishes bad[]
     if (threadIdx.x == 0) {
         g2_out[0] = t;
-        g2_out[1] += 1.0;                 // passes this chain needed (the host resets it)
-        const bool done = bad[0] + bad[1] + bad[2] + bad[3] == 0 || t != t;
-        if (done) *flag = 1;
+        if (!S) return;
+        // done: the solver's tolerance is on the NORM over all sites (what the stop rule of the fit adds to |g|^2); the
+        // per-site shares only decide which sites still move.  (Waiting for every site to meet its share makes the whole
+        // chain wait for the slowest one: measured, 9-14 passes per evaluation with the total long inside the tolerance.)
+        const int open_total = bad[0] + bad[1] + bad[2] + bad[3];
+        // ... or the solver has arrived at the noise floor of its f32 gradient sums (floor2: the host's estimate of it)
+        // and a pass no longer gains a factor 2 in norm: below the floor an evaluation would only burn passes
+        const bool at_floor = S->passes >= 1 && t <= floor2 && t > 0.25 * S->g2_prev;
+        const bool done = open_total == 0 || !(t > tol2) || at_floor || t != t;
+        if (S->passes < PLM_VP_HIST) S->hist[S->passes] = t + 1e-30 * 0 + (double)open_total * 1e9;   // debug trace: norm^2 (+ open sites * 1e9)
+        S->passes += 1;
+        g2_out[1] = (double)S->passes;    // passes this chain needed (the host resets the state per evaluation)
         g2_out[2] = done ? 1.0 : 0.0;     // the host reads the verdict with the scalars (sharded: summed over ranks)
+        if (done) {
+            S->done = 1;                            // the step k_hsolve just wrote to the other buffer is dropped
+            if (S->want_rt) S->final_skip = 1;      // this pass wrote the residual planes: no separate last pass
+        } else {
+            S->cur ^= 1;                            // the chain goes on: the step becomes the current fields
+            // contraction of the squared norm per pass: measured once two passes exist, before that the typical
+            // simplified-Newton rate with sampled Hessians (~0.03 per step in norm)
+            const double rate = (S->passes >= 2 && S->g2_prev > 0) ? fmin(1.0, t / S->g2_prev) : 1e-3;
+            S->want_rt = (t * fmax(1e-6, rate) <= tol2) ? 1 : 0;
+        }
+        S->g2_prev = t;
     }
+}
+__global__ void k_vp_reset(int *state, int want_rt) {
+    PlmVpState *S = (PlmVpState *)state;
+    S->done = 0; S->want_rt = want_rt; S->final_skip = 0; S->passes = 0; S->cur = 0; S->g2_prev = 0.0;
+    for (int k = 0; k < PLM_VP_HIST; k++) S->hist[k] = 0.0;
+}
+hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st) {
+    hipLaunchKernelGGL(k_vp_reset, dim3(1), dim3(1), 0, st, state, want_rt);
+    return hipGetLastError();
 }
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
-                             int *flag, hipStream_t st) {
+                             double floor2, int *state, int chain, hipStream_t st) {
     const int nsites = (d.b16_hi - d.b16_lo) * 16;
-    if (nsites <= 0) {
+    int *cstate = chain ? state : nullptr;      // the chain's bookkeeping runs for chain positions only
+    if (nsites <= 0) {      // a shard without sites: its chain is done at once
         hipError_t e = hipMemsetAsync(g2_out, 0, sizeof(double), st);
-        if (e == hipSuccess && flag) e = hipMemsetD32Async((hipDeviceptr_t)flag, 1, 1, st);
+        if (e == hipSuccess && cstate) {
+            hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, 0, g2_out, 0.0, tol2, floor2, cstate);
+            e = hipGetLastError();
+        }
         return e;
     }
-    // per-site share of the tolerance: twice the equal share in norm -- the largest of a few hundred site gradients
-    // sits ~3x above their rms at the f32 floor, and an equal share would chase that noise (measured: most chains
-    // then run to their last pass); the total stays within 2x of the requested norm, typically at half of it
-    const int live = std::max(1, std::min(d.L, d.own_hi * 16) - d.h_site0);
-    const double tol_site2 = 4.0 * tol2 / live;
+    // Every site steps at every position (tol_site2 = 0).  Rounds 2-4 left a site alone once it was within its share of
+    // the tolerance; with the chain's end decided on the norm over all sites that put a floor of about the tolerance itself
+    // under the norm (the frozen sites' shares) -- the step is tentative instead (k_vp_check commits it).
+    const double tol_site2 = 0.0;
+    const int hs = (int)plm_h64_stride(d);
     switch (d.Q) {
-    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
-    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, flag); break;
+    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
+    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
+    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
+    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out, tol_site2, flag);
+    hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out, tol_site2, tol2, floor2, cstate);
     return hipGetLastError();
 }
 

@@ -178,10 +178,52 @@ def share_rccl_id(group=None):
 
 
 def native_rccl_requested():
-    """PLM_NATIVE_RCCL=1: collectives issued by the library (RCCL on its stream) instead of torch.distributed calls
-    from a host callback.  Opt-in until it has run on a multi-GPU node (single-GPU boxes can only form a one-rank
-    communicator: plm.rccl_selftest)."""
-    return os.environ.get("PLM_NATIVE_RCCL", "0") not in ("", "0")
+    """Collectives issued by the library itself (RCCL on its own stream: no host round trip around any of them) are the
+    default transport of a multi-GPU job since round 5; PLM_NATIVE_RCCL=0 keeps the torch.distributed callbacks.  The
+    default is only taken after `negotiate_native_rccl` has seen it work on every rank."""
+    return os.environ.get("PLM_NATIVE_RCCL", "1") not in ("", "0")
+
+
+def negotiate_native_rccl(group=None, device=None):
+    """Can this job run the library-issued RCCL transport?  Collective over the (nccl-backed) group: every rank checks
+    that it can load RCCL, then all ranks form a probe communicator from an id rank 0 made, push an all-to-all and an
+    all-reduce through it and destroy it (plm_rccl_probe); the verdicts are combined with a torch all-reduce, so every
+    rank returns the same answer.  False = use the torch.distributed callbacks (and say why on rank 0)."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    from evcouplings_amd import plm
+    if not native_rccl_requested() or dist.get_backend(group) != "nccl":
+        return False
+    device = torch.cuda.current_device() if device is None else device
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], device="cuda:%d" % device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(flag.item()))
+
+    why = ""
+    try:
+        ok = plm.rccl_version() >= 20000
+        if not ok:
+            why = "librccl not loadable by libplm_hip"
+    except Exception as exc:       # noqa: BLE001 -- any failure means "not here"
+        ok, why = False, repr(exc)
+    if not agree(ok):
+        if dist.get_rank(group) == 0:
+            print("plm: library-issued RCCL transport unavailable (%s): torch.distributed callbacks" % (why or "another rank"),
+                  file=sys.stderr)
+        return False
+    ident = share_rccl_id(group)
+    try:
+        plm.rccl_probe(ident, dist.get_world_size(group), dist.get_rank(group), device=device)
+        ok = True
+    except Exception as exc:       # noqa: BLE001
+        ok, why = False, repr(exc)
+    ok = agree(ok)
+    if not ok and dist.get_rank(group) == 0:
+        print("plm: RCCL probe communicator failed (%s): torch.distributed callbacks" % (why or "another rank"), file=sys.stderr)
+    return ok
 
 
 def fit_distributed(msa, q=21, group=None, sharded_state=True, transport=None, **kwargs):
@@ -192,18 +234,21 @@ def fit_distributed(msa, q=21, group=None, sharded_state=True, transport=None, *
     one all-gather of the gradient slabs per evaluation.
     transport "rccl": torch.distributed collectives on the library's device buffers (backend nccl); "native": the
     library issues the RCCL calls itself on its stream (torch.distributed only carries the communicator id); "host":
-    staged through host memory (backend gloo; sharded-state mode only).  Default: "rccl", or "native" with
-    PLM_NATIVE_RCCL=1.
+    staged through host memory (backend gloo; sharded-state mode only).  Default on an nccl group: "native" when every
+    rank's probe communicator worked (`negotiate_native_rccl`; PLM_NATIVE_RCCL=0 opts out), else "rccl"; "host" on gloo.
     """
     import torch
     import torch.distributed as dist
     from evcouplings_amd import plm
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     device = kwargs.pop("device", torch.cuda.current_device())
-    if transport is None:
-        transport = "native" if native_rccl_requested() else "rccl"
     if world == 1:
         return plm.fit(msa, q=q, device=device, **kwargs)
+    if transport is None:
+        if dist.get_backend(group) != "nccl":
+            transport = "host"
+        else:
+            transport = "native" if (sharded_state and negotiate_native_rccl(group, device)) else "rccl"
     if sharded_state and transport == "native":
         return plm.fit(msa, q=q, n_shards=world, shard=rank, device=device, rccl_id=share_rccl_id(group), **kwargs)
     if sharded_state:

@@ -389,6 +389,13 @@ def rccl_version():
     return int(_lib.load().plm_rccl_runtime_version())
 
 
+def rccl_probe(rccl_id, nranks, rank, device=0, stream=0):
+    """plm_rccl_probe: every rank forms the communicator, exchanges an all-to-all and an all-reduce, destroys it; raises
+    on this rank if anything failed"""
+    idbuf = C.create_string_buffer(bytes(rccl_id), RCCL_ID_BYTES)
+    check(_lib.load().plm_rccl_probe(idbuf, int(nranks), int(rank), int(device), C.c_void_p(int(stream) or None)))
+
+
 def rccl_selftest(device=0, stream=0):
     """every collective of the sharded-state mode on a one-rank communicator; raises on any failure"""
     check(_lib.load().plm_rccl_selftest(int(device), C.c_void_p(int(stream) or None)))
@@ -519,8 +526,16 @@ class PlmContext:
         check(self.lib.plm_ctx_scores(self._h, _ptr(fn), _ptr(cn)))
         return fn, cn
 
+    def solver_stats(self):
+        """field-solver statistics of the last optimize() on this context (plm_ctx_solver_stats)"""
+        out = np.zeros(_lib.S_COUNT, np.float64)
+        check(self.lib.plm_ctx_solver_stats(self._h, _ptr(out)))
+        ev = max(1.0, out[0])
+        return {"evaluations": int(out[0]), "field_ms_per_evaluation": out[1] / ev, "passes_per_evaluation": out[2] / ev,
+                "chains_continued_by_host": int(out[3])}
+
     def time_kernels(self, reps=5):
         ms = np.zeros(_lib.K_COUNT, np.float32)
         check(self.lib.plm_ctx_time_kernels(self._h, int(reps), _ptr(ms)))
-        names = ["expand", "forward", "backward", "assemble", "total", "reweight", "fields", "forward_accurate"]
+        names = ["expand", "forward", "backward", "assemble", "total", "reweight", "fields", "forward_accurate", "lbfgs_vector"]
         return dict(zip(names, ms.tolist()))

@@ -197,6 +197,10 @@ int plm_fit_sharded(const plm_problem_t *problem, plm_result_t *result, int devi
 int plm_rccl_unique_id(void *id_out);
 int plm_rccl_runtime_version(void);          /* NCCL version code of the resolved library, 0 if none */
 int plm_rccl_selftest(int device, void *stream);
+/* Every rank of a prospective communicator: form it from `rccl_id`, exchange one all-to-all and one all-reduce, check
+ * the data, destroy it.  PLM_OK on this rank = the library-issued transport works here (dist.py negotiates the ranks'
+ * verdicts and falls back to the callback transport if any of them failed). */
+int plm_rccl_probe(const void *rccl_id, int32_t nranks, int32_t rank, int device, void *stream);
 int plm_fit_sharded_rccl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
                          plm_iter_cb iter_cb, void *iter_user, const void *rccl_id);
 
@@ -302,8 +306,18 @@ int plm_ctx_scores(plm_ctx_t *ctx, float *fn_host, float *cn_host);
 #define PLM_K_REWEIGHT 5
 #define PLM_K_FIELDS 6      /* variable-projection fit: Newton passes on the fields + residual pass (0 otherwise) */
 #define PLM_K_FORWARD_ACCURATE 7   /* the forward GEMM's accurate instantiation (f64 outer sums): last iterations, plm_eval */
-#define PLM_K_COUNT 8
+#define PLM_K_LBFGS_VECTOR 8       /* the L-BFGS vector kernels of one iteration (m = 6) on this context's share of the state */
+#define PLM_K_COUNT 9
 int plm_ctx_time_kernels(plm_ctx_t *ctx, int32_t reps, float *out_ms /* [PLM_K_COUNT] */);
+/* Field-solver statistics of the last plm_ctx_optimize on this context (variable-projection fits; zeros otherwise),
+ * measured with HIP events on the context's stream around the solver of every evaluation: bench.py reports the average
+ * field-solver time per evaluation of its timed window from these. */
+#define PLM_S_EVALS 0          /* evaluations whose field solver was timed */
+#define PLM_S_FIELD_MS 1       /* total milliseconds between the forward GEMM and the backward GEMM of those evaluations */
+#define PLM_S_PASSES 2         /* passes over the stored potentials made by the solver's chains (the last, residual-only pass not counted) */
+#define PLM_S_CHAIN_SHORT 3    /* evaluations whose chain ran out of positions and had to be continued by the host */
+#define PLM_S_COUNT 4
+int plm_ctx_solver_stats(plm_ctx_t *ctx, double *out /* [PLM_S_COUNT] */);
 
 /* -- host arithmetic exposed for tests (no device) ------------------------------------------ */
 /* Two-loop recursion of L-BFGS in coefficient space over a ring of m history slots, of which the `stored` slots

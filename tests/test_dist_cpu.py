@@ -171,9 +171,39 @@ def test_rccl_id_travels_from_rank_zero_gloo():
 
 
 def test_native_rccl_switch(monkeypatch):
+    """the library-issued transport is the default of a multi-GPU job (round 5); PLM_NATIVE_RCCL=0 opts out"""
     monkeypatch.delenv("PLM_NATIVE_RCCL", raising=False)
-    assert not pdist.native_rccl_requested()
+    assert pdist.native_rccl_requested()
     monkeypatch.setenv("PLM_NATIVE_RCCL", "0")
     assert not pdist.native_rccl_requested()
     monkeypatch.setenv("PLM_NATIVE_RCCL", "1")
     assert pdist.native_rccl_requested()
+
+
+def _negotiate_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, pdist.negotiate_native_rccl()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_negotiation_keeps_the_callback_transport_on_a_gloo_group():
+    """negotiate_native_rccl is collective and must give every rank the same answer; a group whose backend is not nccl
+    (the CPU / single-GPU flow tests) never takes the library-issued transport and never touches a GPU for the question"""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_negotiate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert got == {0: False, 1: False}

@@ -423,7 +423,7 @@ def test_field_objective_scaling_matches_reference_independent_model(plm, golden
 
 
 # ---------------------------------------------------------------- sharded-state multi-GPU mode on one GPU
-@pytest.mark.parametrize("L,n_shards", [(40, 2), (40, 3), (40, 4), (100, 2), (100, 3), (100, 4), (300, 8), (500, 8)])
+@pytest.mark.parametrize("L,n_shards", [(40, 2), (40, 3), (40, 4), (100, 2), (100, 3), (100, 4), (300, 8), (500, 8), (600, 8)])
 def test_sharded_state_evaluation_matches_single_gpu(plm, oracle64, L, n_shards):
     """every shard in its own thread on the same GPU, collectives through host memory (dist.ThreadedShards):
     objective and gradient must equal the single-GPU evaluation (L=40 with 4 shards leaves one shard empty)"""
@@ -472,9 +472,10 @@ def test_sharded_state_fit_matches_single_gpu(plm, n_shards):
     np.testing.assert_allclose(outs[0]["cn"], ref["cn"], atol=1e-5)
 
 
-@pytest.mark.parametrize("L", [300, 500])
+@pytest.mark.parametrize("L", [300, 500, 600])
 def test_eight_shard_fit_matches_single_gpu(plm, L):
-    """the 8-rank layout of one MI355X node (BASELINE configs 4/5 ask for it) at the headline widths, every shard in
+    """the 8-rank layout of one MI355X node (BASELINE configs 4/5 ask for it) at the headline widths -- L = 600 is config
+    5's two-chain shape (350 + 250 sites: 38 site blocks, 5,5,5,5,5,5,4,4) --, every shard in
     its own thread on this GPU: same fit as the unsharded context (variable projection on both sides)"""
     from evcouplings_amd.dist import ThreadedShards, shard_blocks
     parts = shard_blocks(L, 8)
@@ -490,6 +491,28 @@ def test_eight_shard_fit_matches_single_gpu(plm, L):
         np.testing.assert_allclose(o["cn"], ref["cn"], atol=3e-4)
 
 
+def test_one_shard_of_eight_can_be_timed_alone_and_the_solver_reports_its_passes(plm):
+    """scripts/shard_compute.py (profiles/r05_shard_compute.json): plm_ctx_time_kernels on a sharded-state context times
+    that shard's kernels over its own site blocks; plm_ctx_solver_stats reports the field solver's chain of the last fit"""
+    msa, _ = synthetic_msa(1500, 300, seed=8)
+    with plm.PlmContext(msa, q=Q, max_iter=12, epsilon=1e-3) as ctx:
+        w, _, _ = ctx.reweight()
+        ctx.marginals(pairs=False)
+        ctx.set_x(None)
+        r = ctx.optimize()
+        st = ctx.solver_stats()
+        x0 = ctx.get_x()
+        full = ctx.time_kernels(reps=2)
+    assert st["evaluations"] == r["n_evals"] and 1.0 <= st["passes_per_evaluation"] <= 14.0
+    assert st["field_ms_per_evaluation"] > 0 and st["chains_continued_by_host"] <= r["n_evals"]
+    with plm.PlmContext(msa, q=Q, n_shards=8, shard=7, sharded_state=True, max_iter=12, epsilon=1e-3) as c:
+        c.set_weights(w)
+        c.set_x(x0)
+        part = c.time_kernels(reps=2)
+    for k in ("forward", "backward", "fields", "lbfgs_vector"):
+        assert 0 < part[k] < full[k], (k, part[k], full[k])        # 2 of 19 site blocks, 3 of 190 block pairs
+
+
 def test_native_rccl_collectives_on_one_rank(plm):
     """plm_rccl_*: librccl resolved at run time, a communicator formed from an id, every collective of the
     sharded-state mode issued on the library's stream.  One GPU can only form a one-rank communicator: this pins the
@@ -498,6 +521,7 @@ def test_native_rccl_collectives_on_one_rank(plm):
     ident = plm.rccl_unique_id()
     assert len(ident) == plm.RCCL_ID_BYTES and ident != plm.rccl_unique_id()
     plm.rccl_selftest()
+    plm.rccl_probe(plm.rccl_unique_id(), 1, 0)      # what dist.negotiate_native_rccl runs on every rank before a job commits
     msa, _ = synthetic_msa(300, 40, seed=5)
     ref = plm.fit(msa, Q, max_iter=8, epsilon=1e-12, want_fij=False)
     got = plm.fit(msa, Q, max_iter=8, epsilon=1e-12, want_fij=False, rccl_id=ident)      # n_shards = 1: no exchange

@@ -11,8 +11,12 @@ The oracle (oracle/plm_oracle.c, float64, OpenMP) is the checker: one objective+
     less accurate than the reference's own arithmetic class;
   * optimality certificates: the ORACLE's gradient at the GPU's stop point satisfies the stop rule (status 0 is
     required everywhere: no "converged to precision" escape), a tighter fit moves no CN score by 1e-4;
-  * config 2 and headline: scipy's L-BFGS-B on the oracle's float64 objective, started from the shipped point and given
-    25 evaluations, moves no CN score by 1e-4 ('EC scores vs CPU plmc within 1e-4' with the only CPU solver available);
+  * the PLAIN evaluation (k_fwd_w + three-plane k_bwd_w: what bench.py times and a fit runs until its last iterations)
+    against the same oracle values at config 2 / headline / config 3 / -g headline: inside the float32 CPU build's error
+    and inside an absolute bound per configuration;
+  * config 2, headline and config 5 (two chains, L = 600): scipy's L-BFGS-B on the oracle's float64 objective, started
+    from the shipped point and given 25 / 15 / 6 evaluations, moves no CN score by 1e-4 ('EC scores vs CPU plmc
+    within 1e-4' with the only CPU solver available);
   * config 3 (N = 100 000) converges from two different starts;
   * at the reference's default `iterations: 100` (sample_config_monomer.txt:149), where no solver is converged, the
     default solver's CN ranking is at least as close to the converged one as the plmc-like joint L-BFGS's;
@@ -43,7 +47,14 @@ TIGHT_OF = {"config3": 7e-4}
 # plm_eval run the accurate evaluation (exact integer forward GEMM, exact softmax arguments, 32-bit residuals;
 # DESIGN.md 4.3 / section 5), measured 2.3e-5 at the headline and 4.7e-5 at N = 100 000.
 # (Rounds 2-3, f32 accumulation throughout: 3e-11 N L -- 4.5e-4 at the headline, 1e-3 at N = 100 000, the size of the stop rule.)
-GRAD_ERR = 1.5e-4
+GRAD_ERR = 8e-5
+# The PLAIN evaluation -- k_fwd_w (f16 hi + lo operand planes, f32 accumulation) + __expf softmax + three residual digit
+# planes on k_bwd_w: what a fit runs until its last iterations and what bench.py times -- against the f64 oracle at the
+# same stop points.  Its error is coherent across sequences and grows as ~3e-11 N L |x|; the bounds
+# are the values measured in round 5 (gpurun_out/r5c1: 1.1e-4 / 3.6e-4 / 7.4e-4 / 2.5e-4 -- profiles/r04_error_anatomy.txt had
+# 4.5e-4 / 8.7e-4 / 3.4e-4 for the last three) + 30 %.  The second bound every
+# point has to meet is relative: not worse than the float32 CPU build (oracle32) at the same point.
+PLAIN_ERR = {"config2": 1.5e-4, "headline": 4.7e-4, "config3": 9.6e-4, "headline_g": 3.3e-4}
 # the oracle's |g|/|x| at a point the fit reported converged at epsilon: the stop rule, up to the evaluation error
 COND_SLACK = 1.05
 
@@ -113,6 +124,28 @@ def _oracle_eval(oracle, f, x):
     return fn(f["msa"], f["w"].astype(oracle.real), Q, 0.01, f["lambda_j"], x.astype(oracle.real))
 
 
+def _oracle_cached(oracle, f, point):
+    """oracle evaluation at f["x_far"] / the shipped point, computed once per configuration and precision"""
+    key = "oracle_%s_%s" % (point, np.dtype(oracle.real).name)
+    if key not in f:
+        f[key] = _oracle_eval(oracle, f, f["x_far"] if point == "far" else f["fit_1e-3"]["x"])
+    return f[key]
+
+
+def _hip_eval_plain(plm, f, x, monkeypatch):
+    """one evaluation with the PLAIN arithmetic of the fit's first iterations / of bench.py's timed window (PLM_FWD_ACCURATE
+    is read once, when the context is created): k_fwd_w + plain k_hpass + the three-plane k_bwd_w at 21 states"""
+    monkeypatch.setenv("PLM_FWD_ACCURATE", "0")
+    try:
+        with _context(plm, f, lambda_j=f["lambda_j"], epsilon=1e-3) as ctx:
+            ctx.set_weights(f["w"])
+            ctx.set_x(x)
+            fx, nll = ctx.eval()
+            return fx, nll, ctx.get_g()
+    finally:
+        monkeypatch.delenv("PLM_FWD_ACCURATE")
+
+
 def _hip_eval(plm, f, x):
     """one evaluation through the resident-context API (plm_eval has no -g flag); always the accurate forward GEMM"""
     if not f["gaps"]:
@@ -130,7 +163,7 @@ def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, oracle32, fits, n
     assert f["fit_1e-3"]["status"] == 0, f["fit_1e-3"]["status_msg"]          # converged by its own rule, everywhere
     # far from the optimum: relative criteria (gradient entries are large)
     fx, nll, g = _hip_eval(plm, f, f["x_far"])
-    fxo, nllo, go = _oracle_eval(oracle64, f, f["x_far"])
+    fxo, nllo, go = _oracle_cached(oracle64, f, "far")
     gmax_far = np.abs(go).max()
     assert abs(fx - fxo) <= 2e-6 * abs(fxo) and abs(nll - nllo) <= 2e-6 * abs(nllo)
     assert np.abs(g - go).max() <= 2e-5 * gmax_far
@@ -138,12 +171,12 @@ def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, oracle32, fits, n
     x = f["fit_1e-3"]["x"]
     xn = max(1.0, np.linalg.norm(x))
     fx, nll, g = _hip_eval(plm, f, x)
-    fxo, nllo, go = _oracle_eval(oracle64, f, x)
+    fxo, nllo, go = _oracle_cached(oracle64, f, "stop")
     assert abs(fx - fxo) <= 2e-6 * abs(fxo)
     err = np.linalg.norm(g - go) / xn
     cond64 = np.linalg.norm(go) / xn
     # the same point through the float32 CPU build: the arithmetic class of a plmc openmp32 binary
-    _, _, g32 = _oracle_eval(oracle32, f, x)
+    _, _, g32 = _oracle_cached(oracle32, f, "stop")
     err32 = np.linalg.norm(g32.astype(np.float64) - go) / xn
     print("%s: at the stop point |g_hip - g_f64|/|x| = %.3g, |g_f32cpu - g_f64|/|x| = %.3g, oracle cond %.4g "
           "(fit reported %.4g), %d iterations / %d evaluations" % (
@@ -157,6 +190,32 @@ def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, oracle32, fits, n
 
 
 @pytest.mark.parametrize("name", ["config2", "headline", "config3", "headline_g"])
+def test_plain_evaluation_matches_f64_oracle_at_scale(plm, oracle64, oracle32, fits, monkeypatch, name):
+    """the kernels bench.py times (and every fit runs until its last ~8 evaluations) are the PLAIN
+    ones; test_evaluation_matches_f64_oracle_at_scale goes through the accurate evaluation.  Here the plain path is held
+    against the f64 oracle at BASELINE scale, far from the optimum and at the shipped stop point: (a) not further from
+    f64 than the float32 CPU build (the arithmetic class of a plmc openmp32 binary) at the same point, (b) inside the
+    absolute bound of this configuration."""
+    f = fits(name)
+    for point in ("far", "stop"):
+        x = f["x_far"] if point == "far" else f["fit_1e-3"]["x"]
+        xn = max(1.0, np.linalg.norm(x))
+        fx, nll, g = _hip_eval_plain(plm, f, x, monkeypatch)
+        fxo, nllo, go = _oracle_cached(oracle64, f, point)
+        _, _, g32 = _oracle_cached(oracle32, f, point)
+        err = np.linalg.norm(g - go) / xn
+        err32 = np.linalg.norm(g32.astype(np.float64) - go) / xn
+        print("%s (%s point): PLAIN evaluation |g_hip - g_f64|/|x| = %.3g (bound %.3g), |g_f32cpu - g_f64|/|x| = %.3g, "
+              "max |dg| / max |g64| = %.3g" % (name, point, err, PLAIN_ERR[name], err32,
+                                                np.abs(g - go).max() / np.abs(go).max()))
+        assert abs(fx - fxo) <= 2e-6 * abs(fxo) and abs(nll - nllo) <= 2e-6 * abs(nllo)
+        assert err <= err32, (point, err, err32)            # (a) inside the reference's own arithmetic class
+        assert err <= PLAIN_ERR[name], (point, err)         # (b)
+        if point == "far":
+            assert np.abs(g - go).max() <= 1e-4 * np.abs(go).max()
+
+
+@pytest.mark.parametrize("name", ["config2", "headline", "config3", "headline_g"])
 def test_fit_optimality_certificate(plm, oracle64, fits, name):
     f = fits(name)
     a, b = f["fit_1e-3"], f["fit_tight"]
@@ -166,7 +225,7 @@ def test_fit_optimality_certificate(plm, oracle64, fits, name):
     # (computed by the evaluation test above when it ran on this configuration first)
     cond64 = f.get("cond64_1e-3")
     if cond64 is None:
-        _, _, go = _oracle_eval(oracle64, f, a["x"])
+        _, _, go = _oracle_cached(oracle64, f, "stop")
         cond64 = np.linalg.norm(go) / max(1.0, np.linalg.norm(a["x"]))
     assert cond64 < COND_SLACK * 1e-3, cond64
     # 1.4 - 2.5 times tighter moves no EC score by more than 1e-4 (BASELINE.json's tolerance on EC scores)
@@ -182,9 +241,10 @@ def test_fit_optimality_certificate(plm, oracle64, fits, name):
     assert cond64_tight < COND_SLACK * tight, cond64_tight
 
 
-@pytest.mark.parametrize("name", ["config2", "headline"])
-def test_cn_within_1e4_of_an_independent_f64_optimiser(plm, oracle64, fits, name):
-    """BASELINE.json config 2: 'EC scores vs CPU plmc within 1e-4' (and the same one size up, at the headline).  plmc is
+@pytest.mark.parametrize("name,maxfun", [("config2", 25), ("headline", 15), ("config5", 6)])
+def test_cn_within_1e4_of_an_independent_f64_optimiser(plm, oracle64, fits, name, maxfun):
+    """BASELINE.json config 2: 'EC scores vs CPU plmc within 1e-4' (and the same at the headline and at config 5's two-chain
+    shape, where an oracle evaluation costs ~20 s of host cores: 6 of them; 15 at the headline).  plmc is
     unobtainable; the CPU side here is scipy's L-BFGS-B minimising the ORACLE's float64 objective,
     started from the answer the drop-in SHIPS (stop rule epsilon = 1e-3, not the tighter fit) and given 25 evaluations:
     whatever it still gains must not move a CN score by 1e-4."""
@@ -199,14 +259,15 @@ def test_cn_within_1e4_of_an_independent_f64_optimiser(plm, oracle64, fits, name
         return fx, g
 
     f0 = fun(x0)[0]
-    res = so.minimize(fun, x0, jac=True, method="L-BFGS-B", options=dict(maxfun=25, maxcor=10, ftol=0, gtol=0))
+    res = so.minimize(fun, x0, jac=True, method="L-BFGS-B", options=dict(maxfun=maxfun, maxcor=10, ftol=0, gtol=0))
     assert res.fun <= f0 * (1 + 1e-12)
     L = f["L"]
     _, cn_cpu = oracle64.scores(res.x[L * Q:], L, Q)
     print("%s: scipy f64 from the shipped point: f %.6f -> %.6f, max |dCN| %.3g" % (
         name, f0, res.fun, np.abs(cn_cpu - shipped["cn"]).max()))
     assert np.abs(cn_cpu - shipped["cn"]).max() < 1e-4
-    assert np.abs(cn_cpu - f["fit_tight"]["cn"]).max() < 1e-4
+    if "fit_tight" in f:
+        assert np.abs(cn_cpu - f["fit_tight"]["cn"]).max() < 1e-4
 
 
 def test_config3_converges_from_two_starts(plm, oracle64, fits):
