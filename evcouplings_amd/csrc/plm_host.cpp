@@ -96,11 +96,8 @@ PlmOptions plm_options_from_env() {
     if (const char *e = getenv("PLM_FWD_KERNEL")) o.fwd_kernel = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
-    if (const char *e = getenv("PLM_VP_HESS_POS")) o.vp_hess_pos = atoi(e);
     if (const char *e = getenv("PLM_VP_REL")) o.vp_rel = atof(e);
     if (const char *e = getenv("PLM_ACC_FACTOR")) o.acc_factor = atof(e);
-    if (const char *e = getenv("PLM_STAG_ITERS")) o.stag_iters = std::max(2, atoi(e));
-    if (const char *e = getenv("PLM_STAG_DECADES")) o.stag_range = atof(e);
     o.debug = getenv("PLM_DEBUG") != nullptr;
     o.debug_vp = getenv("PLM_DEBUG_VP") != nullptr;
     return o;
@@ -284,6 +281,8 @@ struct plm_ctx {
     float *hj = nullptr, *hpart = nullptr;
     double *gpart = nullptr;
     double *hg2 = nullptr, *hinv = nullptr, *h64 = nullptr;   // h64: the field solver's f64 copies of the fields (two buffers)
+    double *hcnt = nullptr;    // [local site][Q] weighted state counts (plm_launch_site_counts), refreshed with the weights
+    bool hcnt_valid = false;
     int *vp_flag = nullptr;    // device-side state of the field solver's chain (PlmVpState)
     int vp_hess_age = -1;      // evaluations since the cached inverse Hessians were refreshed (-1: none exist yet)
     // host side of the chain (ctx_eval_vp_enqueue / ctx_eval_vp_finish)
@@ -483,6 +482,8 @@ int vp_alloc(plm_ctx *c) {
     PLM_TRY(dalloc(&c->hg2, nsites));
     PLM_TRY(dalloc(&c->hinv, nsites * c->d.Q * c->d.Q));
     PLM_TRY(dalloc(&c->h64, 2 * plm_h64_stride(c->d)));
+    PLM_TRY(dalloc(&c->hcnt, plm_h64_stride(c->d)));
+    c->hcnt_valid = false;
     PLM_TRY(dalloc((char **)&c->vp_flag, sizeof(PlmVpState)));
     HIP_TRY(hipMemsetAsync(c->vp_flag, 0, sizeof(PlmVpState), c->st));
     for (auto &e : c->vp_ev) HIP_TRY(hipEventCreate(&e));
@@ -490,8 +491,16 @@ int vp_alloc(plm_ctx *c) {
     return PLM_OK;
 }
 // stage 1: forward GEMM (couplings of x) -> HJ
+int vp_counts(plm_ctx *c) {      // weighted state counts per site: once per set of weights
+    if (!c->hcnt_valid) {
+        HIP_TRY(plm_launch_site_counts(c->d, c->msa_cm, c->w, c->hcnt, c->st));
+        c->hcnt_valid = true;
+    }
+    return PLM_OK;
+}
 int vp_stage1(plm_ctx *c) {
     const PlmDims &d = c->d;
+    PLM_TRY(vp_counts(c));
     if (d.sharded) {
         HIP_TRY(plm_launch_pack_x(d, c->x, c->xsend, c->st));
         PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
@@ -508,18 +517,20 @@ int vp_stage1(plm_ctx *c) {
 }
 // One Newton step on the fields with the cached (or, refresh: recomputed) inverse Hessians + the residual pass at the
 // result: the "fields" leg of plm_ctx_time_kernels.  (The fit's evaluations run the chain below.)
+int vp_counts(plm_ctx *c);
 int vp_step_and_residuals(plm_ctx *c, bool refresh) {
     const PlmDims &d = c->d;
+    PLM_TRY(vp_counts(c));
     const int full = (refresh || c->vp_hess_age < 0) ? 1 : 0;
     HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, c->fwd_accurate, nullptr, nullptr, c->hpart,
                              c->gpart, nullptr, PLM_VP_ALWAYS, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
-                              0.0, nullptr, 0, c->st));
+                              0.0, nullptr, 0, c->hcnt, c->st));
     if (full) c->vp_hess_age = 0;
     HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
                              nullptr, PLM_VP_ALWAYS, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
-                              0.0, nullptr, 0, c->st));
+                              0.0, nullptr, 0, c->hcnt, c->st));
     return PLM_OK;
 }
 // stage 2: the field solver as ONE chain of launches (round 5; rounds 2-4 ran it in rounds with a host round trip
@@ -544,7 +555,7 @@ int vp_chain(plm_ctx *c, int npos, int hess_upto, int expected_last, double tol2
         HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
                                  c->vp_flag, PLM_VP_PASS_RT, c->st));
         HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, hess ? 2 : 0, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2,
-                                  c->scal + 5, tol2, c->vp_floor2, c->vp_flag, 1, c->st));
+                                  c->scal + 5, tol2, c->vp_floor2, c->vp_flag, 1, c->hcnt, c->st));
         if (hess) c->vp_hess_age = 0;
     }
     return PLM_OK;
@@ -591,8 +602,9 @@ int ctx_eval_vp_enqueue(plm_ctx *c, double tol2) {
     c->vp_extra = 0;
     c->vp_last_gh2 = INFINITY;
     if (c->vp_hess_age >= 0) c->vp_hess_age++;
-    int hess_upto = c_prev >= 2 ? c_prev : ((c->vp_hess_age < 0 || c->vp_hess_age >= 32) ? 1 : 0);
-    if (c->opt.vp_hess_pos >= 0 && c_prev >= 2) hess_upto = std::min(hess_upto, c->opt.vp_hess_pos);
+    // fresh Hessian sums at every position before the expected last one (measured, gpurun_out/r5c9: Hessians at the
+    // first position only -> 9.8 passes per evaluation in the bench window instead of 4.6, at the first two -> 5.9)
+    const int hess_upto = c_prev >= 2 ? c_prev : ((c->vp_hess_age < 0 || c->vp_hess_age >= 32) ? 1 : 0);
     PLM_TRY(vp_chain(c, std::min(14, c_prev + 3), hess_upto, c_prev, tol2));
     HIP_TRY(plm_launch_fields_to_x(d, c->h64, c->vp_flag, c->x, c->st));
     HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr,
@@ -663,7 +675,7 @@ int ctx_eval_vp_finish(plm_ctx *c, double tol2, bool *again, double *gh2_out) {
     // norm only (update = 0, not a chain position: k_vp_check writes the sum alone -- passes / verdict of the continued
     // chain stay), at the chain's current fields
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
-                              0.0, c->vp_flag, 0, c->st));
+                              0.0, c->vp_flag, 0, c->hcnt, c->st));
     HIP_TRY(hipEventRecord(c->vp_ev[1], c->st));
     c->vp_ev_pending = true;
     PLM_TRY(vp_stage3(c, false));
@@ -827,7 +839,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
         if (e) (void)hipEventDestroy(e);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->vp_flag,
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->hcnt, c->vp_flag,
                     c->xa, c->ga, c->pair_n2};
     for (void *b : bufs)
         if (b) hipFree(b);
@@ -1084,6 +1096,7 @@ int plm_ctx_set_weights(plm_ctx_t *c, const float *weights_host) {
     HIP_TRY(hipStreamSynchronize(c->st));
     c->n_eff = neff;
     c->have_weights = true;
+    c->hcnt_valid = false;
     c->wmax = wmax;
     c->eval_valid = false;
     // residual quantisation of the backward GEMM: |r_s(i,a)| <= w_s, so the largest weight maps to the largest
@@ -1701,13 +1714,14 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             if (last_cond < 0.97 * best_cond) {
                 best_cond = last_cond;
                 best_k = k;
-            } else if (vp && k - best_k >= c->opt.stag_iters && last_cond < c->opt.stag_range * eps && stag_resets < 3 && stored > 0) {
+            } else if (vp && k - best_k >= 12 && last_cond < 10.0 * eps && stag_resets < 3 && stored > 0) {
                 stored = 0;
                 end = 0;
                 anchored = false;
                 step = first_step();
                 stag_resets++;
                 best_k = k;
+                if (c->opt.debug) fprintf(stderr, "[plm] stagnation watch: history dropped at iteration %d (|g|/|x| %.3e, best %.3e)\n", k, last_cond, best_cond);
             }
         }
     }

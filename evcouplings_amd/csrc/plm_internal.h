@@ -118,9 +118,6 @@ struct PlmOptions {
     int jexp_bias = 0;      // PLM_JEXP_BIAS: added to the scale exponent of the forward operand (tests/probes/noise_probe.py)
     int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)
     double acc_factor = 8.0;   // PLM_ACC_FACTOR: the fit switches to the accurate evaluation below max(3 eps, this x 3e-11 N L)
-    int stag_iters = 12;       // PLM_STAG_ITERS / PLM_STAG_DECADES: the stagnation watch of plm_ctx_optimize (iterations without
-    double stag_range = 10.0;  // a new best |g|/|x|, and how far above epsilon it starts watching)
-    int vp_hess_pos = -1;   // PLM_VP_HESS_POS: chain positions that may carry fresh Hessian sums (-1: all before the expected last)
     double vp_rel = 1e-4;   // PLM_VP_REL: field-solver tolerance relative to the reduced gradient of the last accepted point
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)
     bool debug = false;     // PLM_DEBUG: line-search failures are traced to stderr
@@ -189,6 +186,7 @@ struct PlmVpState {
                       // written to the other one and becomes current only if the chain goes on (k_vp_check)
     int pad_;
     double g2_prev;   // squared gradient norm of the previous pass (contraction estimate)
+    double g2_prev2;  // ... and of the pass before it (stall detection over two passes)
     double hist[PLM_VP_HIST];   // squared gradient norm and open sites (x 1e-6 in the fraction... see k_vp_check) per pass: PLM_DEBUG_VP
 };
 #define PLM_VP_ALWAYS 0     // unconditional launch
@@ -218,7 +216,10 @@ hipError_t plm_launch_h64_init(const PlmDims &d, const float *x, double *h64, hi
 // current), x is left alone (plm_launch_fields_to_x after the chain); chain = 0: in place.
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
-                             double floor2, int *state, int chain, hipStream_t st);
+                             double floor2, int *state, int chain, const double *cnt, hipStream_t st);
+// cnt[local site][Q] = sum_s w_s [x_si = a] (f64, fixed order): the constant part of the exact first-order sums k_hsolve
+// rescales the sampled Hessian with (cnt = NULL: the sampled row sums, rounds 2-4)
+hipError_t plm_launch_site_counts(const PlmDims &d, const int8_t *msa_cm, const float *w, double *cnt, hipStream_t st);
 size_t plm_h64_stride(const PlmDims &d);       // doubles per field buffer (h64 holds two)
 // field part of x <- the chain's current fields, rounded to f32
 hipError_t plm_launch_fields_to_x(const PlmDims &d, const double *h64, const int *state, float *x, hipStream_t st);

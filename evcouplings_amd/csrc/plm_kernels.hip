@@ -875,12 +875,22 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
                                           (size_t)d.blk_per_shard * 16 * Q) + ((size_t)b16l * 16 + r) * Q + a_lo;
     auto value = [&](int m, int a, int e) -> float { return (float)__builtin_fma((double)acc[m][a][e], sc64, cref[a]); };
     if constexpr (MODE == FWD_STORE) {
+        // The stored potentials: acc 2^-e + C with the f64 constant as a hi + lo pair of floats -- fma(acc, 2^-e, C_lo) + C_hi,
+        // two f32 operations per value instead of convert / f64 fma / convert (round 5: the f64 epilogue was 0.26 of
+        // k_fwd_w's 2.8 ms, with nothing to overlap it).  The scale is a power of two (exact); what made the f32
+        // constant of round 2 harmful was its rounding, the same for every sequence -- the pair carries all 48 bits, and
+        // the two roundings left depend on acc, i.e. differ from sequence to sequence.  k_fwd_w does the same operations.
         float4 *hj = (float4 *)A.out + ((size_t)tile * 8 + wave) * 2 * Q * 64 + lane;
+        const float sc32 = (float)sc64;
 #pragma unroll
         for (int a = 0; a < QG; a++) {
+            const double c = cref[a];
+            const float chi = (float)c, clo = (float)(c - (double)chi);
 #pragma unroll
             for (int m = 0; m < 2; m++)
-                hj[(size_t)(m * Q + a_lo + a) * 64] = make_float4(value(m, a, 0), value(m, a, 1), value(m, a, 2), value(m, a, 3));
+                hj[(size_t)(m * Q + a_lo + a) * 64] =
+                    make_float4(__builtin_fmaf(acc[m][a][0], sc32, clo) + chi, __builtin_fmaf(acc[m][a][1], sc32, clo) + chi,
+                                __builtin_fmaf(acc[m][a][2], sc32, clo) + chi, __builtin_fmaf(acc[m][a][3], sc32, clo) + chi);
         }
         return;
     }
@@ -1139,20 +1149,20 @@ template <int IDX> __device__ __forceinline__ f32x4 fwdw_acc_read() {
     return v;
 }
 template <int M, int A>
-__device__ __forceinline__ void fwdw_store(float4 *hj, const double *cref, double sc64) {
+__device__ __forceinline__ void fwdw_store(float4 *hj, const float *chi, const float *clo, float sc32) {
     const f32x4 v = fwdw_acc_read<(M * PLM_FWDW_QG + A) * 4>();
-    const double c = cref[A];
+    const float h = chi[A], l = clo[A];       // the f64 constant C_i(a) as hi + lo (see k_fwd's store epilogue)
     hj[(size_t)((M & 1) * 21 + A) * 64 + (size_t)(M >> 1) * 2 * 21 * 64] =
-        make_float4((float)__builtin_fma((double)v[0], sc64, c), (float)__builtin_fma((double)v[1], sc64, c),
-                    (float)__builtin_fma((double)v[2], sc64, c), (float)__builtin_fma((double)v[3], sc64, c));
+        make_float4(__builtin_fmaf(v[0], sc32, l) + h, __builtin_fmaf(v[1], sc32, l) + h,
+                    __builtin_fmaf(v[2], sc32, l) + h, __builtin_fmaf(v[3], sc32, l) + h);
 }
 template <int M, int... A>
-__device__ __forceinline__ void fwdw_store_row(float4 *hj, const double *cref, double sc64, std::integer_sequence<int, A...>) {
-    (fwdw_store<M, A>(hj, cref, sc64), ...);
+__device__ __forceinline__ void fwdw_store_row(float4 *hj, const float *chi, const float *clo, float sc32, std::integer_sequence<int, A...>) {
+    (fwdw_store<M, A>(hj, chi, clo, sc32), ...);
 }
 template <int... M>
-__device__ __forceinline__ void fwdw_store_all(float4 *hj, const double *cref, double sc64, std::integer_sequence<int, M...>) {
-    (fwdw_store_row<M>(hj, cref, sc64, std::make_integer_sequence<int, PLM_FWDW_QG>{}), ...);
+__device__ __forceinline__ void fwdw_store_all(float4 *hj, const float *chi, const float *clo, float sc32, std::integer_sequence<int, M...>) {
+    (fwdw_store_row<M>(hj, chi, clo, sc32, std::make_integer_sequence<int, PLM_FWDW_QG>{}), ...);
 }
 
 __global__ __launch_bounds__(256) void k_fwd_w(PlmDims d, FwdArgs A) {
@@ -1257,7 +1267,14 @@ __global__ __launch_bounds__(256) void k_fwd_w(PlmDims d, FwdArgs A) {
     // k_fwd's layout: [tile][wave of 32 sequences][row fragment pair][state][lane]; this wave's row fragment M is row
     // fragment M & 1 of wave 4 (wv & 1) + M / 2 there
     float4 *hj = (float4 *)A.out + ((size_t)(b16l * d.nstiles + stile) * 8 + (wv & 1) * 4) * 2 * Q * 64 + (size_t)a_lo * 64 + lane;
-    fwdw_store_all(hj, cref, sc64, std::make_integer_sequence<int, NM>{});
+    float chi[QG], clo[QG];
+#pragma unroll
+    for (int a = 0; a < QG; a++) {
+        const double c = cref[a];
+        chi[a] = (float)c;
+        clo[a] = (float)(c - (double)chi[a]);
+    }
+    fwdw_store_all(hj, chi, clo, (float)sc64, std::make_integer_sequence<int, NM>{});
 }
 
 // state groups per workgroup of the exact forward GEMM (56 + 112 registers of accumulators and f64 sums at 7 states)
@@ -1719,6 +1736,44 @@ size_t plm_h64_stride(const PlmDims &d) {
 }
 size_t plm_gpart_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d.b16_lo) * 16 * d.Q * sizeof(double); }
 
+// cnt[site][a] = sum_s w_s [x_si = a] over the sequences that count for the site (gap mode: the ungapped ones), f64, in a
+// fixed summation order (bit-reproducible): the constant part of the exact first-order sums m_a = sum_s w_s P_s(a) =
+// (gradient sum of the pass) + cnt_a that k_hsolve rescales the sampled Hessian with.  One workgroup per local site.
+template <int Q>
+__global__ __launch_bounds__(256) void k_site_counts(PlmDims d, const int8_t *__restrict__ msa_cm, const float *__restrict__ w,
+                                                    double *__restrict__ cnt) {
+    __shared__ double red[4];
+    const int il = blockIdx.x, i = d.h_site0 + il;
+    double acc[Q];
+#pragma unroll
+    for (int a = 0; a < Q; a++) acc[a] = 0.0;
+    if (i < d.L)
+        for (int s = threadIdx.x; s < d.N; s += 256) {
+            const int x = msa_cm[(size_t)i * d.Np + s];
+            const double ws = (d.gap_mode && x == 0) ? 0.0 : (double)w[s];
+#pragma unroll
+            for (int a = 0; a < Q; a++) acc[a] += (x == a) ? ws : 0.0;
+        }
+#pragma unroll
+    for (int a = 0; a < Q; a++) {
+        const double t = block_reduce_sum(acc[a], red);
+        if (threadIdx.x == 0) cnt[(size_t)il * Q + a] = t;
+        __syncthreads();
+    }
+}
+hipError_t plm_launch_site_counts(const PlmDims &d, const int8_t *msa_cm, const float *w, double *cnt, hipStream_t st) {
+    const int nsites = (d.b16_hi - d.b16_lo) * 16;
+    if (nsites <= 0) return hipSuccess;
+    switch (d.Q) {
+    case 21: hipLaunchKernelGGL(k_site_counts<21>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
+    case 20: hipLaunchKernelGGL(k_site_counts<20>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
+    case 5: hipLaunchKernelGGL(k_site_counts<5>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
+    case 4: hipLaunchKernelGGL(k_site_counts<4>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // Newton step on the fields of one site (one wave per site).  The workgroup partials of the last pass are summed
 // in f64 (fixed order).  full = 1: the pass carried Hessian sums -- H = diag(rowsum M) - M + 2 lambda_h I is
 // inverted (Gauss-Jordan in LDS, f64) and the inverse cached in hinv; otherwise the cached inverse is reused
@@ -1730,7 +1785,8 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
                                               float *__restrict__ x, double *__restrict__ h64,
                                               double lambda_h, int update,
                                               double *__restrict__ hinv, double *__restrict__ g2_site,
-                                              double tol_site2, const int *__restrict__ state, int chain, int hstride) {
+                                              double tol_site2, const int *__restrict__ state, int chain, int hstride,
+                                              const double *__restrict__ cnt) {
     constexpr int NVF = PLM_HSTATS(Q);
     const PlmVpState *S = (const PlmVpState *)state;
     int cur = 0;
@@ -1744,7 +1800,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     __shared__ double st[NVF];
     __shared__ double Hm[Q][2 * Q + 1];             // [H | I] -> [I | H^-1] (odd row stride: no bank conflicts)
     __shared__ double Hi[Q][Q + 1];                 // the inverse the step is taken with
-    __shared__ double gr[Q];
+    __shared__ double gr[Q], Dv[Q], mv[Q];
     const int il = blockIdx.x, t = threadIdx.x;     // local site index
     const int i = d.h_site0 + il;
     if (i >= min(d.L, d.own_hi * 16)) {             // padding sites of the last block
@@ -1795,9 +1851,40 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
             Hm[a][Q + b] = (a == b) ? 1.0 : 0.0;
         }
         __syncthreads();
+        // The second-order sums M~ come from every 16th sequence tile; their row sums estimate the first-order sums
+        // m_a = sum_s w P_s(a) -- which this pass knows EXACTLY (gradient sum + weighted count of the state).  A rare state
+        // whose few sequences happen to sit in (or outside) the sampled tiles has its row of M~ off by up to 16x, and the
+        // site then converges at 0.6 ... 0.94 per step (round 5 traces: tails of 5-9 passes; at config 3 ten times the
+        // tolerance).  The sampled matrix is therefore rescaled symmetrically, X = D M~ D, until its row sums ARE m (three
+        // Sinkhorn sweeps), and H = diag(rowsum X) - X + 2 lambda I: still a graph Laplacian (positive semidefinite, rows
+        // summing to zero: the softmax gauge direction stays exact), with exact first-order content.  CPU lab
+        // (tests/probes/field_solver_lab.py): contraction per step 0.03 -> 0.003.  (Scaling the rows to m without
+        // restoring the zero row sums -- H = diag(m) - D M~ D -- breaks the cancellation between the two terms and is far
+        // worse than no correction: measured, gpurun_out/r5c13.)
+        if (t < Q) {
+            mv[t] = cnt ? fmax(0.0, st[t] + cnt[(size_t)il * Q + t]) : 0.0;
+            Dv[t] = 1.0;
+        }
+        __syncthreads();
+        if (cnt) {
+            for (int sweep = 0; sweep < 3; sweep++) {
+                double nd = 0.0;
+                if (t < Q) {
+                    double rs = 0;
+                    for (int b = 0; b < Q; b++) rs -= Hm[t][b] * Dv[b];
+                    rs *= Dv[t];
+                    nd = rs > 0.0 ? Dv[t] * sqrt(mv[t] / rs) : 0.0;
+                }
+                __syncthreads();
+                if (t < Q) Dv[t] = nd;
+                __syncthreads();
+            }
+            for (int k = t; k < Q * Q; k += 64) Hm[k / Q][k % Q] *= Dv[k / Q] * Dv[k % Q];
+            __syncthreads();
+        }
         if (t < Q) {
             double rowsum = 0;
-            for (int b = 0; b < Q; b++) rowsum -= Hm[t][b];   // sum_b M_ab = sum_s w P_s(a)
+            for (int b = 0; b < Q; b++) rowsum -= Hm[t][b];   // sum_b X_ab (~ m_a)
             Hm[t][2 * Q] = rowsum;
         }
         __syncthreads();
@@ -1914,9 +2001,16 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
         // per-site shares only decide which sites still move.  (Waiting for every site to meet its share makes the whole
         // chain wait for the slowest one: measured, 9-14 passes per evaluation with the total long inside the tolerance.)
         const int open_total = bad[0] + bad[1] + bad[2] + bad[3];
-        // ... or the solver has arrived at the noise floor of its f32 gradient sums (floor2: the host's estimate of it)
-        // and a pass no longer gains a factor 2 in norm: below the floor an evaluation would only burn passes
-        const bool at_floor = S->passes >= 1 && t <= floor2 && t > 0.25 * S->g2_prev;
+        // ... or the solver has arrived at the noise floor of its f32 gradient sums, where an evaluation would only burn
+        // passes: below the host's estimate of the floor (floor2) a single pass that no longer gains a factor 2 in norm
+        // ends the chain; within a factor 10 of the tolerance two passes that together gain less than that do (the
+        // estimate is only an estimate: at N = 100 000 the plain passes stall above it, and 95 of 271 chains of a config-3
+        // fit ran out of positions until this rule existed; a site whose sampled Hessian is poor converges at 0.6 per
+        // pass, 0.36 over two, and goes on).  Far from the tolerance the norm may stand still for a few capped steps:
+        // no stall rule there.
+        const bool near_tol = t <= 100.0 * tol2;
+        const bool stall1 = S->passes >= 1 && t > 0.25 * S->g2_prev, stall2 = S->passes >= 2 && t > 0.25 * S->g2_prev2;
+        const bool at_floor = (stall1 && t <= floor2) || (near_tol && stall2);
         const bool done = open_total == 0 || !(t > tol2) || at_floor || t != t;
         if (S->passes < PLM_VP_HIST) S->hist[S->passes] = t + 1e-30 * 0 + (double)open_total * 1e9;   // debug trace: norm^2 (+ open sites * 1e9)
         S->passes += 1;
@@ -1930,14 +2024,16 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
             // contraction of the squared norm per pass: measured once two passes exist, before that the typical
             // simplified-Newton rate with sampled Hessians (~0.03 per step in norm)
             const double rate = (S->passes >= 2 && S->g2_prev > 0) ? fmin(1.0, t / S->g2_prev) : 1e-3;
-            S->want_rt = (t * fmax(1e-6, rate) <= tol2) ? 1 : 0;
+            // ... or a first pass without gain next to the tolerance: the next one ends the chain either way
+            S->want_rt = (t * fmax(1e-6, rate) <= tol2 || (near_tol && stall1)) ? 1 : 0;
         }
+        S->g2_prev2 = S->g2_prev;
         S->g2_prev = t;
     }
 }
 __global__ void k_vp_reset(int *state, int want_rt) {
     PlmVpState *S = (PlmVpState *)state;
-    S->done = 0; S->want_rt = want_rt; S->final_skip = 0; S->passes = 0; S->cur = 0; S->g2_prev = 0.0;
+    S->done = 0; S->want_rt = want_rt; S->final_skip = 0; S->passes = 0; S->cur = 0; S->g2_prev = 0.0; S->g2_prev2 = 0.0;
     for (int k = 0; k < PLM_VP_HIST; k++) S->hist[k] = 0.0;
 }
 hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st) {
@@ -1946,7 +2042,7 @@ hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st) {
 }
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
-                             double floor2, int *state, int chain, hipStream_t st) {
+                             double floor2, int *state, int chain, const double *cnt, hipStream_t st) {
     const int nsites = (d.b16_hi - d.b16_lo) * 16;
     int *cstate = chain ? state : nullptr;      // the chain's bookkeeping runs for chain positions only
     if (nsites <= 0) {      // a shard without sites: its chain is done at once
@@ -1963,10 +2059,10 @@ hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double 
     const double tol_site2 = 0.0;
     const int hs = (int)plm_h64_stride(d);
     switch (d.Q) {
-    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
-    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
-    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
-    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs); break;
+    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
+    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
+    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
+    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
     default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out, tol_site2, tol2, floor2, cstate);

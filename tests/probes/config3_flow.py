@@ -2,7 +2,7 @@
 """GPU-side: the flow of tests/test_gpu_scale.py's fixture on one configuration (20 iterations, then a resumed fit to the
 stop rule) with the line-search diagnostics of PLM_DEBUG=1."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED

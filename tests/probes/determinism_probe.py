@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU-side probe: is one objective+gradient evaluation bit-reproducible?  (many reps)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa

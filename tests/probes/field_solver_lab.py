@@ -76,6 +76,15 @@ class Solver:
             else:
                 wP = (w[:, None, None] * P)
                 M = torch.einsum("sia,sib->iab", wP[samp], P[samp]) * samp_scale
+                if "sink" in self.variant:
+                    # k_hsolve (round 5): the sampled second-order sums rescaled symmetrically until their row sums are
+                    # the exact first-order sums m = sum_s w P (three Sinkhorn sweeps)
+                    m = wP.sum(0)
+                    D = torch.ones_like(m)
+                    for _ in range(3):
+                        rs = (D[:, :, None] * M * D[:, None, :]).sum(2)
+                        D = D * torch.sqrt(m / rs.clamp_min(1e-300))
+                    M = D[:, :, None] * M * D[:, None, :]
                 Hh = torch.diag_embed(M.sum(2)) - M + 2 * lh * EYE
         return g, Hh, (H, lse, P)
 

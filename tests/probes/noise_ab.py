@@ -5,7 +5,7 @@ rounding of the forward GEMM, the mathematics is unchanged).  Prints |g0 - g1| /
 point a fit reached after PLM_ITERS iterations (joint evaluation, plm_ctx_eval).  A/B between libraries with
 PLM_HIP_LIB (e.g. a -DPLM_SPARSE_FWD=0 build)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED

@@ -2,7 +2,7 @@
 """Phase breakdown of k_fwd / k_bwd from a -DPLM_PROBE=1 build (PLM_HIP_LIB=<probe .so>): per-wave cycles
 spent waiting (pre-barrier vmcnt + barrier) and in the epilogue (headline workload)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm, _lib
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED

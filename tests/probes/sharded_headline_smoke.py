@@ -2,7 +2,7 @@
 """GPU-side: sharded-state mode at the headline shape with all shards on one GPU (threads): checks the
 8-way partition (19 site blocks -> 3,3,3,3,3,3,1,0) against the single-GPU result."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.dist import ThreadedShards

@@ -2,7 +2,7 @@
 """Wall time of plm.hamiltonians (statistical energies of N sequences under an L-site model) on the headline
 shape, next to the CPU oracle (the reference's loop restated in C) on a sample -- SURVEY.md 8f N2."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED

@@ -2,7 +2,7 @@
 """Wall time of plm.mean_field (mean-field DCA): first call (loads rocSOLVER), a repeat, and the
 headline shape."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED

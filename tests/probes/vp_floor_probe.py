@@ -2,7 +2,7 @@
 """GPU-side: the smallest field-subproblem gradient the solver reaches (PLM_DEBUG_VP lines of a fit with an unreachable
 tolerance), to place the floor of its tolerance.  usage: PLM_DEBUG_VP=1 PLM_VP_FLOOR=0 vp_floor_probe.py 2> log"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from evcouplings_amd import plm
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED
