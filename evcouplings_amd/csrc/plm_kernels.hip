@@ -389,25 +389,41 @@ __global__ __launch_bounds__(256) void k_reweight_reg(const u32 *__restrict__ ms
     const int nch = (Lw + 15) / 16;
     const int max_mism = 4 * Lw - thresh_padded + 4 * (16 * nch - Lw);
     int cnt = 0;   // the sequence itself is pre-counted: the launcher fills counts[] with 1
-    for (int t = max(tb0, (int)blockIdx.x * 256 + 1); t < tb1; ++t) {
+    const int t_first = max(tb0, (int)blockIdx.x * 256 + 1);
+    // Early exit (round 5): mismatch counts only grow along a row, so once EVERY lane of the wave is past max_mism the
+    // partner cannot be a neighbour of any of its 64 sequences and the rest of the row is skipped -- the same counts,
+    // fewer compares.  Unrelated sequences (identity 0.2-0.3) pass 1 - theta = 0.2 L mismatches after a quarter to a
+    // half of the row: 2.1 of 5 chunks per (wave, partner) at the headline.  The first chunk of the NEXT partner row is
+    // requested before this row's compares start (rows are short now: its latency would be exposed once per row).
+    Chunk head = *(const Chunk *)(msa32 + (size_t)t_first * Lw);
+    for (int t = t_first; t < tb1; ++t) {
         const Chunk *__restrict__ trow = (const Chunk *)(msa32 + (size_t)t * Lw);
         int mism = 0;
-        Chunk cur = trow[0];
+        Chunk cur = head;
+        head = *(const Chunk *)(msa32 + (size_t)(t + 1) * Lw);      // (rows up to Np + 32 exist: t + 1 <= N is readable)
+        bool far = false;
 #pragma unroll
         for (int c = 0; c < LW / 16; c++) {
-            if (c < nch) {
+            if (c < nch && !far) {
                 Chunk nxt = cur;
                 if (c + 1 < nch) nxt = trow[c + 1];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    u32 y;   // (mine ^ partner) + 0x7f7f7f7f in one VALU op: bit 7 of a byte set <=> sites differ
-                    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(y) : "v"(mine[16 * c + k]), "s"(cur.v[k]), "v"(c7f));
-                    mism += __builtin_popcount(y & 0x80808080u);
+                for (int hf = 0; hf < 2; hf++) {
+                    if (!far) {
+#pragma unroll
+                        for (int k = 8 * hf; k < 8 * hf + 8; k++) {
+                            u32 y;   // (mine ^ partner) + 0x7f7f7f7f in one VALU op: bit 7 of a byte set <=> sites differ
+                            asm("v_xad_u32 %0, %1, %2, %3" : "=v"(y) : "v"(mine[16 * c + k]), "s"(cur.v[k]), "v"(c7f));
+                            mism += __builtin_popcount(y & 0x80808080u);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        far = __all(mism > max_mism) != 0;     // wave-uniform; looked at every 32 sites
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
             }
         }
+        if (far) continue;
         const bool hit = t > s && s < N && mism <= max_mism;
         cnt += hit ? 1 : 0;
         const unsigned long long m = __ballot(hit);

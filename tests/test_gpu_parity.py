@@ -46,6 +46,32 @@ def test_reweight_matches_oracle_bit_exact(plm, oracle64, N, L, theta):
     np.testing.assert_array_equal(plm.reweight(msa, theta), oracle64.reweight(msa, theta))
 
 
+@pytest.mark.parametrize("gaps", [False, True])
+def test_reweight_early_exit_keeps_every_neighbour(plm, oracle64, gaps):
+    """k_reweight_reg leaves a partner row as soon as all 64 sequences of a wave are past the allowed mismatches.  Rows
+    built to sit on both sides of that decision: copies of one sequence whose mismatches lie only at the END of the row
+    (a wave must not leave early on them), only at the START (the count is over the limit after the first chunk for
+    some lanes, not for all), around the threshold T - 1 / T / T + 1, scattered among unrelated rows so that waves mix
+    neighbours and strangers."""
+    N, L, theta = 3000, 300, 0.8
+    msa, _ = synthetic_msa(N, L, seed=4242)
+    rng = np.random.default_rng(7)
+    limit = L - int(np.ceil(theta * L - 1e-9))               # mismatches a neighbour may have
+    rows = rng.permutation(N)[:600]
+    for k, r in enumerate(rows):
+        m = limit - 3 + k % 7                                 # limit - 3 .. limit + 3 mismatching sites
+        src = msa[0] if k % 2 == 0 else msa[1]
+        row = src.copy()
+        sites = np.arange(L - m, L) if k % 4 < 2 else np.arange(m)
+        row[sites] = (row[sites] + 1 + rng.integers(0, 19, m)) % 21    # a different state at every chosen site
+        msa[r] = row
+    if gaps:
+        msa[rng.random(msa.shape) < 0.05] = 0
+        np.testing.assert_array_equal(plm.reweight(msa, theta, ignore_gaps=True), oracle64.reweight_gaps(msa, theta))
+    else:
+        np.testing.assert_array_equal(plm.reweight(msa, theta), oracle64.reweight(msa, theta))
+
+
 def test_reweight_large_sortedness_and_duplicates(plm):
     # size-independent properties at a size the CPU oracle would need minutes for
     N, L = 20000, 200
