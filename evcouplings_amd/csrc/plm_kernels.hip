@@ -330,6 +330,15 @@ __global__ __launch_bounds__(256) void k_reweight(const u32 *__restrict__ msa32,
                 }
                 ident[tt] = acc;
             }
+            // early exit as in k_reweight_reg: when no (lane, partner) pair of the wave can still reach the threshold
+            // with every remaining site a match, the rest of the columns changes no count
+            if constexpr (!UNGAPPED) {
+                const int rest = 4 * max(0, Lw - (c0 + RW_CW));
+                bool alive = false;
+#pragma unroll
+                for (int tt = 0; tt < RW_TT; tt++) alive |= ident[tt] + rest >= thresh_padded;
+                if (rest > 0 && !__any(alive)) break;
+            }
         }
 #pragma unroll
         for (int tt = 0; tt < RW_TT; tt++) {
