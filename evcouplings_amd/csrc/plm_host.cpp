@@ -888,16 +888,13 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
         plm_ctx_destroy(c);
         return code;
     };
-    // padded host images of the alignment (row- and column-major)
+    // padded host image of the alignment, row-major; the column-major image (+ the "ones" block) is made from it on the
+    // device (round 5: the strided host transposition was 25 ms of every context at the headline)
     const size_t rm_rows = (size_t)d.Np + 32, cm_rows = (size_t)(d.nb16 + 1) * 16;
-    std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE), cm(cm_rows * d.Np, (int8_t)PLM_PAD_STATE);
-    for (int s = 0; s < d.N; s++) {
-        const int8_t *row = prob->msa + (size_t)s * d.L;
-        memcpy(&rm[(size_t)s * d.Lp32], row, d.L);
-        for (int i = 0; i < d.L; i++) cm[(size_t)i * d.Np + s] = row[i];
-        cm[(size_t)(d.nb16 * 16) * d.Np + s] = 0;  // "ones" column: state 0 for every real sequence
-    }
-    if ((rc = dalloc(&c->msa_rm, rm.size())) || (rc = dalloc(&c->msa_cm, cm.size())) ||
+    std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE);
+    for (int s = 0; s < d.N; s++) memcpy(&rm[(size_t)s * d.Lp32], prob->msa + (size_t)s * d.L, d.L);
+    const size_t cm_size = cm_rows * d.Np;
+    if ((rc = dalloc(&c->msa_rm, rm.size())) || (rc = dalloc(&c->msa_cm, cm_size)) ||
         (rc = dalloc(&c->w, (size_t)d.Np)) || (rc = dalloc(&c->counts, (size_t)d.Np)) ||
         (rc = dalloc((char **)&c->Bt, plm_bt_bytes(d))) || (rc = dalloc((char **)&c->Rt, plm_rt_bytes(dmax))) ||
         (rc = dalloc((char **)&c->G, plm_g_bytes(dmax))) || (rc = dalloc(&c->fx_part, (size_t)c->n_fx_part())) ||
@@ -933,7 +930,7 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     if ((e = (expr)) != hipSuccess)                                                               \
         return bail(fail(PLM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e)));
     CT(hipMemcpyAsync(c->msa_rm, rm.data(), rm.size(), hipMemcpyHostToDevice, c->st));
-    CT(hipMemcpyAsync(c->msa_cm, cm.data(), cm.size(), hipMemcpyHostToDevice, c->st));
+    CT(plm_launch_msa_columns(d, c->msa_rm, c->msa_cm, (int)cm_rows, c->st));
     CT(hipMemsetAsync(c->w, 0, sizeof(float) * d.Np, c->st));
     CT(hipMemsetAsync(c->Rt, 0, plm_rt_bytes(dmax), c->st));
     CT(hipMemsetAsync(c->x, 0, sizeof(float) * d.n_local, c->st));
@@ -1137,7 +1134,10 @@ int plm_ctx_get_weights(plm_ctx_t *c, float *weights_host, int32_t *counts_host,
     return PLM_OK;
 }
 
-int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
+// compact: device scratch for PLM_FLAG_COMPACT_GAPS (gap mode: fij_host receives (Q-1)-state blocks); nullptr = q-state layout
+static int ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host, float *compact);
+int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) { return ctx_marginals(c, fi_host, fij_host, nullptr); }
+static int ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host, float *compact) {
     if (!c) return fail(PLM_EINVAL, "NULL ctx");
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set: call plm_ctx_reweight / plm_ctx_set_weights");
     if (c->d.nshards > 1) return fail(PLM_EUNSUPPORTED, "marginals run unsharded (create a 1-shard context)");
@@ -1154,14 +1154,25 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
     HIP_TRY(plm_launch_native_to_canon(d, c->g, c->canon, c->st));
     c->h_fi.resize((size_t)d.L * d.Qc);
     HIP_TRY(hipMemcpyAsync(c->h_fi.data(), c->canon, sizeof(float) * d.L * d.Qc, hipMemcpyDeviceToHost, c->st));
-    if (fij_host)
-        HIP_TRY(hipMemcpyAsync(fij_host, c->canon + (size_t)d.L * d.Qc,
-                               sizeof(float) * (d.n_canon - (int64_t)d.L * d.Qc), hipMemcpyDeviceToHost, c->st));
+    // PLM_CONV_G_FREQ_TOTAL: normalised by N_eff (all sequences) instead of the ungapped ones
+    const bool by_total = d.conv & PLM_CONV_G_FREQ_TOTAL;
+    if (fij_host) {
+        // gap mode: the pair blocks are normalised over the jointly ungapped sequences on the device (round 5; the host
+        // loop over 44 850 blocks was 15 ms of a -g fit), same arithmetic: total in f64 in block order, (float)(f / total)
+        if (d.gap_mode)
+            HIP_TRY(plm_launch_gap_normalise_pairs(d, c->canon + (size_t)d.L * d.Qc, by_total ? (double)c->n_eff : 0.0, c->st));
+        if (compact && d.gap_mode) {
+            const size_t npair = (size_t)d.L * (d.L - 1) / 2, qn = (size_t)d.Qc - 1;
+            HIP_TRY(plm_launch_compact_gap_blocks(d, c->canon + (size_t)d.L * d.Qc, compact, c->st));
+            HIP_TRY(hipMemcpyAsync(fij_host, compact, sizeof(float) * npair * qn * qn, hipMemcpyDeviceToHost, c->st));
+        } else {
+            HIP_TRY(hipMemcpyAsync(fij_host, c->canon + (size_t)d.L * d.Qc,
+                                   sizeof(float) * (d.n_canon - (int64_t)d.L * d.Qc), hipMemcpyDeviceToHost, c->st));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(c->st));
     if (d.gap_mode) {
         const int Q = d.Qc;
-        // PLM_CONV_G_FREQ_TOTAL: normalised by N_eff (all sequences) instead of the ungapped ones
-        const bool by_total = d.conv & PLM_CONV_G_FREQ_TOTAL;
         for (int i = 0; i < d.L; i++) {
             float *f = &c->h_fi[(size_t)i * Q];
             double tot = 0;
@@ -1169,19 +1180,6 @@ int plm_ctx_marginals(plm_ctx_t *c, float *fi_host, float *fij_host) {
             if (by_total) tot = c->n_eff;
             f[0] = 0.f;
             for (int a = 1; a < Q; a++) f[a] = tot > 0 ? (float)(f[a] / tot) : 0.f;
-        }
-        if (fij_host) {
-            const size_t npair = (size_t)d.L * (d.L - 1) / 2;
-            for (size_t p = 0; p < npair; p++) {
-                float *f = fij_host + p * Q * Q;
-                double tot = 0;
-                for (int a = 1; a < Q; a++)
-                    for (int b = 1; b < Q; b++) tot += f[a * Q + b];
-                if (by_total) tot = c->n_eff;
-                for (int a = 0; a < Q; a++)
-                    for (int b = 0; b < Q; b++)
-                        f[a * Q + b] = (a && b && tot > 0) ? (float)(f[a * Q + b] / tot) : 0.f;
-            }
         }
     }
     if (fi_host) memcpy(fi_host, c->h_fi.data(), sizeof(float) * d.L * d.Qc);
@@ -1233,6 +1231,30 @@ static int get_vec(plm_ctx_t *c, const float *native, float *out_host) {
     PLM_TRY(canon_full(c, native));
     HIP_TRY(hipMemcpyAsync(out_host, c->canon, sizeof(float) * c->d.n_canon, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
+    return PLM_OK;
+}
+// the same vector as two host arrays (fields [L][q], couplings [pairs][q][q]): what plm_fit hands back, without a
+// staging copy of the whole vector (79 MB at the headline: allocation, zero fill and a second memcpy were 25 ms)
+// compact (gap mode, PLM_FLAG_COMPACT_GAPS): device scratch; both arrays then come back in the (Q-1)-state layout
+static int get_vec_split(plm_ctx_t *c, const float *native, float *h_host, float *j_host, float *compact) {
+    if (!c) return fail(PLM_EINVAL, "NULL ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    PLM_TRY(canon_full(c, native));
+    const PlmDims &d = c->d;
+    const size_t nh = (size_t)d.L * d.Qc;
+    const bool cut = compact && d.gap_mode;
+    std::vector<float> hfull(cut && h_host ? nh : 0);
+    if (h_host) HIP_TRY(hipMemcpyAsync(cut ? hfull.data() : h_host, c->canon, sizeof(float) * nh, hipMemcpyDeviceToHost, c->st));
+    if (j_host && cut) {
+        const size_t npair = (size_t)d.L * (d.L - 1) / 2, qn = (size_t)d.Qc - 1;
+        HIP_TRY(plm_launch_compact_gap_blocks(d, c->canon + nh, compact, c->st));
+        HIP_TRY(hipMemcpyAsync(j_host, compact, sizeof(float) * npair * qn * qn, hipMemcpyDeviceToHost, c->st));
+    } else if (j_host) {
+        HIP_TRY(hipMemcpyAsync(j_host, c->canon + nh, sizeof(float) * ((size_t)d.n_canon - nh), hipMemcpyDeviceToHost, c->st));
+    }
+    HIP_TRY(hipStreamSynchronize(c->st));
+    if (cut && h_host)
+        for (int i = 0; i < d.L; i++) memcpy(h_host + (size_t)i * (d.Qc - 1), &hfull[(size_t)i * d.Qc + 1], sizeof(float) * (d.Qc - 1));
     return PLM_OK;
 }
 int plm_ctx_get_x(plm_ctx_t *c, float *x_canonical_host) { return get_vec(c, c ? c->x : nullptr, x_canonical_host); }
@@ -1763,25 +1785,14 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
     const PlmDims &d = c->d;
     float *fn_dev = c->canon + d.n_canon;
     PLM_TRY(canon_full(c, c->x));
+    PlmDims dc = d;
+    dc.Q = d.Qc;             // k_fn walks the canonical blocks: the gauge is taken over the problem's states only
     if (d.gap_mode) {
-        // the zero-sum gauge must be taken over the model's (Q-1) states only: repack the blocks
-        const int Q = d.Qc, Qn = Q - 1;
-        const size_t npair = (size_t)d.L * (d.L - 1) / 2;
-        std::vector<float> full(npair * Q * Q), cut(npair * Qn * Qn);
-        HIP_TRY(hipMemcpyAsync(full.data(), c->canon + (size_t)d.L * Q, sizeof(float) * full.size(),
-                               hipMemcpyDeviceToHost, c->st));
-        HIP_TRY(hipStreamSynchronize(c->st));
-        for (size_t p = 0; p < npair; p++)
-            for (int a = 1; a < Q; a++)
-                memcpy(&cut[(p * Qn + (a - 1)) * Qn], &full[(p * Q + a) * Q + 1], sizeof(float) * Qn);
-        HIP_TRY(hipMemcpyAsync(c->canon, cut.data(), sizeof(float) * cut.size(), hipMemcpyHostToDevice, c->st));
-        PlmDims dn = d;
-        dn.Q = Qn;
-        HIP_TRY(plm_launch_fn(dn, c->canon, fn_dev, 0, c->st));
+        // the zero-sum gauge and the norm are taken over the model's (Q-1) states only: k_fn leaves out row and column 0
+        // of every block (round 5; rounds 2-4 repacked the blocks on the host: 54 ms of a -g fit at the headline)
+        HIP_TRY(plm_launch_fn(dc, c->canon + (size_t)d.L * d.Qc, fn_dev, 1, 1, c->st));
     } else {
-        PlmDims dc = d;
-        dc.Q = d.Qc;             // k_fn walks the canonical blocks: the gauge is taken over the problem's states only
-        HIP_TRY(plm_launch_fn(dc, c->canon + (size_t)d.L * d.Qc, fn_dev, (d.conv & PLM_CONV_FN_NO_GAP) ? 1 : 0, c->st));
+        HIP_TRY(plm_launch_fn(dc, c->canon + (size_t)d.L * d.Qc, fn_dev, (d.conv & PLM_CONV_FN_NO_GAP) ? 1 : 0, 0, c->st));
     }
     HIP_TRY(hipMemcpyAsync(fn_host, fn_dev, sizeof(float) * d.L * d.L, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
@@ -2028,7 +2039,7 @@ int plm_scores_ex(const float *jij, int32_t n_sites, int32_t n_states, int32_t f
     int rc = dalloc(&dfn, (size_t)n_sites * n_sites);
     if (rc) { hipFree(dj); return rc; }
     hipError_t e = hipMemcpy(dj, jij, sizeof(float) * nj, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = plm_launch_fn(d, dj, dfn, (flags & PLM_CONV_FN_NO_GAP) ? 1 : 0, nullptr);
+    if (e == hipSuccess) e = plm_launch_fn(d, dj, dfn, (flags & PLM_CONV_FN_NO_GAP) ? 1 : 0, 0, nullptr);
     if (e == hipSuccess) e = hipMemcpy(fn_out, dfn, sizeof(float) * n_sites * n_sites, hipMemcpyDeviceToHost);
     hipFree(dj);
     hipFree(dfn);
@@ -2240,7 +2251,13 @@ static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int devi
     if (!rc) rc = plm_ctx_get_weights(c1, w.data(), nullptr, &neff);
     result->seconds_reweight = now_s() - t1;
     t1 = now_s();
-    if (!rc) rc = plm_ctx_marginals(c1, fi.data(), result->fij);
+    // PLM_FLAG_COMPACT_GAPS: the pair arrays lose the gap state's row and column on the device, before the download
+    const bool compact = (problem->flags & PLM_FLAG_COMPACT_GAPS) && (problem->flags & PLM_FLAG_IGNORE_GAPS);
+    float *cbuf = nullptr;
+    if (!rc && compact && (result->fij || result->jij) && q > 1 &&
+        hipMalloc((void **)&cbuf, sizeof(float) * (size_t)L * (L - 1) / 2 * (q - 1) * (q - 1) + 16) != hipSuccess)
+        rc = fail(PLM_ENOMEM, "out of device memory (gap compaction buffer)");
+    if (!rc) rc = ctx_marginals(c1, fi.data(), result->fij, cbuf);
     result->seconds_marginals = now_s() - t1;
     plm_ctx_t *c = c1;
     if (!rc && nshards > 1) {
@@ -2257,12 +2274,8 @@ static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int devi
     }
     if (!rc) rc = plm_ctx_set_x(c, nullptr);
     if (!rc) rc = plm_ctx_optimize(c, iter_cb, iter_user, result);
-    if (!rc && (result->hi || result->jij)) {
-        std::vector<float> x((size_t)c->d.n_canon);
-        rc = plm_ctx_get_x(c, x.data());
-        if (!rc && result->hi) memcpy(result->hi, x.data(), sizeof(float) * L * q);
-        if (!rc && result->jij) memcpy(result->jij, x.data() + (size_t)L * q, sizeof(float) * npq);
-    }
+    if (!rc && (result->hi || result->jij)) rc = get_vec_split(c, c->x, result->hi, result->jij, cbuf);
+    if (cbuf) (void)hipFree(cbuf);
     if (!rc && (result->fn || result->cn)) {   // either score matrix may be asked for on its own
         std::vector<float> spare;
         float *fn = result->fn, *cn = result->cn;
@@ -2274,7 +2287,10 @@ static int fit_impl(const plm_problem_t *problem, plm_result_t *result, int devi
     }
     if (!rc) {
         if (result->weights) memcpy(result->weights, w.data(), sizeof(float) * N);
-        if (result->fi) memcpy(result->fi, fi.data(), sizeof(float) * L * q);
+        if (result->fi && compact)
+            for (int i = 0; i < L; i++) memcpy(result->fi + (size_t)i * (q - 1), &fi[(size_t)i * q + 1], sizeof(float) * (q - 1));
+        else if (result->fi)
+            memcpy(result->fi, fi.data(), sizeof(float) * L * q);
         result->n_eff = neff;
     }
     if (c) plm_ctx_destroy(c);

@@ -258,7 +258,10 @@ hipError_t plm_launch_lincomb(float *out, float ca, const float *a, float cb, co
 hipError_t plm_launch_canon_to_native(const PlmDims &d, const float *xc, float *xn, hipStream_t st);
 hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *xc, hipStream_t st);
 // a_lo = 1: state 0 is left out of the norm (PLM_CONV_FN_NO_GAP), the gauge is still taken over all Q states
-hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, int a_lo, hipStream_t st);
+hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, int a_lo, int g_lo, hipStream_t st);
+hipError_t plm_launch_msa_columns(const PlmDims &d, const int8_t *msa_rm, int8_t *msa_cm, int cm_rows, hipStream_t st);
+hipError_t plm_launch_compact_gap_blocks(const PlmDims &d, const float *blocks, float *out, hipStream_t st);
+hipError_t plm_launch_gap_normalise_pairs(const PlmDims &d, float *fij_canon, double fixed_total, hipStream_t st);
 // alignment statistics (row N3): per-sequence gap counts + identities to a query, per-column gap counts
 hipError_t plm_launch_align_stats(const int8_t *msa, int n, int L, int gap_state, const int8_t *query, int32_t *seq_gaps,
                                   int32_t *col_gaps, int32_t *ident, hipStream_t st);

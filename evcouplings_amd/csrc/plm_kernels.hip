@@ -488,6 +488,38 @@ hipError_t plm_launch_reweight(const PlmDims &d, const int8_t *msa_rm, int thres
 }
 
 // =========================================================================================
+// column-major image of the alignment for the backward GEMM's A operand: cm[i][s] = rm[s][i] for the sites, pad 127 in
+// the rows past Lp32 and the sequences past N, and the "ones" row nb16 * 16 = state 0 for every real sequence (its
+// one-hot row against state 0 is all ones: the field gradient / the single-site counts come out of the same GEMM).
+// 64 x 64 byte tiles through LDS, both sides coalesced.
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_msa_columns(PlmDims d, const int8_t *__restrict__ rm, int8_t *__restrict__ cm,
+                                                    int cm_rows) {
+    __shared__ int8_t tile[64][65];
+    const int s0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ones_row = d.nb16 * 16;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int s = s0 + ty * 16 + k, i = i0 + tx;
+        int8_t v = (int8_t)PLM_PAD_STATE;
+        if (s < d.Np && i < d.Lp32) v = rm[(size_t)s * d.Lp32 + i];       // rows N..Np-1 and columns L..Lp32-1 are pad
+        if (i == ones_row) v = s < d.N ? (int8_t)0 : (int8_t)PLM_PAD_STATE;
+        tile[ty * 16 + k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int i = i0 + ty * 16 + k, s = s0 + tx;
+        if (i < cm_rows && s < d.Np) cm[(size_t)i * d.Np + s] = tile[tx][ty * 16 + k];
+    }
+}
+hipError_t plm_launch_msa_columns(const PlmDims &d, const int8_t *msa_rm, int8_t *msa_cm, int cm_rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_msa_columns, dim3((d.Np + 63) / 64, (cm_rows + 63) / 64), dim3(256), 0, st, d, msa_rm, msa_cm, cm_rows);
+    return hipGetLastError();
+}
+
+// =========================================================================================
 // one-hot residual builder for the marginals:  R[s,(i,a)] = w_s [x_si = a]  in Rt layout
 // =========================================================================================
 __global__ __launch_bounds__(256) void k_onehot_rt(PlmDims d, const int8_t *__restrict__ msa_rm,
@@ -2826,9 +2858,12 @@ hipError_t plm_launch_native_to_canon(const PlmDims &d, const float *xn, float *
 }
 
 // row a8: zero-sum gauge + Frobenius norm per pair (couplings/model.py:208-231, 792),
-// one wave per pair; means and the squared norm are accumulated in f64
+// one wave per pair; means and the squared norm are accumulated in f64.
+//   g_lo: first state of the model -- 1 in gap mode (plmc -g: the gauge and the norm are those of the (Q-1)-state model,
+//         row and column 0 of a block do not exist), else 0;
+//   a_lo: first state that enters the norm (1: PLM_CONV_FN_NO_GAP, gauge over all states, gap state left out of the norm).
 __global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict__ jij, float *__restrict__ fn,
-                                          int a_lo) {
+                                          int a_lo, int g_lo) {
     __shared__ float blk[32 * 32];
     __shared__ double rm[32], cm[32];
     __shared__ double red[1];
@@ -2837,27 +2872,28 @@ __global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict
         if (threadIdx.x == 0 && j == i) fn[(size_t)i * L + i] = 0.f;
         return;
     }
-    const int QQ = Q * Q;
+    const int QQ = Q * Q, Qm = Q - g_lo;
     const float *src = jij + (size_t)plm_pair_index(i, j, L) * QQ;
     for (int k = threadIdx.x; k < QQ; k += 64) blk[k] = src[k];
     __syncthreads();
     if (threadIdx.x < Q) {
         double r = 0, c = 0;
-        for (int k = 0; k < Q; k++) {
+        for (int k = g_lo; k < Q; k++) {
             r += blk[threadIdx.x * Q + k];
             c += blk[k * Q + threadIdx.x];
         }
-        rm[threadIdx.x] = r / Q;
-        cm[threadIdx.x] = c / Q;
+        rm[threadIdx.x] = r / Qm;
+        cm[threadIdx.x] = c / Qm;
     }
     __syncthreads();
     double m = 0;
-    for (int k = 0; k < Q; k++) m += rm[k];
-    m /= Q;
+    for (int k = g_lo; k < Q; k++) m += rm[k];
+    m /= Qm;
+    const int n_lo = a_lo > g_lo ? a_lo : g_lo;
     double ss = 0;
     for (int k = threadIdx.x; k < QQ; k += 64) {
         const double z = (double)blk[k] - rm[k / Q] - cm[k % Q] + m;
-        if (k / Q >= a_lo && k % Q >= a_lo) ss += z * z;   // a_lo = 1: gap state left out (PLM_CONV_FN_NO_GAP)
+        if (k / Q >= n_lo && k % Q >= n_lo) ss += z * z;
     }
     const double t = block_reduce_sum(ss, red);
     if (threadIdx.x == 0) {
@@ -2866,8 +2902,51 @@ __global__ __launch_bounds__(64) void k_fn(int L, int Q, const float *__restrict
         fn[(size_t)j * L + i] = v;
     }
 }
-hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, int a_lo, hipStream_t st) {
-    hipLaunchKernelGGL(k_fn, dim3(d.L, d.L), dim3(64), 0, st, d.L, d.Q, jij_canon, fn, a_lo);
+hipError_t plm_launch_fn(const PlmDims &d, const float *jij_canon, float *fn, int a_lo, int g_lo, hipStream_t st) {
+    hipLaunchKernelGGL(k_fn, dim3(d.L, d.L), dim3(64), 0, st, d.L, d.Q, jij_canon, fn, a_lo, g_lo);
+    return hipGetLastError();
+}
+
+// gap mode (plmc -g): pair frequencies over the jointly ungapped sequences.  In: canonical blocks [pairs][Q][Q] of raw
+// weighted counts; out: f(a, b) / total for a, b >= 1 (total = the block's sum over a, b >= 1, or `fixed_total` > 0:
+// PLM_CONV_G_FREQ_TOTAL), row and column 0 zero.  The total is summed by one thread in block order in f64 and every
+// entry is (float)(f / total) -- the arithmetic of the host loop this replaces, bit for bit.
+__global__ __launch_bounds__(64) void k_gap_normalise_pairs(int Q, float *__restrict__ fij, double fixed_total) {
+    __shared__ double tot_s;
+    float *f = fij + (size_t)blockIdx.x * Q * Q;
+    if (threadIdx.x == 0) {
+        double tot = 0;
+        for (int a = 1; a < Q; a++)
+            for (int b = 1; b < Q; b++) tot += f[a * Q + b];
+        tot_s = fixed_total > 0 ? fixed_total : tot;
+    }
+    __syncthreads();
+    const double tot = tot_s;
+    for (int k = threadIdx.x; k < Q * Q; k += 64) {
+        const int a = k / Q, b = k % Q;
+        f[k] = (a && b && tot > 0) ? (float)((double)f[k] / tot) : 0.f;
+    }
+}
+// PLM_FLAG_COMPACT_GAPS: canonical pair blocks [pairs][Q][Q] -> [pairs][Q-1][Q-1] without row and column 0
+__global__ __launch_bounds__(256) void k_compact_gap_blocks(int Q, const float *__restrict__ in, float *__restrict__ out,
+                                                           size_t npair) {
+    const int Qn = Q - 1, QQn = Qn * Qn;
+    for (size_t p = blockIdx.x; p < npair; p += gridDim.x) {
+        const float *src = in + p * Q * Q;
+        float *dst = out + p * QQn;
+        for (int k = threadIdx.x; k < QQn; k += 256) dst[k] = src[(k / Qn + 1) * Q + (k % Qn + 1)];
+    }
+}
+hipError_t plm_launch_compact_gap_blocks(const PlmDims &d, const float *blocks, float *out, hipStream_t st) {
+    const size_t npair = (size_t)d.L * (d.L - 1) / 2;
+    if (npair)
+        hipLaunchKernelGGL(k_compact_gap_blocks, dim3((unsigned)std::min<size_t>(npair, 65535)), dim3(256), 0, st, d.Qc, blocks,
+                           out, npair);
+    return hipGetLastError();
+}
+hipError_t plm_launch_gap_normalise_pairs(const PlmDims &d, float *fij_canon, double fixed_total, hipStream_t st) {
+    const size_t npair = (size_t)d.L * (d.L - 1) / 2;
+    if (npair) hipLaunchKernelGGL(k_gap_normalise_pairs, dim3((unsigned)npair), dim3(64), 0, st, d.Qc, fij_canon, fixed_total);
     return hipGetLastError();
 }
 

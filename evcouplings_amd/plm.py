@@ -222,6 +222,7 @@ FLAG_IGNORE_GAPS = 2
 FLAG_SHARDED_STATE = 4
 FLAG_PRECOND = 8
 FLAG_JOINT_LBFGS = 16
+FLAG_COMPACT_GAPS = 1024
 
 
 class _IterationCallback:
@@ -331,10 +332,11 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     if lambda_j is None:
         lambda_j = default_lambda_j(L, q - 1 if ignore_gaps else q)
     npair = L * (L - 1) // 2
+    qo = q - 1 if ignore_gaps else q       # -g: the library returns the (q-1)-state arrays (PLM_FLAG_COMPACT_GAPS)
     out = dict(
-        weights=np.zeros(N, np.float32), fi=np.zeros((L, q), np.float32),
-        fij=np.zeros((npair, q, q), np.float32) if want_fij else None,
-        hi=np.zeros((L, q), np.float32), jij=np.zeros((npair, q, q), np.float32),
+        weights=np.zeros(N, np.float32), fi=np.zeros((L, qo), np.float32),
+        fij=np.zeros((npair, qo, qo), np.float32) if want_fij else None,
+        hi=np.zeros((L, qo), np.float32), jij=np.zeros((npair, qo, qo), np.float32),
         fn=np.zeros((L, L), np.float32), cn=np.zeros((L, L), np.float32))
     res = PlmResult()
     for k in ("weights", "fi", "fij", "hi", "jij", "fn", "cn"):
@@ -348,6 +350,8 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
     prob = _problem(msa, q, theta_id, scale, lambda_h, lambda_j, max_iter, epsilon, lbfgs_m,
                     n_shards, shard, ignore_gaps, sharded_state=collective is not None or rccl_id is not None,
                     precond=precond, joint=joint, conventions=conventions, lambda_group=lambda_group)
+    if ignore_gaps:
+        prob.flags |= FLAG_COMPACT_GAPS
     if rccl_id is not None:
         idbuf = C.create_string_buffer(bytes(rccl_id), RCCL_ID_BYTES)
         check(lib.plm_fit_sharded_rccl(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
@@ -360,11 +364,6 @@ def fit(msa, q=21, theta_id=0.8, scale=1.0, lambda_h=0.01, lambda_j=None, max_it
         check(lib.plm_fit(C.byref(prob), C.byref(res), int(device), C.c_void_p(int(stream) or None), cb,
                           None, xcb, None))
     icb.reraise()      # an exception (or a signal handler's SystemExit) met inside the iteration callback
-    if ignore_gaps:   # drop the (all-zero) entries of state 0
-        out["fi"], out["hi"] = out["fi"][:, 1:].copy(), out["hi"][:, 1:].copy()
-        out["jij"] = out["jij"][:, 1:, 1:].copy()
-        if out["fij"] is not None:
-            out["fij"] = out["fij"][:, 1:, 1:].copy()
     out.update(
         n_eff=float(res.n_eff), iters=int(res.iters_done), n_evals=int(res.n_evals),
         status=int(res.status), status_msg=res.status_msg.decode("ascii", "replace"),

@@ -91,6 +91,11 @@ typedef struct {
  * different points.  The Python boundary exposes it as solver="joint" / PLM_HIP_SOLVER=joint / plmc_hip --solver joint.
  * (lambda_h = 0 always runs this path: the per-site Hessians of the field solver are then singular.) */
 #define PLM_FLAG_JOINT_LBFGS 16
+/* plm_fit / plm_fit_sharded / plm_fit_sharded_rccl with PLM_FLAG_IGNORE_GAPS only: the result arrays come back in the
+ * (q-1)-state layout plmc -g itself writes -- fi, hi: [L][q-1]; fij, jij: [L(L-1)/2][q-1][q-1] -- instead of the q-state
+ * layout with zero entries for the gap state.  The entries are dropped on the device before the download (the Python host
+ * used to drop them with two strided copies of the pair arrays: 30 ms of a -g fit at the headline). */
+#define PLM_FLAG_COMPACT_GAPS 1024
 /* ---- convention switches ---------------------------------------------------------------------------------------
  * plmc is not available to this project, so a few of its conventions cannot be checked; each
  * is a switch here (same bits in the oracle, oracle/plm_oracle.c), so that a plmc binary on a future host pins the

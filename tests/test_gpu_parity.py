@@ -1438,3 +1438,42 @@ def test_fit_on_a_protein_family_like_alignment(plm, oracle64, gaps):
     print("family-like alignment, gaps=%s: n_eff %.0f of %d, %d iterations / %d evaluations, oracle cond %.3e" % (
         gaps, n_eff, N, r["iters"], r["n_evals"], cond))
     assert cond < 1.05e-3, cond
+
+
+@pytest.mark.gpu
+def test_compact_gap_output_equals_the_stripped_q_state_arrays(plm):
+    """PLM_FLAG_COMPACT_GAPS (include/plm_hip.h): with -g the library hands back fi / hi / fij / jij in the (q-1)-state
+    layout plmc -g writes, dropping the gap state's entries on the device.  Same fit without the flag through the C ABI:
+    the q-state arrays have zeros in every entry of state 0 and, stripped, are the compact ones bit for bit."""
+    import ctypes as C
+    from evcouplings_amd import _lib
+    N, L = 600, 37
+    msa, _ = synthetic_msa(N, L, seed=77)
+    npair = L * (L - 1) // 2
+    lam = plm.default_lambda_j(L, Q - 1)
+    got = {}
+    for compact in (False, True):
+        qo = Q - 1 if compact else Q
+        out = dict(weights=np.zeros(N, np.float32), fi=np.full((L, qo), 7, np.float32), fij=np.full((npair, qo, qo), 7, np.float32),
+                   hi=np.full((L, qo), 7, np.float32), jij=np.full((npair, qo, qo), 7, np.float32),
+                   fn=np.zeros((L, L), np.float32), cn=np.zeros((L, L), np.float32))
+        res = plm.PlmResult()
+        for k, v in out.items():
+            setattr(res, k, v.ctypes.data)
+        prob = plm._problem(msa, Q, 0.8, 1.0, 0.01, lam, 15, 1e-3, 6, 1, 0, ignore_gaps=True)
+        if compact:
+            prob.flags |= plm.FLAG_COMPACT_GAPS
+        lib = _lib.load()
+        plm.check(lib.plm_fit(C.byref(prob), C.byref(res), 0, None, C.cast(None, _lib.ITER_CB), None,
+                              C.cast(None, _lib.EXCHANGE_CB), None))
+        got[compact] = out
+    full, cut = got[False], got[True]
+    assert not full["fi"][:, 0].any() and not full["hi"][:, 0].any()
+    assert not full["fij"][:, 0, :].any() and not full["fij"][:, :, 0].any()
+    assert not full["jij"][:, 0, :].any() and not full["jij"][:, :, 0].any()
+    np.testing.assert_array_equal(cut["fi"], full["fi"][:, 1:])
+    np.testing.assert_array_equal(cut["hi"], full["hi"][:, 1:])
+    np.testing.assert_array_equal(cut["fij"], full["fij"][:, 1:, 1:])
+    np.testing.assert_array_equal(cut["jij"], full["jij"][:, 1:, 1:])
+    np.testing.assert_array_equal(cut["cn"], full["cn"])
+    assert np.abs(cut["jij"]).max() > 0 and abs(cut["fij"].sum() / npair - 1.0) < 1e-3
