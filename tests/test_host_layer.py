@@ -67,6 +67,76 @@ def test_non_focus_mode_and_errors(tmp_path):
     assert enc.msa.tolist() == [[1, 2, 3, 4, 0], [1, 2, 0, 4, 4]]
 
 
+def test_native_alignment_input_equals_the_python_twin(tmp_path, monkeypatch):
+    """plm_fasta_split + plm_encode_columns (libplm_hip's host-side input passes, used when the library is built) against
+    alignment_io's pure-Python reader on files that exercise every framing rule: wrapped sequences, CRLF line ends,
+    blank and whitespace-only lines, leading / trailing blanks, whitespace INSIDE a data line (kept: the record then
+    has the wrong length), no final newline, headers with descriptions, '.', lowercase and symbols outside the alphabet,
+    data before the first header, an empty file."""
+    from evcouplings_amd import _lib
+    lib = _lib.load()
+    assert hasattr(lib, "plm_fasta_split") and hasattr(lib, "plm_encode_columns")
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"-ACDEFGHIKLMNPQRSTVWY.acdxBZ", dtype=np.uint8)
+
+    def both(path, **kw):
+        out = []
+        for mode in ("1", ""):
+            if mode:
+                monkeypatch.setenv("PLM_IO_PYTHON", mode)
+            else:
+                monkeypatch.delenv("PLM_IO_PYTHON", raising=False)
+            try:
+                out.append(alignment_io.encode_alignment(path, **kw))
+            except alignment_io.AlignmentFormatError as exc:
+                out.append(str(exc))
+        return out
+
+    def same(a, b):
+        if isinstance(a, str) or isinstance(b, str):
+            assert a == b, (a, b)
+            return
+        for k in ("msa", "valid", "columns", "index_list"):
+            np.testing.assert_array_equal(getattr(a, k), getattr(b, k), err_msg=k)
+        for k in ("ids", "target_seq", "focus_index", "region_start", "n_total_sites", "n_total_seqs", "n_valid_seqs"):
+            assert getattr(a, k) == getattr(b, k), k
+        assert a.msa.dtype == b.msa.dtype == np.int8 and a.msa.flags["C_CONTIGUOUS"] and b.msa.flags["C_CONTIGUOUS"]
+
+    for case in range(12):
+        n, w = int(rng.integers(1, 40)), int(rng.integers(2, 90))
+        rows = letters[rng.integers(0, letters.size if case % 3 else 21, (n, w))]
+        rows[0] = letters[rng.integers(1, 21, w)]                       # a clean focus row
+        eol = b"\r\n" if case % 2 else b"\n"
+        chunks = []
+        for r in range(n):
+            chunks.append(b">s%d/%d-%d some description" % (r, 5, 4 + w) + eol)
+            seq = rows[r].tobytes()
+            wrap = int(rng.integers(1, w + 1)) if case % 4 == 1 else w
+            for o in range(0, w, wrap):
+                lead = b"  " if case % 5 == 2 else b""
+                chunks.append(lead + seq[o:o + wrap] + (b" \t" if case % 5 == 3 else b"") + eol)
+            if case % 3 == 0:
+                chunks.append(b"   " + eol + eol)
+        body = b"".join(chunks)
+        if case % 4 == 2:
+            body = body.rstrip()                                         # no final newline
+        path = str(tmp_path / ("case%d.a2m" % case))
+        open(path, "wb").write(body)
+        same(*both(path, focus_seq="s0"))
+        same(*both(path))
+    ragged = str(tmp_path / "inner_space.fa")
+    open(ragged, "wb").write(b">a\nAC DE\n>b\nACDE\n")              # the blank inside the line belongs to the record
+    same(*both(ragged))
+    early = str(tmp_path / "early.fa")
+    open(early, "wb").write(b"ACDE\n>a\nACDE\n")
+    a, b = both(early)
+    assert isinstance(a, str) and a == b and "before the first" in a
+    empty = str(tmp_path / "empty.fa")
+    open(empty, "wb").write(b"\n\n")
+    a, b = both(empty)
+    assert isinstance(a, str) and a == b
+
+
 def test_synthetic_a2m_round_trip(tmp_path):
     msa, _ = synthetic_msa(50, 30, seed=3)
     path = msa_to_a2m(msa, str(tmp_path / "syn.a2m"), region_start=7)
