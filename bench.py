@@ -275,6 +275,13 @@ def main():
         # HIP events around it in every evaluation); time_kernels' own figure -- one Newton step + the residual pass --
         # is kept as fields_one_step.  `total` = the evaluation as the timed window ran it.
         km["fields_one_step"] = km["fields"]
+        # the two GEMMs: their average launch duration INSIDE the timed window (HIP events on the library's stream around
+        # the forward and the backward GEMM of every evaluation, plm_ctx_solver_stats); time_kernels' figures -- the same
+        # launches in isolation, a host synchronisation between repetitions -- are kept as *_isolated
+        km["forward_isolated"], km["backward_isolated"] = km["forward"], km["backward"]
+        if solver.get("gemm_evaluations", 0) > 0:
+            km["forward"], km["backward"] = solver["forward_ms_per_evaluation"], solver["backward_ms_per_evaluation"]
+            km["gemm_evaluations_timed"] = solver["gemm_evaluations"]
         if solver["evaluations"] > 0:
             km["fields"] = solver["field_ms_per_evaluation"]
             km["total"] = km["expand"] + km["forward"] + km["fields"] + km["backward"] + km["assemble"]

@@ -16,7 +16,7 @@ PLM_OK = 0
 STATUS_CONVERGED, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_INTERRUPTED = 0, 1, 2, 3
 ABI_VERSION = 2
 K_EXPAND, K_FORWARD, K_BACKWARD, K_ASSEMBLE, K_TOTAL, K_REWEIGHT, K_FIELDS, K_FORWARD_ACCURATE, K_LBFGS_VECTOR, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-S_COUNT = 4
+S_COUNT = 7
 
 ITER_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                       C.c_double, C.c_double, C.c_void_p)

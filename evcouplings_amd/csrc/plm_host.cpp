@@ -292,9 +292,11 @@ struct plm_ctx {
     double vp_last_gh2 = 0;    // squared field-gradient norm when the current evaluation's chain was last looked at
     double vp_floor2 = 0;      // squared noise floor of the field gradient's f32 sums (set by plm_ctx_optimize)
     hipEvent_t vp_ev[2] = {nullptr, nullptr};   // around the field solver of the last enqueued evaluation
+    hipEvent_t gemm_ev[3] = {nullptr, nullptr, nullptr};   // in front of the forward GEMM / in front of / behind the backward GEMM
     bool vp_ev_pending = false;
     // statistics of the field solver since the last plm_ctx_optimize began (plm_ctx_solver_stats)
-    double stat_field_ms = 0, stat_passes = 0;
+    double stat_field_ms = 0, stat_passes = 0, stat_fwd_ms = 0, stat_bwd_ms = 0;
+    int stat_gemm_evals = 0;
     int stat_field_evals = 0, stat_chain_short = 0;
     int hist_m = 0;
     double *h_scal = nullptr;  // pinned host scalars
@@ -487,6 +489,7 @@ int vp_alloc(plm_ctx *c) {
     PLM_TRY(dalloc((char **)&c->vp_flag, sizeof(PlmVpState)));
     HIP_TRY(hipMemsetAsync(c->vp_flag, 0, sizeof(PlmVpState), c->st));
     for (auto &e : c->vp_ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : c->gemm_ev) HIP_TRY(hipEventCreate(&e));
     c->vp_hess_age = -1;
     return PLM_OK;
 }
@@ -511,6 +514,7 @@ int vp_stage1(plm_ctx *c) {
         HIP_TRY(plm_launch_maxabs(d, c->x, c->maxbits, c->jexp, c->st));
         HIP_TRY(plm_launch_expand(d, c->x, nullptr, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
     }
+    if (c->gemm_ev[0]) HIP_TRY(hipEventRecord(c->gemm_ev[0], c->st));
     HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->fwd_accurate, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
     return PLM_OK;
@@ -569,8 +573,10 @@ int vp_stage3(plm_ctx *c, bool conditional, float *gout = nullptr, int mode = 2)
     // conditional: the backward GEMM runs only if the chain in front of it is done (PlmVpState::done is the first int
     // of the state) -- otherwise the host continues the chain and enqueues stage 3 again.  Not when sharded: every rank
     // takes part in the gradient-halo exchange of every stage 3, and the ranks' chains end independently.
+    if (c->gemm_ev[1]) HIP_TRY(hipEventRecord(c->gemm_ev[1], c->st));
     if (d.nblk_own > 0 || !d.sharded)
         HIP_TRY(plm_launch_backward(d, c->msa_cm, c->Rt, c->G, (conditional && !d.sharded) ? c->vp_flag : nullptr, c->st));
+    if (c->gemm_ev[2]) HIP_TRY(hipEventRecord(c->gemm_ev[2], c->st));
     if (d.sharded) {
         HIP_TRY(plm_launch_pack_g(d, c->G, c->gsend, c->st));
         PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->gsend, c->ghalo, c->g_send.data(), c->g_recv.data()));
@@ -625,11 +631,20 @@ int ctx_eval_vp_finish(plm_ctx *c, double tol2, bool *again, double *gh2_out) {
     const double gh2 = c->h_scal[5];
     const int passes = (int)std::lround(c->h_scal[6] / nsh);
     const bool done = c->h_scal[7] > nsh - 0.5;
-    if (c->vp_ev_pending) {      // both events lie in front of the synchronisation the caller just made
+    if (c->vp_ev_pending) {      // the events lie in front of the synchronisation the caller just made
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->vp_ev[0], c->vp_ev[1]) == hipSuccess) {
             c->stat_field_ms += ms;
             if (c->vp_extra == 0) c->stat_field_evals++;
+        }
+        // the two GEMMs of this evaluation, as the fit ran them: only evaluations in the plain arithmetic whose chain was
+        // done at the first look (the conditional backward GEMM did its work; h64_init rides with the forward GEMM: 5 us)
+        float f = 0, b = 0;
+        if (done && c->vp_extra == 0 && !c->fwd_accurate && hipEventElapsedTime(&f, c->gemm_ev[0], c->vp_ev[0]) == hipSuccess &&
+            hipEventElapsedTime(&b, c->gemm_ev[1], c->gemm_ev[2]) == hipSuccess) {
+            c->stat_fwd_ms += f;
+            c->stat_bwd_ms += b;
+            c->stat_gemm_evals++;
         }
         c->vp_ev_pending = false;
     }
@@ -835,6 +850,8 @@ const char *plm_last_error(void) { return g_err.c_str(); }
 void plm_ctx_destroy(plm_ctx_t *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    for (auto &e : c->gemm_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto &e : c->vp_ev)
         if (e) (void)hipEventDestroy(e);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
@@ -1379,8 +1396,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     // L-BFGS then only sees the couplings (field part of g is zero, field part of s = the change of the optimal fields)
     const bool vp = vp_enabled(c);
     if (vp) PLM_TRY(vp_alloc(c));
-    c->stat_field_ms = c->stat_passes = 0;
-    c->stat_field_evals = c->stat_chain_short = 0;
+    c->stat_field_ms = c->stat_passes = c->stat_fwd_ms = c->stat_bwd_ms = 0;
+    c->stat_field_evals = c->stat_chain_short = c->stat_gemm_evals = 0;
     double gh2 = 0;                          // |grad_h|^2 left by the field solver at the current point
     // field-solver tolerance: a fraction of what the stop rule allows the whole gradient, and never below what the
     // solver can reach.  The fields themselves are iterated in f64 (k_hsolve); what is left is the random f32
@@ -1939,6 +1956,9 @@ int plm_ctx_solver_stats(plm_ctx_t *c, double *out) {
     out[PLM_S_FIELD_MS] = c->stat_field_ms;
     out[PLM_S_PASSES] = c->stat_passes;
     out[PLM_S_CHAIN_SHORT] = c->stat_chain_short;
+    out[PLM_S_GEMM_EVALS] = c->stat_gemm_evals;
+    out[PLM_S_FWD_MS] = c->stat_fwd_ms;
+    out[PLM_S_BWD_MS] = c->stat_bwd_ms;
     return PLM_OK;
 }
 

@@ -529,9 +529,11 @@ class PlmContext:
         """field-solver statistics of the last optimize() on this context (plm_ctx_solver_stats)"""
         out = np.zeros(_lib.S_COUNT, np.float64)
         check(self.lib.plm_ctx_solver_stats(self._h, _ptr(out)))
-        ev = max(1.0, out[0])
+        ev, gv = max(1.0, out[0]), max(1.0, out[4])
         return {"evaluations": int(out[0]), "field_ms_per_evaluation": out[1] / ev, "passes_per_evaluation": out[2] / ev,
-                "chains_continued_by_host": int(out[3])}
+                "chains_continued_by_host": int(out[3]),
+                # the two GEMMs as the fit ran them (HIP events inside the fit; plain arithmetic only)
+                "gemm_evaluations": int(out[4]), "forward_ms_per_evaluation": out[5] / gv, "backward_ms_per_evaluation": out[6] / gv}
 
     def time_kernels(self, reps=5):
         ms = np.zeros(_lib.K_COUNT, np.float32)

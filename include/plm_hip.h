@@ -335,7 +335,10 @@ int plm_ctx_time_kernels(plm_ctx_t *ctx, int32_t reps, float *out_ms /* [PLM_K_C
 #define PLM_S_FIELD_MS 1       /* total milliseconds between the forward GEMM and the backward GEMM of those evaluations */
 #define PLM_S_PASSES 2         /* passes over the stored potentials made by the solver's chains (the last, residual-only pass not counted) */
 #define PLM_S_CHAIN_SHORT 3    /* evaluations whose chain ran out of positions and had to be continued by the host */
-#define PLM_S_COUNT 4
+#define PLM_S_GEMM_EVALS 4     /* evaluations (plain arithmetic, chain done at the first look) whose two GEMMs were timed */
+#define PLM_S_FWD_MS 5         /* total milliseconds of their forward GEMMs (HIP events on the context's stream, inside the fit) */
+#define PLM_S_BWD_MS 6         /* total milliseconds of their backward GEMMs */
+#define PLM_S_COUNT 7
 int plm_ctx_solver_stats(plm_ctx_t *ctx, double *out /* [PLM_S_COUNT] */);
 
 /* -- host arithmetic exposed for tests (no device) ------------------------------------------ */
