@@ -137,6 +137,21 @@ def test_native_alignment_input_equals_the_python_twin(tmp_path, monkeypatch):
     assert isinstance(a, str) and a == b
 
 
+def test_family_like_generator_is_deterministic_and_has_the_advertised_shape(oracle64):
+    """synthetic.family_msa (the robustness alignments of tests/test_gpu_parity.py): same seed -> same matrix, states in
+    range, row 0 gap-free, a fifth or more of the cells gaps, and strongly clustered -- N_eff well below N at theta = 0.8."""
+    from evcouplings_amd.synthetic import family_msa
+    a, pa = family_msa(1500, 90, seed=11, depth=4, row_mut=(1.0, 15.0))
+    b, pb = family_msa(1500, 90, seed=11, depth=4, row_mut=(1.0, 15.0))
+    c, _ = family_msa(1500, 90, seed=12, depth=4, row_mut=(1.0, 15.0))
+    assert a.dtype == np.int8 and a.shape == (1500, 90) and np.array_equal(a, b) and pa == pb and not np.array_equal(a, c)
+    assert a.min() == 0 and a.max() <= 20 and (a[0] > 0).all()
+    assert 0.15 < (a == 0).mean() < 0.45
+    counts = oracle64.reweight(a, 0.8)
+    assert (1.0 / counts).sum() < 0.6 * a.shape[0] and counts.max() > 20
+    assert all(0 <= i < j < 90 and j - i >= 6 for i, j in pa)
+
+
 def test_synthetic_a2m_round_trip(tmp_path):
     msa, _ = synthetic_msa(50, 30, seed=3)
     path = msa_to_a2m(msa, str(tmp_path / "syn.a2m"), region_start=7)
