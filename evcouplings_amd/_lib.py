@@ -107,6 +107,7 @@ SYMBOLS = [
     ("plm_ctx_time_kernels", C.c_int, [_P, C.c_int32, _P]),
     ("plm_ctx_solver_stats", C.c_int, [_P, _P]),
     ("plm_rccl_probe", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int, _P]),
+    ("plm_rccl_probe_local", C.c_int, [C.c_int32, C.c_int, _P]),
     ("plm_lbfgs_coefficients", None, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]

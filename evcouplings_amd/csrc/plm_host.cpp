@@ -1035,21 +1035,31 @@ int plm_rccl_probe(const void *rccl_id, int32_t nranks, int32_t rank, int device
     if (!rccl_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(PLM_EINVAL, "bad communicator shape");
     PLM_TRY(check_device(device));
     hipStream_t st = (hipStream_t)stream;
-    PlmRccl *r = nullptr;
-    if (plm_rccl_init(rccl_id, nranks, rank, &r) != 0)
-        return fail(PLM_ECALLBACK, "RCCL communicator of %d ranks: %s", nranks, plm_rccl_error());
+    // Everything that can fail on this rank ALONE comes first: a rank that returned from here before the
+    // communicator call would leave its peers blocked inside ncclCommInitRank.  The host agrees on the outcome of
+    // plm_rccl_probe_local (the same steps) before any rank enters this function; here they can only fail again if the
+    // device was lost in between.
     const int per = 128;                                   // doubles per peer message
     double *buf = nullptr;
-    int rc = dalloc(&buf, (size_t)(2 * nranks + 1) * per);
+    PLM_TRY(dalloc(&buf, (size_t)(2 * nranks + 1) * per));
     std::vector<double> h((size_t)(2 * nranks + 1) * per, 0.0);
     for (int k = 0; k < nranks; k++)
         for (int j = 0; j < per; j++) h[(size_t)k * per + j] = 1000.0 * rank + k;          // message to rank k
     h[(size_t)2 * nranks * per] = 1.0 + rank;
     const std::vector<int64_t> counts((size_t)nranks, (int64_t)sizeof(double) * per);
     const int64_t one = sizeof(double);
-    if (rc == PLM_OK && hipMemcpyAsync(buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st) != hipSuccess)
-        rc = fail(PLM_EDEVICE, "upload failed");
-    if (rc == PLM_OK && plm_rccl_collective(r, PLM_COLL_ALLTOALL, buf, buf + (size_t)nranks * per, counts.data(), counts.data(), st) != 0)
+    if (hipMemcpyAsync(buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        hipFree(buf);
+        return fail(PLM_EDEVICE, "upload failed");
+    }
+    PlmRccl *r = nullptr;
+    if (plm_rccl_init(rccl_id, nranks, rank, &r) != 0) {
+        hipFree(buf);
+        return fail(PLM_ECALLBACK, "RCCL communicator of %d ranks: %s", nranks, plm_rccl_error());
+    }
+    int rc = PLM_OK;
+    if (plm_rccl_collective(r, PLM_COLL_ALLTOALL, buf, buf + (size_t)nranks * per, counts.data(), counts.data(), st) != 0)
         rc = fail(PLM_ECALLBACK, "all-to-all: %s", plm_rccl_error());
     if (rc == PLM_OK && plm_rccl_collective(r, PLM_COLL_ALLREDUCE_F64, buf + (size_t)2 * nranks * per, nullptr, &one, &one, st) != 0)
         rc = fail(PLM_ECALLBACK, "all-reduce: %s", plm_rccl_error());
@@ -1061,10 +1071,26 @@ int plm_rccl_probe(const void *rccl_id, int32_t nranks, int32_t rank, int device
         for (int k = 0; k < nranks && rc == PLM_OK; k++)
             if (h[(size_t)(nranks + k) * per] != 1000.0 * k + rank) rc = fail(PLM_ECALLBACK, "all-to-all delivered a wrong message from rank %d", k);
     }
-    if (buf) hipFree(buf);
     hipStreamSynchronize(st);
+    hipFree(buf);
     plm_rccl_destroy(r);
     return rc;
+}
+
+// The rank-local half of plm_rccl_probe -- device, RCCL library, buffer, upload -- with no communicator call in it: hosts
+// run it on every rank and agree on the verdicts BEFORE any rank enters plm_rccl_probe.
+int plm_rccl_probe_local(int32_t nranks, int device, void *stream) {
+    if (nranks < 1) return fail(PLM_EINVAL, "bad communicator shape");
+    PLM_TRY(check_device(device));
+    if (plm_rccl_version() < 20000) return fail(PLM_ECALLBACK, "librccl not loadable: %s", plm_rccl_error());
+    hipStream_t st = (hipStream_t)stream;
+    double *buf = nullptr;
+    PLM_TRY(dalloc(&buf, (size_t)(2 * nranks + 1) * 128));
+    std::vector<double> h((size_t)(2 * nranks + 1) * 128, 1.0);
+    const bool ok = hipMemcpyAsync(buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st) == hipSuccess &&
+                    hipStreamSynchronize(st) == hipSuccess;
+    hipFree(buf);
+    return ok ? PLM_OK : fail(PLM_EDEVICE, "upload failed");
 }
 
 int plm_ctx_set_options(plm_ctx_t *c, int32_t max_iter, double epsilon, int32_t lbfgs_m) {

@@ -84,7 +84,7 @@ __device__ __forceinline__ void barrier_raw() { asm volatile("s_barrier" ::: "me
 #if PLM_PROBE
 __device__ unsigned long long plm_probe_acc[2][8];
 #define PROBE_NOW() __builtin_readcyclecounter()
-extern "C" void plm_probe_read(unsigned long long *out, int reset) {
+extern "C" __attribute__((visibility("default"))) void plm_probe_read(unsigned long long *out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(plm_probe_acc), sizeof(unsigned long long) * 16);
     if (reset) {
         unsigned long long z[16] = {0};

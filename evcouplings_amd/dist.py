@@ -178,10 +178,12 @@ def share_rccl_id(group=None):
 
 
 def native_rccl_requested():
-    """Collectives issued by the library itself (RCCL on its own stream: no host round trip around any of them) are the
-    default transport of a multi-GPU job since round 5; PLM_NATIVE_RCCL=0 keeps the torch.distributed callbacks.  The
-    default is only taken after `negotiate_native_rccl` has seen it work on every rank."""
-    return os.environ.get("PLM_NATIVE_RCCL", "1") not in ("", "0")
+    """Collectives issued by the library itself (RCCL on its own stream: no host round trip around any of them) are
+    OPT-IN (PLM_NATIVE_RCCL=1, or transport="native"): no multi-GPU node was available in any round, so the grouped
+    send/recv all-to-all of plm_rccl.cpp has only ever run on a one-rank communicator.  The default
+    transport of an nccl group is torch.distributed's own collectives on the library's device buffers.  Even when
+    requested, the native transport is only taken after `negotiate_native_rccl` has seen it work on every rank."""
+    return os.environ.get("PLM_NATIVE_RCCL", "0") not in ("", "0")
 
 
 def negotiate_native_rccl(group=None, device=None):
@@ -204,9 +206,10 @@ def negotiate_native_rccl(group=None, device=None):
 
     why = ""
     try:
-        ok = plm.rccl_version() >= 20000
-        if not ok:
-            why = "librccl not loadable by libplm_hip"
+        # everything that can fail on one rank alone (device, librccl, buffer, upload) is settled BEFORE any rank
+        # enters a communicator call: a rank that dropped out there would leave its peers blocked in ncclCommInitRank
+        plm.rccl_probe_local(dist.get_world_size(group), device=device)
+        ok = True
     except Exception as exc:       # noqa: BLE001 -- any failure means "not here"
         ok, why = False, repr(exc)
     if not agree(ok):
@@ -234,8 +237,9 @@ def fit_distributed(msa, q=21, group=None, sharded_state=True, transport=None, *
     one all-gather of the gradient slabs per evaluation.
     transport "rccl": torch.distributed collectives on the library's device buffers (backend nccl); "native": the
     library issues the RCCL calls itself on its stream (torch.distributed only carries the communicator id); "host":
-    staged through host memory (backend gloo; sharded-state mode only).  Default on an nccl group: "native" when every
-    rank's probe communicator worked (`negotiate_native_rccl`; PLM_NATIVE_RCCL=0 opts out), else "rccl"; "host" on gloo.
+    staged through host memory (backend gloo; sharded-state mode only).  Default:
+    "rccl" on an nccl group ("native" is opt-in: PLM_NATIVE_RCCL=1, taken only when every rank's probe communicator
+    worked, `negotiate_native_rccl`); "host" on gloo.
     """
     import torch
     import torch.distributed as dist

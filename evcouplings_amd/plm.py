@@ -395,6 +395,11 @@ def rccl_probe(rccl_id, nranks, rank, device=0, stream=0):
     check(_lib.load().plm_rccl_probe(idbuf, int(nranks), int(rank), int(device), C.c_void_p(int(stream) or None)))
 
 
+def rccl_probe_local(nranks, device=0, stream=0):
+    """plm_rccl_probe_local: the steps of the probe that can fail on one rank alone (no communicator call)"""
+    check(_lib.load().plm_rccl_probe_local(int(nranks), int(device), C.c_void_p(int(stream) or None)))
+
+
 def rccl_selftest(device=0, stream=0):
     """every collective of the sharded-state mode on a one-rank communicator; raises on any failure"""
     check(_lib.load().plm_rccl_selftest(int(device), C.c_void_p(int(stream) or None)))

@@ -22,6 +22,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libplm_hip.so is built with -fvisibility=hidden: the declarations between this push and the pop at the end of the
+ * file are its whole dynamic symbol table (tests/test_abi.py compares `nm -D` with this header). */
+#pragma GCC visibility push(default)
 
 #define PLM_ABI_VERSION 2   /* 2: plm_iter_cb returns int (cancellation), PLM_STATUS_INTERRUPTED, lambda_group */
 
@@ -206,6 +209,10 @@ int plm_rccl_selftest(int device, void *stream);
  * the data, destroy it.  PLM_OK on this rank = the library-issued transport works here (dist.py negotiates the ranks'
  * verdicts and falls back to the callback transport if any of them failed). */
 int plm_rccl_probe(const void *rccl_id, int32_t nranks, int32_t rank, int device, void *stream);
+/* The rank-local half of the probe (device, librccl, buffer, upload) with no communicator call in it.  A rank that
+ * failed these steps inside plm_rccl_probe would leave its peers blocked in the communicator call: run this on every
+ * rank and agree on the verdicts first. */
+int plm_rccl_probe_local(int32_t nranks, int device, void *stream);
 int plm_fit_sharded_rccl(const plm_problem_t *problem, plm_result_t *result, int device, void *stream,
                          plm_iter_cb iter_cb, void *iter_user, const void *rccl_id);
 
@@ -349,6 +356,7 @@ int plm_ctx_solver_stats(plm_ctx_t *ctx, double *out /* [PLM_S_COUNT] */);
 void plm_lbfgs_coefficients(int m, int stored, int end, const double *SY, const double *YDY, const double *Sg,
                             const double *YDg, double gDg, double *cs, double *cy, double *cg, double *dg);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

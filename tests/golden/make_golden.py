@@ -11,6 +11,7 @@ What is pinned here, and by which reference code:
   * raw EC file reader        <- evcouplings/couplings/pairs.py:34-65
   * mean-field DCA            <- evcouplings/couplings/mean_field.py:717-1014 (regularisation, covariance,
                                  reshape, fields, direct_information) on frequencies of golden alignments
+  * raw EC file WRITER        <- notebooks/example/PABP_YEAST_ECs.txt, test_b0.6_ECs.txt (real plmc output, copied as data)
   * statistical energies      <- evcouplings/couplings/model.py:25-109 (_hamiltonians,
                                  _single_mutant_hamiltonians) and the CouplingsModel methods on top
 
@@ -251,6 +252,12 @@ def main():
         iu3 = np.triu_indices(Lm, 1)
         np.savez_compressed(os.path.join(HERE, "meanfield_%s.npz" % name), pseudo_count=pc, fi=fi_r,
                             fij_pairs=fij_r[iu3], rfi=rfi, cov=cov, jij_full=J4, hi=h_mf, di=di)
+    # ---- (9) the only REAL plmc artefacts the reference holds: two raw EC files (data, not source; their input
+    # alignments are not in the reference -- .MISSING_LARGE_BLOBS:1-2).  Kept as byte-exact pins of the a9 writer
+    # (pairs.py:55-58): non-contiguous numbering and negative scores in the second one.
+    import shutil
+    for fn in ("PABP_YEAST_ECs.txt", "test_b0.6_ECs.txt"):
+        shutil.copyfile(os.path.join(REF, "notebooks/example", fn), os.path.join(HERE, "plmc_real_" + fn))
     print("golden vectors written to", HERE)
 
 

@@ -31,6 +31,15 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert bound <= set(declared), "binding for undeclared symbol: %s" % (bound - set(declared))
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """a foreign host links against include/plm_hip.h and nothing else -- no C++ internals, no HIP
+    kernel handles (-fvisibility=hidden + csrc/plm_exports.map)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared_symbols(), (set(exported) ^ set(_declared_symbols()))
+
+
 def test_version_and_error_strings():
     lib = _lib.load()
     assert lib.plm_version() == _lib.ABI_VERSION == 2

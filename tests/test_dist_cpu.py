@@ -171,9 +171,10 @@ def test_rccl_id_travels_from_rank_zero_gloo():
 
 
 def test_native_rccl_switch(monkeypatch):
-    """the library-issued transport is the default of a multi-GPU job (round 5); PLM_NATIVE_RCCL=0 opts out"""
+    """the library-issued transport is opt-in (round 6, ADVICE r5: it has never run on more than one rank);
+    PLM_NATIVE_RCCL=1 asks for it, and it is still only taken after a successful probe on every rank"""
     monkeypatch.delenv("PLM_NATIVE_RCCL", raising=False)
-    assert pdist.native_rccl_requested()
+    assert not pdist.native_rccl_requested()
     monkeypatch.setenv("PLM_NATIVE_RCCL", "0")
     assert not pdist.native_rccl_requested()
     monkeypatch.setenv("PLM_NATIVE_RCCL", "1")

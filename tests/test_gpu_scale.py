@@ -54,7 +54,11 @@ GRAD_ERR = 8e-5
 # are the values measured in round 5 (gpurun_out/r5c1: 1.1e-4 / 3.6e-4 / 7.4e-4 / 2.5e-4 -- profiles/r04_error_anatomy.txt had
 # 4.5e-4 / 8.7e-4 / 3.4e-4 for the last three) + 30 %.  The second bound every
 # point has to meet is relative: not worse than the float32 CPU build (oracle32) at the same point.
-PLAIN_ERR = {"config2": 1.5e-4, "headline": 4.7e-4, "config3": 9.6e-4, "headline_g": 3.3e-4}
+# Configs 4 / 5 / 3-g (round 6): their plain evaluation is checked at the stop point inside
+# test_evaluation_matches_f64_oracle_at_scale, against the oracle values that test computes anyway.
+# The measured values of every configuration and point are committed as profiles/r06_error_table.txt.
+PLAIN_ERR = {"config2": 1.5e-4, "headline": 4.7e-4, "config3": 9.6e-4, "headline_g": 3.3e-4,
+             "config4": 9.9e-4, "config5": 7.0e-4, "config3_g": 7.0e-4}
 # the oracle's |g|/|x| at a point the fit reported converged at epsilon: the stop rule, up to the evaluation error
 COND_SLACK = 1.05
 
@@ -158,14 +162,14 @@ def _hip_eval(plm, f, x):
 
 
 @pytest.mark.parametrize("name", ["config2", "headline", "config3", "config4", "config5", "headline_g", "config3_g"])
-def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, oracle32, fits, name):
+def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, oracle32, fits, monkeypatch, name):
     f = fits(name)
     assert f["fit_1e-3"]["status"] == 0, f["fit_1e-3"]["status_msg"]          # converged by its own rule, everywhere
-    # far from the optimum: relative criteria (gradient entries are large).  Not at configs 4 / 5: their oracle evaluations
-    # cost 15-20 s of host cores each, the far point is held at five other shapes, and the GPU suite is kept near 8 minutes;
+    # far from the optimum: relative criteria (gradient entries are large).  Not at config 5: its oracle evaluation
+    # costs ~20 s of host cores, the far point is held at six other shapes (config 4, L = 500, among them);
     # the scale of the gradient entries comes from the GPU's own far-point gradient there.
     fx, nll, g = _hip_eval(plm, f, f["x_far"])
-    if name in ("config4", "config5"):
+    if name == "config5":
         gmax_far = np.abs(g).max()
     else:
         fxo, nllo, go = _oracle_cached(oracle64, f, "far")
@@ -192,6 +196,16 @@ def test_evaluation_matches_f64_oracle_at_scale(plm, oracle64, oracle32, fits, n
     # optimality as the ORACLE sees it: the stop rule, up to the evaluation error
     assert cond64 < COND_SLACK * 1e-3, cond64
     f["cond64_1e-3"] = cond64
+    if name not in FULL:
+        # the PLAIN kernels (what bench.py times) at the shapes test_plain_evaluation_... does not
+        # visit, against the oracle values already in hand: one more HIP evaluation, no oracle time
+        fxp, nllp, gp = _hip_eval_plain(plm, f, x, monkeypatch)
+        errp = np.linalg.norm(gp - go) / xn
+        print("%s (stop point): PLAIN evaluation |g_hip - g_f64|/|x| = %.3g (bound %.3g), |g_f32cpu - g_f64|/|x| = %.3g" % (
+            name, errp, PLAIN_ERR[name], err32))
+        assert abs(fxp - fxo) <= 2e-6 * abs(fxo) and abs(nllp - nllo) <= 2e-6 * abs(nllo)
+        assert errp <= err32, (errp, err32)
+        assert errp <= PLAIN_ERR[name], errp
 
 
 @pytest.mark.parametrize("name", ["config2", "headline", "config3", "headline_g"])
@@ -246,7 +260,7 @@ def test_fit_optimality_certificate(plm, oracle64, fits, name):
     assert cond64_tight < COND_SLACK * tight, cond64_tight
 
 
-@pytest.mark.parametrize("name,maxfun", [("config2", 25), ("headline", 10), ("config5", 4)])
+@pytest.mark.parametrize("name,maxfun", [("config2", 25), ("headline", 25), ("config5", 4)])
 def test_cn_within_1e4_of_an_independent_f64_optimiser(plm, oracle64, fits, name, maxfun):
     """BASELINE.json config 2: 'EC scores vs CPU plmc within 1e-4' (and the same at the headline and at config 5's two-chain
     shape, where an oracle evaluation costs ~20 s of host cores: 4 of them; 10 at the headline -- the whole GPU suite is
