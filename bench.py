@@ -17,7 +17,9 @@ gradient halo) and scalar all-reduces over RCCL (evcouplings_amd/dist.py, DESIGN
 Extra blocks on the same line:
   roofline      dominant kernel (HIP events inside the library, on the stream it launches on)
   cpu_baseline  the oracle's float32/OpenMP build timed on this host on a bounded sample
-  fit           wall-clock of whole fits: the reference's default 100 iterations, to |g|/|x| < 1e-3, and a short leg of
+  value_plmc_unit   joint L-BFGS iterations/s: plmc's own unit (value counts variable-projection iterations)
+  fit           (run_plmc_hip_default: A2M file -> run_plmc_hip, reference defaults -> _ECs.txt + .model, wall-clock split)
+                wall-clock of whole fits: the reference's default 100 iterations, to |g|/|x| < 1e-3, and a short leg of
                 the joint L-BFGS path (plmc's algorithm) whose iterations/s shares its unit with cpu_baseline.value
 """
 import argparse
@@ -36,6 +38,36 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
 PEAK_I8_MFMA_TOPS = 5000.0        # dense int8, 2 x the f16 rate (MI355X_MICROARCH.md)
 PEAK_F32_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+VALU_CLK_PER_WAVE_INSTR = 4.3     # measured, scripts/ubench/valu_rate.hip -> profiles/r05_valu_rate_ubench.txt
+
+
+def reweight_executed_fraction(msa, theta, n_waves=24, n_partners=1500, seed=7):
+    """Share of the 32-site half chunks k_reweight_reg really compares: a wave of 64 consecutive
+    sequences walks a partner row in 32-site steps and leaves it once ALL 64 running mismatch counts are past the
+    allowed L - T (padding sites of the last half chunk always match).  Host emulation of that rule on a random sample
+    of (wave, later partner) pairs of this alignment -- measurement bookkeeping only, the counts come from the kernel."""
+    N, L = msa.shape
+    T = int(np.ceil(theta * L - 1e-9))
+    allowed = L - T
+    nh = (L + 31) // 32
+    rng = np.random.default_rng(seed)
+    done, total = 0, 0
+    for w0 in rng.choice(max(1, N // 64 - 1), size=min(n_waves, max(1, N // 64 - 1)), replace=False):
+        rows = msa[w0 * 64:(w0 + 1) * 64]                                  # (64, L)
+        lo = w0 * 64 + 1                                                   # the kernel compares partners t > s only
+        if lo >= N:
+            continue
+        ts = rng.integers(lo, N, size=min(n_partners, N - lo))
+        mism = (rows[None, :, :] != msa[ts][:, None, :])                   # (P, 64, L)
+        pad = nh * 32 - L
+        if pad:
+            mism = np.concatenate([mism, np.zeros(mism.shape[:2] + (pad,), bool)], axis=2)
+        run = mism.reshape(len(ts), 64, nh, 32).sum(3).cumsum(2)          # running counts after each half chunk
+        far = (run > allowed).all(1)                                       # (P, nh): every lane past the limit
+        first = np.where(far.any(1), far.argmax(1) + 1, nh)                # half chunks executed before the exit
+        done += int(first.sum())
+        total += len(ts) * nh
+    return done / max(1, total)
 
 
 def usable_cores():
@@ -348,10 +380,24 @@ def main():
                                                     "traffic x launches per evaluation (committed profiles/, not "
                                                     "re-collected); ratio to eval_hbm_alg_bytes = wasted re-reads")
         pairs = float(N) * (N - 1) / 2
+        exe = reweight_executed_fraction(msa, 0.8)
+        # three VALU instructions (v_xad_u32, v_and_b32, v_bcnt_u32_b32) per dword of 4 sites, 64 sequences per
+        # wave-instruction, rows padded to 32-site half chunks; measured issue rate of exactly this triple with every
+        # operand in registers: 4.3 clocks per wave-instruction per SIMD (profiles/r05_valu_rate_ubench.txt), 2.4 GHz
+        instr_full = pairs * (((L + 31) // 32) * 8) * 3 / 64
+        floor_full = instr_full * VALU_CLK_PER_WAVE_INSTR / (256 * 4 * 2.4e9) * 1e3
         out["roofline"]["reweight"] = {
             "ms": km["reweight"], "byte_compares_per_s": pairs * L / (km["reweight"] * 1e-3),
-            "valu_floor_ms": pairs * (((L + 31) // 32) * 8) * 3 / 64 / (256 * 4 * 2.4e9 / 2) * 1e3,
-            "note": "symmetric: N(N-1)/2 sequence pairs; floor = 3 VALU per 4 sites at 1 wave-instr / 2 clk / SIMD"}
+            "executed_fraction": exe,
+            "executed_byte_compares_per_s": exe * pairs * ((L + 31) // 32 * 32) / (km["reweight"] * 1e-3),
+            "valu_floor_ms_full_rows": floor_full,
+            "valu_floor_ms": exe * floor_full,
+            "frac_of_valu_floor": exe * floor_full / km["reweight"],
+            "note": "symmetric: N(N-1)/2 sequence pairs.  The kernel leaves a partner row once all 64 sequences of a wave "
+                    "are past the allowed mismatches (looked at every 32 sites): executed_fraction = share of the 32-site "
+                    "half chunks it really compares, from a host emulation of that rule on a sample of (wave, partner) "
+                    "pairs of THIS alignment.  Floor = executed instructions at the MEASURED 4.3 clocks per "
+                    "wave-instruction per SIMD (not the 2 clocks earlier rounds assumed)"}
         # --- whole fit: (a) the reference's default 100 iterations, (b) to |g|/|x| < 1e-3 -------------------
         if not args.no_fit:
             t1 = time.perf_counter()
@@ -389,6 +435,10 @@ def main():
                             "~20 of these"}
                 # the plmc-comparable rate next to the headline value, so the record carries both
                 out["joint_lbfgs_iterations_per_s"] = out["fit"]["joint_lbfgs"]["iterations_per_s"]
+                # `value` counts variable-projection iterations (one is worth ~20 of plmc's); THIS is the figure in plmc's
+                # own unit -- joint L-BFGS iterations per second -- and the only one to read beside cpu_baseline.value
+                out["value_plmc_unit"] = out["fit"]["joint_lbfgs"]["iterations_per_s"]
+                out["value_plmc_unit_note"] = "joint L-BFGS iterations/s (PLM_FLAG_JOINT_LBFGS, plmc's algorithm); same unit as cpu_baseline.value"
         # --- the reference's DEFAULT mode: plmc -g / ignore_gaps (config/sample_config_monomer.txt:155), 20 model
         # states, lambda_J scaled with q - 1 = 19 (couplings/protocol.py:159-165): kernel times and the fit to epsilon
         if not args.no_fit:
@@ -410,6 +460,35 @@ def main():
                 "note": "plmc -g semantics of DESIGN.md 2b on the headline alignment (the path every default pipeline run "
                         "takes): the 21-state kernel instantiations with the gap state masked out of every softmax and "
                         "structurally zero in parameters and gradient; 20 useful states per site"}
+        # --- the boundary itself, as a pipeline user calls it: A2M FILE -> run_plmc_hip with the reference's default
+        # settings (ignore_gaps: True, iterations: 100; config/sample_config_monomer.txt:149-155) -> _ECs.txt + .model
+        if not args.no_fit:
+            import shutil
+            import tempfile
+            from evcouplings_amd import tools
+            from evcouplings_amd.synthetic import msa_to_a2m
+            tmp = tempfile.mkdtemp(prefix="plm_bench_")
+            try:
+                ali = msa_to_a2m(msa, os.path.join(tmp, "headline.a2m"))
+                ec_file, model_file = os.path.join(tmp, "headline_ECs.txt"), os.path.join(tmp, "headline.model")
+                t1 = time.perf_counter()
+                r, raw, _ = tools.infer_to_files(ali, ec_file, model_file, focus_seq="SYN/1-%d" % L, theta=0.8,
+                                                 ignore_gaps=True, iterations=100, lambda_h=0.01,
+                                                 lambda_J=plm.default_lambda_j(L, q - 1))
+                wall = time.perf_counter() - t1
+                sec = raw["seconds"]
+                out["fit"]["run_plmc_hip_default"] = {
+                    "seconds_wall": wall, "seconds_read_alignment": sec["read_alignment"],
+                    "seconds_library": sec["library"], "seconds_optimize": sec["optimize"],
+                    "seconds_write_files": sec["write_files"], "iterations": int(raw["iters"]),
+                    "status": r.optimization_status, "alignment_bytes": os.path.getsize(ali),
+                    "model_bytes": os.path.getsize(model_file), "ec_lines": sum(1 for _ in open(ec_file)),
+                    "note": "evcouplings_amd.tools.run_plmc_hip's body (infer_to_files) on the headline alignment written "
+                            "as an A2M file: reference defaults ignore_gaps=True, iterations=100, lambda_J = 0.01 (q-1)(L-1); "
+                            "wall-clock from the file path going in to _ECs.txt + plmc_v2 .model on disk (tmpfs or disk "
+                            "of this box), PCIe and file I/O included"}
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
         # --- CPU baseline: oracle f32 + OpenMP on a bounded sample --------------------------
         if not args.no_cpu:
             # one OpenMP thread per usable core (the box shows 256 CPUs but runs under a 16-core quota)

@@ -657,7 +657,7 @@ int ctx_eval_vp_finish(plm_ctx *c, double tol2, bool *again, double *gh2_out) {
         if (hipMemcpy(&S, c->vp_flag, sizeof S, hipMemcpyDeviceToHost) == hipSuccess)
             for (int k = 0; k < std::min(S.passes, PLM_VP_HIST); k++) {
                 const double open_sites = std::floor(S.hist[k] / 1e9);
-                fprintf(stderr, " %.2e/%d", std::sqrt(S.hist[k] - open_sites * 1e9), (int)open_sites);
+                fprintf(stderr, " %.2e/%d/%d", std::sqrt(S.hist[k] - open_sites * 1e9), (int)open_sites, S.hist_loud[k]);
             }
         fprintf(stderr, "\n");
     }

@@ -188,6 +188,7 @@ struct PlmVpState {
     double g2_prev;   // squared gradient norm of the previous pass (contraction estimate)
     double g2_prev2;  // ... and of the pass before it (stall detection over two passes)
     double hist[PLM_VP_HIST];   // squared gradient norm and open sites (x 1e-6 in the fraction... see k_vp_check) per pass: PLM_DEBUG_VP
+    int hist_loud[PLM_VP_HIST]; // 16-site blocks with a site above tol2 / (8 n) after the pass: PLM_DEBUG_VP
 };
 #define PLM_VP_ALWAYS 0     // unconditional launch
 #define PLM_VP_PASS 1       // chain pass in its statistics role: runs while !done && !want_rt

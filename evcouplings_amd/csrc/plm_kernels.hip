@@ -2043,10 +2043,18 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
     if (S && S->done) return;
     double s = 0;
     int open_sites = 0;
+    __shared__ int loud_blocks;
+    if (threadIdx.x == 0) loud_blocks = 0;
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
         const double v = g2_site[i];
         s += v;
         open_sites += (v > tol_site2) ? 1 : 0;
+    }
+    for (int b = threadIdx.x; b < n / 16; b += 256) {      // debug trace only
+        bool loud = false;
+        for (int k = 0; k < 16; k++) loud |= g2_site[b * 16 + k] > tol2 / (8.0 * n);
+        if (loud) atomicAdd(&loud_blocks, 1);
     }
     for (int o = 32; o > 0; o >>= 1) open_sites += __shfl_down(open_sites, o, 64);
     if ((threadIdx.x & 63) == 0) bad[threadIdx.x >> 6] = open_sites;
@@ -2069,6 +2077,7 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
         const bool stall1 = S->passes >= 1 && t > 0.25 * S->g2_prev, stall2 = S->passes >= 2 && t > 0.25 * S->g2_prev2;
         const bool at_floor = (stall1 && t <= floor2) || (near_tol && stall2);
         const bool done = open_total == 0 || !(t > tol2) || at_floor || t != t;
+        if (S->passes < PLM_VP_HIST) S->hist_loud[S->passes] = loud_blocks;
         if (S->passes < PLM_VP_HIST) S->hist[S->passes] = t + 1e-30 * 0 + (double)open_total * 1e9;   // debug trace: norm^2 (+ open sites * 1e9)
         S->passes += 1;
         g2_out[1] = (double)S->passes;    // passes this chain needed (the host resets the state per evaluation)

@@ -152,18 +152,22 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
     except Exception as exc:       # library missing / no device: the same error type every other solver failure has
         raise ExternalToolError("HIP PLM solver failed: {}".format(exc))
 
+    import time
+    t_read = time.perf_counter()
     try:
         enc = alignment_io.encode_alignment(alignment, focus_seq=focus_seq, alphabet=alphabet)
     except alignment_io.AlignmentFormatError as exc:
         raise ExternalToolError("Could not read alignment {}: {}".format(alignment, exc))
     q = len(enc.alphabet)
     N, L = enc.msa.shape
+    t_read = time.perf_counter() - t_read
 
     fit_kwargs = dict(q=q, ignore_gaps=bool(ignore_gaps), theta_id=theta, scale=scale, lambda_h=lambda_h, lambda_j=lambda_J,
                       max_iter=iterations, epsilon=DEFAULTS["epsilon"] if epsilon is None else float(epsilon),
                       lbfgs_m=lbfgs_m, callback=callback, joint=(solver == "joint"), lambda_group=lambda_g,
                       # PLM_CONV_* switches: explicit, or the environment variable PLM_HIP_CONVENTIONS
                       conventions=plm.conventions_from_env(conventions))
+    t_lib = time.perf_counter()
     try:
         if distributed:
             res = _dist.fit_distributed(enc.msa, **fit_kwargs)
@@ -181,6 +185,8 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
     except Exception as exc:   # PlmError, ImportError (library missing), ...
         raise ExternalToolError("HIP PLM solver failed: {}".format(exc))
 
+    t_lib = time.perf_counter() - t_lib
+    t_write = time.perf_counter()
     # weights in original sequence order; invalid sequences get weight 0 (App. A field 4)
     weights = np.zeros(enc.n_total_seqs, dtype=np.float32)
     weights[enc.valid] = res["weights"]
@@ -202,6 +208,8 @@ def infer_to_files(alignment, couplings_file, param_file=None, focus_seq=None, a
     if param_file and not _valid_file(param_file):
         raise ResourceError("HIP PLM solver returned no parameter file: file={}".format(param_file))
 
+    # where the wall-clock of this call went (bench.py's run_plmc_hip_default leg reports it)
+    res.setdefault("seconds", {}).update(read_alignment=t_read, library=t_lib, write_files=time.perf_counter() - t_write)
     focus_name = focus_seq.split("/")[0] if focus_seq is not None else None
     log = format_plmc_log(focus_name, enc.focus_index, enc.n_valid_seqs, enc.n_total_seqs, L,
                           enc.n_total_sites, enc.region_start, res["n_eff"], res["status_msg"], res["table"],

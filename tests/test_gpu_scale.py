@@ -51,14 +51,15 @@ GRAD_ERR = 8e-5
 # The PLAIN evaluation -- k_fwd_w (f16 hi + lo operand planes, f32 accumulation) + __expf softmax + three residual digit
 # planes on k_bwd_w: what a fit runs until its last iterations and what bench.py times -- against the f64 oracle at the
 # same stop points.  Its error is coherent across sequences and grows as ~3e-11 N L |x|; the bounds
-# are the values measured in round 5 (gpurun_out/r5c1: 1.1e-4 / 3.6e-4 / 7.4e-4 / 2.5e-4 -- profiles/r04_error_anatomy.txt had
-# 4.5e-4 / 8.7e-4 / 3.4e-4 for the last three) + 30 %.  The second bound every
+# are the values measured on the MI355X (profiles/r06_error_table.txt: 1.1e-4 / 3.5e-4 / 6.6e-4 / 2.5e-4 at the stop points,
+# 1.2e-4 / 3.9e-4 / 8.6e-4 / 2.5e-4 far from the optimum; configs 4 / 5 / 3-g: 5.5e-4 / 4.5e-4 / 5.5e-4) + 30 % (config 3:
+# + 12 % over its far point).  The second bound every
 # point has to meet is relative: not worse than the float32 CPU build (oracle32) at the same point.
 # Configs 4 / 5 / 3-g (round 6): their plain evaluation is checked at the stop point inside
 # test_evaluation_matches_f64_oracle_at_scale, against the oracle values that test computes anyway.
 # The measured values of every configuration and point are committed as profiles/r06_error_table.txt.
 PLAIN_ERR = {"config2": 1.5e-4, "headline": 4.7e-4, "config3": 9.6e-4, "headline_g": 3.3e-4,
-             "config4": 9.9e-4, "config5": 7.0e-4, "config3_g": 7.0e-4}
+             "config4": 7.1e-4, "config5": 5.9e-4, "config3_g": 7.1e-4}
 # the oracle's |g|/|x| at a point the fit reported converged at epsilon: the stop rule, up to the evaluation error
 COND_SLACK = 1.05
 
