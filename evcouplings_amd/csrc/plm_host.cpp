@@ -97,6 +97,7 @@ PlmOptions plm_options_from_env() {
     if (const char *e = getenv("PLM_FWD_ACCURATE")) o.fwd_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("PLM_VP_FLOOR")) o.vp_floor = atof(e);
     if (const char *e = getenv("PLM_VP_REL")) o.vp_rel = atof(e);
+    if (const char *e = getenv("PLM_VP_HESS_POS")) o.vp_hess_pos = atoi(e);
     if (const char *e = getenv("PLM_ACC_FACTOR")) o.acc_factor = atof(e);
     o.debug = getenv("PLM_DEBUG") != nullptr;
     o.debug_vp = getenv("PLM_DEBUG_VP") != nullptr;
@@ -279,7 +280,7 @@ struct plm_ctx {
     float *dinv = nullptr;     // H0 diagonal of the preconditioned L-BFGS (n_local floats), built by plm_ctx_optimize
     // variable-projection fit: coupling part of the conditionals, Newton statistics, per-site gradient norms
     float *hj = nullptr, *hpart = nullptr;
-    double *gpart = nullptr;
+    double *gpart = nullptr, *dpart = nullptr;
     double *hg2 = nullptr, *hinv = nullptr, *h64 = nullptr;   // h64: the field solver's f64 copies of the fields (two buffers)
     double *hcnt = nullptr;    // [local site][Q] weighted state counts (plm_launch_site_counts), refreshed with the weights
     bool hcnt_valid = false;
@@ -399,7 +400,7 @@ int forward_at_x(plm_ctx *c) {
     PLM_TRY(vp_alloc(c));
     HIP_TRY(plm_launch_forward_store(d, c->msa_rm, c->Bt, c->jexp, c->hj, c->fwd_accurate, c->st));
     HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr, PLM_VP_ALWAYS, c->st));
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr, nullptr, PLM_VP_ALWAYS, c->st));
     return PLM_OK;
 }
 
@@ -481,6 +482,7 @@ int vp_alloc(plm_ctx *c) {
     PLM_TRY(dalloc((char **)&c->hj, plm_hj_bytes(c->d)));
     PLM_TRY(dalloc((char **)&c->hpart, plm_hpart_bytes(c->d)));
     PLM_TRY(dalloc((char **)&c->gpart, plm_gpart_bytes(c->d)));
+    PLM_TRY(dalloc((char **)&c->dpart, plm_gpart_bytes(c->d)));      // diagonal second-order sums: same shape
     PLM_TRY(dalloc(&c->hg2, nsites));
     PLM_TRY(dalloc(&c->hinv, nsites * c->d.Q * c->d.Q));
     PLM_TRY(dalloc(&c->h64, 2 * plm_h64_stride(c->d)));
@@ -527,14 +529,14 @@ int vp_step_and_residuals(plm_ctx *c, bool refresh) {
     PLM_TRY(vp_counts(c));
     const int full = (refresh || c->vp_hess_age < 0) ? 1 : 0;
     HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, full ? 2 : 1, c->fwd_accurate, nullptr, nullptr, c->hpart,
-                             c->gpart, nullptr, PLM_VP_ALWAYS, c->st));
+                             c->gpart, c->dpart, nullptr, PLM_VP_ALWAYS, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, full, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5, 0.0,
-                              0.0, nullptr, 0, c->hcnt, c->st));
+                              0.0, nullptr, 0, c->hcnt, c->dpart, c->st));
     if (full) c->vp_hess_age = 0;
     HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
-                             nullptr, PLM_VP_ALWAYS, c->st));
+                             nullptr, nullptr, PLM_VP_ALWAYS, c->st));
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
-                              0.0, nullptr, 0, c->hcnt, c->st));
+                              0.0, nullptr, 0, c->hcnt, c->dpart, c->st));
     return PLM_OK;
 }
 // stage 2: the field solver as ONE chain of launches (round 5; rounds 2-4 ran it in rounds with a host round trip
@@ -555,11 +557,11 @@ int vp_chain(plm_ctx *c, int npos, int hess_upto, int expected_last, double tol2
         // inverse exists yet, and at every position past the expected end (the cached inverses were not good enough)
         const bool hess = pos < hess_upto || pos > expected_last || c->vp_hess_age < 0;
         HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, hess ? 2 : 1, c->fwd_accurate, nullptr, nullptr, c->hpart,
-                                 c->gpart, c->vp_flag, PLM_VP_PASS, c->st));
+                                 c->gpart, c->dpart, c->vp_flag, PLM_VP_PASS, c->st));
         HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
-                                 c->vp_flag, PLM_VP_PASS_RT, c->st));
+                                 nullptr, c->vp_flag, PLM_VP_PASS_RT, c->st));
         HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, hess ? 2 : 0, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2,
-                                  c->scal + 5, tol2, c->vp_floor2, c->vp_flag, 1, c->hcnt, c->st));
+                                  c->scal + 5, tol2, c->vp_floor2, c->vp_flag, 1, c->hcnt, c->dpart, c->st));
         if (hess) c->vp_hess_age = 0;
     }
     return PLM_OK;
@@ -610,10 +612,11 @@ int ctx_eval_vp_enqueue(plm_ctx *c, double tol2) {
     if (c->vp_hess_age >= 0) c->vp_hess_age++;
     // fresh Hessian sums at every position before the expected last one (measured, gpurun_out/r5c9: Hessians at the
     // first position only -> 9.8 passes per evaluation in the bench window instead of 4.6, at the first two -> 5.9)
-    const int hess_upto = c_prev >= 2 ? c_prev : ((c->vp_hess_age < 0 || c->vp_hess_age >= 32) ? 1 : 0);
+    int hess_upto = c_prev >= 2 ? c_prev : ((c->vp_hess_age < 0 || c->vp_hess_age >= 32) ? 1 : 0);
+    if (c->opt.vp_hess_pos >= 0) hess_upto = std::min(hess_upto, std::max(c->opt.vp_hess_pos, c->vp_hess_age < 0 ? 1 : 0));
     PLM_TRY(vp_chain(c, std::min(14, c_prev + 3), hess_upto, c_prev, tol2));
     HIP_TRY(plm_launch_fields_to_x(d, c->h64, c->vp_flag, c->x, c->st));
-    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr,
+    HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr, nullptr,
                              c->vp_flag, PLM_VP_FINAL, c->st));
     HIP_TRY(hipEventRecord(c->vp_ev[1], c->st));
     c->vp_ev_pending = true;
@@ -686,11 +689,11 @@ int ctx_eval_vp_finish(plm_ctx *c, double tol2, bool *again, double *gh2_out) {
     if (gh2 > tol2) PLM_TRY(vp_chain(c, 6, 1 << 30, -1, tol2));
     HIP_TRY(plm_launch_fields_to_x(d, c->h64, c->vp_flag, c->x, c->st));
     HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, c->fwd_accurate, c->Rt, c->fx_part, c->hpart, c->gpart,
-                             c->vp_flag, PLM_VP_ALWAYS, c->st));
+                             nullptr, c->vp_flag, PLM_VP_ALWAYS, c->st));
     // norm only (update = 0, not a chain position: k_vp_check writes the sum alone -- passes / verdict of the continued
     // chain stay), at the chain's current fields
     HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5, 0.0,
-                              0.0, c->vp_flag, 0, c->hcnt, c->st));
+                              0.0, c->vp_flag, 0, c->hcnt, c->dpart, c->st));
     HIP_TRY(hipEventRecord(c->vp_ev[1], c->st));
     c->vp_ev_pending = true;
     PLM_TRY(vp_stage3(c, false));
@@ -856,7 +859,7 @@ void plm_ctx_destroy(plm_ctx_t *c) {
         if (e) (void)hipEventDestroy(e);
     void *bufs[] = {c->msa_rm, c->msa_cm, c->w, c->counts, c->Bt, c->Rt, c->G, c->gather, c->fx_part, c->reg_part,
                     c->dot_scratch, c->scal, c->maxbits, c->jexp, c->x, c->g, c->xp, c->gp, c->dir, c->hist,
-                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->hg2, c->hinv, c->h64, c->hcnt, c->vp_flag,
+                    c->canon, c->xhalo, c->ghalo, c->xsend, c->gsend, c->dinv, c->hj, c->hpart, c->gpart, c->dpart, c->hg2, c->hinv, c->h64, c->hcnt, c->vp_flag,
                     c->xa, c->ga, c->pair_n2};
     for (void *b : bufs)
         if (b) hipFree(b);
@@ -1509,7 +1512,7 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     auto shipped_cond = [&](double *out) -> int {
         HIP_TRY(plm_launch_h64_init(d, c->x, c->h64, c->st));
         HIP_TRY(plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 0, c->fwd_accurate, c->Rt, c->fx_part, nullptr, nullptr,
-                                 nullptr, PLM_VP_ALWAYS, c->st));
+                                 nullptr, nullptr, PLM_VP_ALWAYS, c->st));
         PLM_TRY(vp_stage3(c, false, c->dir, 0));
         const float *a[1] = {c->dir};
         PLM_TRY(dots(c, 1, a, a, n, SL_DG));

@@ -119,6 +119,7 @@ struct PlmOptions {
     int fwd_mode = -1;      // PLM_FWD_ACCURATE = 0 | 1: force the plain / the exact forward GEMM (-1: the solver decides)
     double acc_factor = 8.0;   // PLM_ACC_FACTOR: the fit switches to the accurate evaluation below max(3 eps, this x 3e-11 N L)
     double vp_rel = 1e-4;   // PLM_VP_REL: field-solver tolerance relative to the reduced gradient of the last accepted point
+    int vp_hess_pos = -1;   // PLM_VP_HESS_POS: chain positions that take fresh Hessian sums at most (-1: every one before the expected last)
     double vp_floor = 2e-7; // PLM_VP_FLOOR: noise floor of the field solver's tolerance (scripts/vp_floor_probe.py)
     bool debug = false;     // PLM_DEBUG: line-search failures are traced to stderr
     bool debug_vp = false;  // PLM_DEBUG_VP: every round of the field solver is traced to stderr
@@ -171,12 +172,13 @@ int plm_fwd_groups(int q, int exact);
 // exact: the passes of an accurate evaluation (exact-argument exponentials, see exp_softmax)
 hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w,
                             const double *h64, int write_rt, int stats, int exact, void *Rt, double *fx_part, float *hpart,
-                            double *gpart, const int *state, int cond, hipStream_t st);
+                            double *gpart, double *dpart, const int *state, int cond, hipStream_t st);
 // The field solver of one evaluation is ONE chain of launches without host round trips: per chain
 // position a statistics pass over the stored potentials OR (when the chain predicts that this pass is the last) a pass
 // that also writes the residual planes, then the per-site Newton step, then k_vp_check.  The state lives in HBM; every
 // launch of the chain looks at it first and returns at once when its role is not wanted.
 #define PLM_VP_HIST 24
+#define PLM_VP_MAXBLK 256   // local 16-site blocks the quiet flags cover (more: no block is ever quiet)
 struct PlmVpState {
     int done;         // every site is within its share of the tolerance: the rest of the chain does nothing
     int want_rt;      // the next pass is predicted to be the last: it runs in its residual-writing role
@@ -188,7 +190,14 @@ struct PlmVpState {
     double g2_prev;   // squared gradient norm of the previous pass (contraction estimate)
     double g2_prev2;  // ... and of the pass before it (stall detection over two passes)
     double hist[PLM_VP_HIST];   // squared gradient norm and open sites (x 1e-6 in the fraction... see k_vp_check) per pass: PLM_DEBUG_VP
-    int hist_loud[PLM_VP_HIST]; // 16-site blocks with a site above tol2 / (8 n) after the pass: PLM_DEBUG_VP
+    int hist_loud[PLM_VP_HIST]; // 16-site blocks still active (not quiet) after the pass: PLM_DEBUG_VP
+    // Quiet blocks (round 6): a 16-site block whose squared field-gradient norm is within its share of a quarter of the
+    // tolerance stops moving for the rest of the chain -- its gradient is then a constant (fixed potentials, fixed
+    // fields), so the statistics passes that follow skip it (k_hpass workgroups of the block return at once, k_hsolve
+    // keeps its norm and copies its fields).  Passes in the residual-writing role and the final residual pass cover every
+    // block.  The late passes of a chain work for a handful of slowly converging sites: PLM_DEBUG_VP traces of the
+    // headline fit show 19, 19, 19, 10, 2 active blocks over the five passes of a typical evaluation.
+    unsigned char quiet[PLM_VP_MAXBLK];
 };
 #define PLM_VP_ALWAYS 0     // unconditional launch
 #define PLM_VP_PASS 1       // chain pass in its statistics role: runs while !done && !want_rt
@@ -217,7 +226,7 @@ hipError_t plm_launch_h64_init(const PlmDims &d, const float *x, double *h64, hi
 // current), x is left alone (plm_launch_fields_to_x after the chain); chain = 0: in place.
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
-                             double floor2, int *state, int chain, const double *cnt, hipStream_t st);
+                             double floor2, int *state, int chain, const double *cnt, const double *dpart, hipStream_t st);
 // cnt[local site][Q] = sum_s w_s [x_si = a] (f64, fixed order): the constant part of the exact first-order sums k_hsolve
 // rescales the sampled Hessian with (cnt = NULL: the sampled row sums, rounds 2-4)
 hipError_t plm_launch_site_counts(const PlmDims &d, const int8_t *msa_cm, const float *w, double *cnt, hipStream_t st);

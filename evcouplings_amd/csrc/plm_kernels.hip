@@ -1412,7 +1412,9 @@ size_t plm_hj_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d
 // of the solver's forward epilogue.  k_hsolve takes one Newton step per site: H = diag(rowsum M) - M + 2 lambda_h I.
 // =========================================================================================
 #define PLM_HSTATS(Q) ((Q) + (Q) * ((Q) + 1) / 2)
-#define PLM_HESS_SAMPLE 16
+#ifndef PLM_HESS_SAMPLE
+#define PLM_HESS_SAMPLE 32    // measured round 6 (with the exact diagonal): 8 / 16 / 32 / 64 / 128 -> 95.7 / 96.9 / 100.5 / 99.5 / 99.2 it/s in the bench window
+#endif
 #ifndef PLM_NEWTON_CAP
 #define PLM_NEWTON_CAP 3.0   // largest change of a field in one Newton step
 #endif
@@ -1466,6 +1468,7 @@ struct HpassArgs {
     float *hpart;         // [workgroup][16 sites][NH]  Hessian sums, NH = Q (Q + 1) / 2 (STATS == 2 only)
     double *gpart;        // [workgroup][16 sites][Q]   gradient sums, f64: their f32 accumulation was the noise floor
     float rscale;         //                            of the field solver (|g_h| ~ 1e-2 at N = 50 000)
+    double *dpart;        // [workgroup][16 sites][Q]   diagonal second-order sums sum_s w P_a^2 (STATS == 2: the tiles without Hessian sums)
     const int *state;     // chain state of the field solver (PlmVpState, may be NULL) and which role this launch has in
     int cond;             // the chain (PLM_VP_*): a launch whose role is not wanted returns at once
     int sel;              // sequence tiles of this launch: 0 all, 1 the Hessian-sampled ones, 2 all the others
@@ -1478,7 +1481,12 @@ __device__ __forceinline__ bool vp_runs(const int *state, int cond) {
     if (S->done) return false;
     return cond == PLM_VP_PASS_RT ? S->want_rt != 0 : S->want_rt == 0;
 }
-template <int Q, bool WRITE_RT, int STATS, bool XACT>   // STATS: 0 none, 1 gradient sums, 2 gradient + Hessian sums; XACT: exact softmax arguments
+// STATS: 0 none, 1 gradient sums, 2 a Hessian position of the chain: gradient sums everywhere, Hessian sums sum_s w P P^T on
+// every PLM_HESS_SAMPLE-th sequence tile and the DIAGONAL second-order sums sum_s w P_a^2 on all the others (k_hsolve then
+// knows the diagonal exactly and rescales only the sampled off-diagonal part -- round 6).  One launch: both kinds of tile
+// run at one workgroup per CU anyway (512 threads at > 128 registers), the sampled ones take ~3x as long and are given the
+// lowest workgroup numbers so that they start first.  XACT: exact softmax arguments
+template <int Q, bool WRITE_RT, int STATS, bool XACT>
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NH = (STATS == 2) ? Q * (Q + 1) / 2 : 0;
@@ -1486,12 +1494,20 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     if (A.state) A.h += (size_t)((const PlmVpState *)A.state)->cur * A.hstride;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
-    // a Hessian pass is two launches: the sampled tiles with the big LDS statistics area (one workgroup per CU), all
-    // other tiles with the small one (three per CU) -- one launch for both ran every tile at the low occupancy
+    // a Hessian position (STATS == 2, sel 3): workgroups 0 .. ns1 * nb - 1 take the sampled tiles, the rest all others
     const int ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
-    const int nst = A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1);
-    const int kt = blockIdx.x % nst, b16l = blockIdx.x / nst;
-    const int stile = A.sel == 0 ? kt : (A.sel == 1 ? kt * PLM_HESS_SAMPLE : kt + kt / (PLM_HESS_SAMPLE - 1) + 1);
+    int sel = A.sel, bid = blockIdx.x;
+    if (sel == 3) {
+        const int nS = ns1 * (d.b16_hi - d.b16_lo);
+        sel = bid < nS ? 1 : 2;
+        bid -= bid < nS ? 0 : nS;
+    }
+    const int nst = sel == 0 ? d.nstiles : (sel == 1 ? ns1 : d.nstiles - ns1);
+    const int kt = bid % nst, b16l = bid / nst;
+    // a statistics pass of the chain leaves quiet blocks alone (PlmVpState::quiet; wave-uniform, scalar cache)
+    if (A.state && A.cond == PLM_VP_PASS && b16l < PLM_VP_MAXBLK && ((const PlmVpState *)A.state)->quiet[b16l]) return;
+    const int stile = sel == 0 ? kt : (sel == 1 ? kt * PLM_HESS_SAMPLE : kt + kt / (PLM_HESS_SAMPLE - 1) + 1);
+    const bool sampled = STATS == 2 && (stile % PLM_HESS_SAMPLE) == 0;      // wave-uniform
     const int blk = b16l * d.nstiles + stile;          // index of the (site block, sequence tile) pair everywhere
     const int b16 = d.b16_lo + b16l;
     const int r = lane & 15, g = lane >> 4;
@@ -1530,9 +1546,13 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     double *lg = (double *)smem + ((size_t)wave * 16 + r) * Q;
     float *lh0 = (float *)((double *)smem + (size_t)8 * 16 * Q);
     float *ls = lh0 + ((size_t)wave * 16 + r) * NH;
-    if (STATS) {
+    double *ld = lg + (size_t)8 * 16 * Q;             // diagonal sums (tiles without Hessian sums): f64, in the Hessian area
+    if (STATS) {      // every wave clears what IT accumulates into (no barrier needed): a workgroup is sampled or not as a whole
         for (int k = lane; k < 16 * Q; k += 64) ((double *)smem)[(size_t)wave * 16 * Q + k] = 0.0;
-        for (int k = lane; k < 16 * NH; k += 64) lh0[(size_t)wave * 16 * NH + k] = 0.f;
+        if (sampled)
+            for (int k = lane; k < 16 * NH; k += 64) lh0[(size_t)wave * 16 * NH + k] = 0.f;
+        else if (STATS == 2)
+            for (int k = lane; k < 16 * Q; k += 64) ((double *)smem)[(size_t)(8 + wave) * 16 * Q + k] = 0.0;
     }
     // wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset: no 64-bit per-lane addresses
     const char *hj_u = (const char *)(A.hj + ((size_t)blk * 8 + wave) * 2 * Q * 64);
@@ -1629,12 +1649,21 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 // Q gradient sums: the 4 lanes of a site add straight into LDS (f64, one ds_add_f64, resolved in
                 // lane order); the Hessian sums below are reduced in registers first
                 unsafeAtomicAdd(&lg[a], (double)ga);
+                if (STATS == 2 && !sampled) {
+                    float da = 0.f;                                           // sum_k w P_a^2, P_a = acc + [x = a]
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool obs = xk[k] == a;
+                        da = fmaf(t[k] + (obs ? wk[k] : 0.f), acc[a][k] + (obs ? 1.f : 0.f), da);
+                    }
+                    unsafeAtomicAdd(&ld[a], (double)da);
+                    continue;
+                }
                 if constexpr (STATS == 2) {
                     // Hessian sums M_ab = sum_s w P_a P_b from every PLM_HESS_SAMPLE-th sequence tile only (scaled up
                     // by k_hsolve): the Newton iteration tolerates a few per cent of sampling error in H, the
                     // gradient sums above stay exact.  (Taking the diagonal M_aa from every tile buys nothing:
                     // H_aa = sum_b M_ab - M_aa + 2 lambda_h, it cancels.)
-                    if ((stile % PLM_HESS_SAMPLE) != 0) continue;
                     idx = a * Q - a * (a - 1) / 2;
 #pragma unroll
                     for (int k = 0; k < 4; k++) t[k] += (xk[k] == a) ? wk[k] : 0.f;     // w P(a)
@@ -1719,7 +1748,16 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             for (int wv = 0; wv < 8; wv++) v += ((const double *)smem)[(size_t)wv * 16 * Q + k];
             gout[k] = v;
         }
-        if constexpr (STATS == 2) {
+        if (STATS == 2 && !sampled) {
+            double *dout = A.dpart + (size_t)blk * 16 * Q;
+            for (int k = tid; k < 16 * Q; k += 512) {
+                double v = 0;
+#pragma unroll
+                for (int wv = 0; wv < 8; wv++) v += ((const double *)smem)[(size_t)(8 + wv) * 16 * Q + k];
+                dout[k] = v;
+            }
+        }
+        if (STATS == 2 && sampled) {
             float *out = A.hpart + (size_t)blk * 16 * NH;
             for (int k = tid; k < 16 * NH; k += 512) {
                 float v = 0.f;
@@ -1737,15 +1775,15 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
 }
 hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa_rm, const float *w,
                             const double *h64, int write_rt, int stats, int exact, void *Rt, double *fx_part, float *hpart,
-                            double *gpart, const int *state, int cond, hipStream_t st) {
+                            double *gpart, double *dpart, const int *state, int cond, hipStream_t st) {
     if (d.b16_hi <= d.b16_lo) return hipSuccess;
     const int nb = d.b16_hi - d.b16_lo, ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
     const dim3 block(512);
     HpassArgs A{(const float4 *)hj, msa_rm, w, h64, (int)plm_h64_stride(d), (char *)Rt, fx_part,
-                hpart, gpart, d.rscale, state, cond, 0};
+                hpart, gpart, d.rscale, dpart, state, cond, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
-        const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
+        const dim3 grid(d.nstiles * nb);                                                               \
         const size_t lds = (size_t)8 * 16 * ((QQ) * sizeof(double) + ((SS) == 2 ? (QQ) * ((QQ) + 1) / 2 : 0) * sizeof(float)); \
         {                                                                                              \
             hipError_t e = exact ? plm_allow_lds<k_hpass<QQ, WW, SS, true>>(lds) : plm_allow_lds<k_hpass<QQ, WW, SS, false>>(lds); \
@@ -1760,9 +1798,8 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
         else if (write_rt && stats == 0) HP_LAUNCH(QQ, true, 0)                                        \
         else if (write_rt) HP_LAUNCH(QQ, true, 1)                                                      \
         else if (stats == 2) {                                                                         \
-            A.sel = 2;                                                                                 \
-            if (d.nstiles > ns1) HP_LAUNCH(QQ, false, 1)                                               \
-            A.sel = 1;                                                                                 \
+            if (!dpart) return hipErrorInvalidValue;                                                   \
+            A.sel = 3;                                                                                 \
             HP_LAUNCH(QQ, false, 2)                                                                    \
         } else HP_LAUNCH(QQ, false, 1)                                                                 \
         break;
@@ -1843,7 +1880,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
                                               double lambda_h, int update,
                                               double *__restrict__ hinv, double *__restrict__ g2_site,
                                               double tol_site2, const int *__restrict__ state, int chain, int hstride,
-                                              const double *__restrict__ cnt) {
+                                              const double *__restrict__ cnt, const double *__restrict__ dpart) {
     constexpr int NVF = PLM_HSTATS(Q);
     const PlmVpState *S = (const PlmVpState *)state;
     int cur = 0;
@@ -1857,7 +1894,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     __shared__ double st[NVF];
     __shared__ double Hm[Q][2 * Q + 1];             // [H | I] -> [I | H^-1] (odd row stride: no bank conflicts)
     __shared__ double Hi[Q][Q + 1];                 // the inverse the step is taken with
-    __shared__ double gr[Q], Dv[Q], mv[Q];
+    __shared__ double gr[Q], Dv[Q], mv[Q], Md[Q];
     const int il = blockIdx.x, t = threadIdx.x;     // local site index
     const int i = d.h_site0 + il;
     if (i >= min(d.L, d.own_hi * 16)) {             // padding sites of the last block
@@ -1867,6 +1904,15 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     const double *hc = h64 + (size_t)cur * hstride + (size_t)il * Q;                       // the fields the pass saw
     double *hn = h64 + (size_t)((S && chain) ? (cur ^ 1) : cur) * hstride + (size_t)il * Q; // where the step goes
     const int b16l = il >> 4, r = il & 15;
+    // quiet block (PlmVpState::quiet): its sites no longer move.  A statistics pass skipped it -- the norm of its last
+    // pass stands; a pass in the residual-writing role covered it -- fresh norm below, no step
+    const bool quiet = S && chain && b16l < PLM_VP_MAXBLK && S->quiet[b16l];
+    if (quiet) {
+        if (update && t < Q) hn[t] = hc[t];
+        if (!S->want_rt) return;
+        update = 0;
+        full = 0;
+    }
     constexpr int NH = Q * (Q + 1) / 2;
     {
         // gradient sums: lane = sequence tile (mod 64), then the 64 lane sums per state are added in a fixed butterfly
@@ -1894,6 +1940,29 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
                 v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NH + k];
             st[Q + k] = v * ((double)d.nstiles / nsamp);
         }
+        // exact diagonal second-order sums M_aa = sum_s w P_a^2 over ALL sequences (round 6): the tiles without Hessian
+        // sums deliver them as f64 partials (k_hpass STATS = 3), the sampled tiles as the diagonal entries of their sums
+        if (dpart) {      // lane = sequence tile (mod 64), as for the gradient sums above
+            double part[Q];
+#pragma unroll
+            for (int k = 0; k < Q; k++) part[k] = 0;
+            for (int tt = t; tt < d.nstiles; tt += 64) {
+                const size_t blk = ((size_t)b16l * d.nstiles + tt) * 16 + r;
+                if ((tt % PLM_HESS_SAMPLE) == 0) {
+#pragma unroll
+                    for (int k = 0; k < Q; k++) part[k] += (double)hpart[blk * NH + (k * Q - k * (k - 1) / 2)];   // (k, k) of the upper triangle
+                } else {
+#pragma unroll
+                    for (int k = 0; k < Q; k++) part[k] += dpart[blk * Q + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                double v = part[k];
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (t == 0) Md[k] = v;
+            }
+        }
     }
     __syncthreads();
     const int a0 = d.gap_mode;                      // gap mode: state 0 is not a model state
@@ -1918,8 +1987,17 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
         // (tests/probes/field_solver_lab.py): contraction per step 0.03 -> 0.003.  (Scaling the rows to m without
         // restoring the zero row sums -- H = diag(m) - D M~ D -- breaks the cancellation between the two terms and is far
         // worse than no correction: measured, gpurun_out/r5c13.)
+        // Round 6: with the DIAGONAL of sum_s w P P^T known exactly (Md) only the off-diagonal part of the sampled matrix
+        // is rescaled, to the row sums m_a - M_aa it must have; the diagonal of H is then exact.  CPU lab
+        // (tests/probes/field_solver_lab.py chain_dev_sink / chain_dev_xdiag / chain_dev_exact, N = 49 152, sampling 1/16):
+        // 7.2 / 5.5 / 5.3 passes per evaluation -- nearly the exact Hessian's.
+        const bool xdiag = cnt && dpart;
         if (t < Q) {
             mv[t] = cnt ? fmax(0.0, st[t] + cnt[(size_t)il * Q + t]) : 0.0;
+            if (xdiag) {
+                mv[t] = fmax(0.0, mv[t] - Md[t]);
+                Hm[t][t] = 0.0;
+            }
             Dv[t] = 1.0;
         }
         __syncthreads();
@@ -2051,11 +2129,16 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
         s += v;
         open_sites += (v > tol_site2) ? 1 : 0;
     }
-    for (int b = threadIdx.x; b < n / 16; b += 256) {      // debug trace only
-        bool loud = false;
-        for (int k = 0; k < 16; k++) loud |= g2_site[b * 16 + k] > tol2 / (8.0 * n);
-        if (loud) atomicAdd(&loud_blocks, 1);
-    }
+    // quiet blocks: within their share of a quarter of the tolerance -> they stop moving, later statistics passes
+    // skip them (sticky for the rest of the chain; the flags only matter if the chain goes on)
+    const int nblk = n / 16;
+    if (S && nblk <= PLM_VP_MAXBLK && tol2 > 0.0)
+        for (int b = threadIdx.x; b < nblk; b += 256) {
+            double sb = 0;
+            for (int k = 0; k < 16; k++) sb += g2_site[b * 16 + k];
+            if (!S->quiet[b] && sb <= 0.25 * tol2 / nblk) S->quiet[b] = 1;
+            if (!S->quiet[b]) atomicAdd(&loud_blocks, 1);
+        }
     for (int o = 32; o > 0; o >>= 1) open_sites += __shfl_down(open_sites, o, 64);
     if ((threadIdx.x & 63) == 0) bad[threadIdx.x >> 6] = open_sites;
     const double t = block_reduce_sum(s, red);     // contains the barrier that publishes bad[]
@@ -2101,6 +2184,7 @@ __global__ void k_vp_reset(int *state, int want_rt) {
     PlmVpState *S = (PlmVpState *)state;
     S->done = 0; S->want_rt = want_rt; S->final_skip = 0; S->passes = 0; S->cur = 0; S->g2_prev = 0.0; S->g2_prev2 = 0.0;
     for (int k = 0; k < PLM_VP_HIST; k++) S->hist[k] = 0.0;
+    for (int k = 0; k < PLM_VP_MAXBLK; k++) S->quiet[k] = 0;
 }
 hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st) {
     hipLaunchKernelGGL(k_vp_reset, dim3(1), dim3(1), 0, st, state, want_rt);
@@ -2108,7 +2192,7 @@ hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st) {
 }
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
                              double lambda_h, int update, double *hinv, double *g2_site, double *g2_out, double tol2,
-                             double floor2, int *state, int chain, const double *cnt, hipStream_t st) {
+                             double floor2, int *state, int chain, const double *cnt, const double *dpart, hipStream_t st) {
     const int nsites = (d.b16_hi - d.b16_lo) * 16;
     int *cstate = chain ? state : nullptr;      // the chain's bookkeeping runs for chain positions only
     if (nsites <= 0) {      // a shard without sites: its chain is done at once
@@ -2125,10 +2209,10 @@ hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double 
     const double tol_site2 = 0.0;
     const int hs = (int)plm_h64_stride(d);
     switch (d.Q) {
-    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
-    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
-    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
-    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt); break;
+    case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
+    case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
+    case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
+    case 4: hipLaunchKernelGGL(k_hsolve<4>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
     default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(k_vp_check, dim3(1), dim3(256), 0, st, g2_site, nsites, g2_out, tol_site2, tol2, floor2, cstate);

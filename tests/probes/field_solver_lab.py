@@ -70,13 +70,25 @@ class Solver:
         Hh = None
         if hess:
             self.hess_passes += 1
-            if self.variant.startswith("exact"):
+            if "exact" in self.variant:
                 wP = w[:, None, None] * P
                 Hh = torch.diag_embed(wP.sum(0)) - torch.einsum("sia,sib->iab", wP, P) + 2 * lh * EYE
             else:
                 wP = (w[:, None, None] * P)
                 M = torch.einsum("sia,sib->iab", wP[samp], P[samp]) * samp_scale
-                if "sink" in self.variant:
+                if "xdiag" in self.variant:
+                    # round 6 experiment: the DIAGONAL second-order sums M_aa = sum_s w P_a^2 from every tile (exact), the
+                    # off-diagonal ones sampled and rescaled symmetrically until their row sums are m_a - M_aa
+                    m = wP.sum(0)
+                    Md = (wP * P).sum(0)
+                    off = M - torch.diag_embed(torch.diagonal(M, dim1=1, dim2=2))
+                    tgt = (m - Md).clamp_min(0)
+                    D = torch.ones_like(m)
+                    for _ in range(3):
+                        rs = (D[:, :, None] * off * D[:, None, :]).sum(2)
+                        D = D * torch.sqrt(tgt / rs.clamp_min(1e-300))
+                    M = D[:, :, None] * off * D[:, None, :] + torch.diag_embed(Md)
+                elif "sink" in self.variant:
                     # k_hsolve (round 5): the sampled second-order sums rescaled symmetrically until their row sums are
                     # the exact first-order sums m = sum_s w P (three Sinkhorn sweeps)
                     m = wP.sum(0)
