@@ -468,9 +468,7 @@ int ctx_eval_enqueue(plm_ctx *c) {
 bool vp_enabled(const plm_ctx *c) {
     // lambda_h = 0: the per-site Hessians are singular along the softmax gauge direction (the Newton solver has no
     // pivoting) -- such a problem runs the joint path
-    // (alphabets above 21 symbols run the 32-state instantiation, which has no field solver: joint path)
-    return !(c->prob.flags & PLM_FLAG_JOINT_LBFGS) && (c->d.nshards == 1 || c->d.sharded) && c->prob.lambda_h > 0 &&
-           c->d.Q <= 21;
+    return !(c->prob.flags & PLM_FLAG_JOINT_LBFGS) && (c->d.nshards == 1 || c->d.sharded) && c->prob.lambda_h > 0;
 }
 int vp_alloc(plm_ctx *c) {
     if (c->hj) return PLM_OK;

@@ -1481,11 +1481,11 @@ __device__ __forceinline__ bool vp_runs(const int *state, int cond) {
     if (S->done) return false;
     return cond == PLM_VP_PASS_RT ? S->want_rt != 0 : S->want_rt == 0;
 }
-// STATS: 0 none, 1 gradient sums, 2 a Hessian position of the chain: gradient sums everywhere, Hessian sums sum_s w P P^T on
-// every PLM_HESS_SAMPLE-th sequence tile and the DIAGONAL second-order sums sum_s w P_a^2 on all the others (k_hsolve then
-// knows the diagonal exactly and rescales only the sampled off-diagonal part -- round 6).  One launch: both kinds of tile
-// run at one workgroup per CU anyway (512 threads at > 128 registers), the sampled ones take ~3x as long and are given the
-// lowest workgroup numbers so that they start first.  XACT: exact softmax arguments
+// STATS: 0 none, 1 gradient sums; a Hessian position of the chain is two launches: 2 = gradient + Hessian sums
+// sum_s w P P^T on every PLM_HESS_SAMPLE-th sequence tile (118 KB of LDS statistics: one workgroup per CU), 3 = gradient +
+// DIAGONAL second-order sums sum_s w P_a^2 on all the others (two workgroups per CU) -- k_hsolve then knows the diagonal
+// exactly and rescales only the sampled off-diagonal part (round 6).  (One merged launch was measured: no gain, the sampled
+// tiles are throughput, not a tail -- gpurun_out/r6f.)  XACT: exact softmax arguments
 template <int Q, bool WRITE_RT, int STATS, bool XACT>
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1494,20 +1494,18 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     if (A.state) A.h += (size_t)((const PlmVpState *)A.state)->cur * A.hstride;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
-    // a Hessian position (STATS == 2, sel 3): workgroups 0 .. ns1 * nb - 1 take the sampled tiles, the rest all others
     const int ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
-    int sel = A.sel, bid = blockIdx.x;
-    if (sel == 3) {
-        const int nS = ns1 * (d.b16_hi - d.b16_lo);
-        sel = bid < nS ? 1 : 2;
-        bid -= bid < nS ? 0 : nS;
-    }
+    const int sel = A.sel, bid = blockIdx.x;
     const int nst = sel == 0 ? d.nstiles : (sel == 1 ? ns1 : d.nstiles - ns1);
     const int kt = bid % nst, b16l = bid / nst;
     // a statistics pass of the chain leaves quiet blocks alone (PlmVpState::quiet; wave-uniform, scalar cache)
     if (A.state && A.cond == PLM_VP_PASS && b16l < PLM_VP_MAXBLK && ((const PlmVpState *)A.state)->quiet[b16l]) return;
     const int stile = sel == 0 ? kt : (sel == 1 ? kt * PLM_HESS_SAMPLE : kt + kt / (PLM_HESS_SAMPLE - 1) + 1);
-    const bool sampled = STATS == 2 && (stile % PLM_HESS_SAMPLE) == 0;      // wave-uniform
+    // Alphabets above 21 states (the 32-state instantiation): the Hessian sums of eight waves do not fit the LDS -- two waves
+    // of a sampled tile contribute them (k_hsolve scales accordingly), and the sampled tiles deliver their exact diagonal
+    // sums like all the others
+    constexpr int HW = Q > 21 ? 2 : 8;
+    constexpr bool sampled = STATS == 2, DIAG = STATS == 3 || (STATS == 2 && Q > 21);
     const int blk = b16l * d.nstiles + stile;          // index of the (site block, sequence tile) pair everywhere
     const int b16 = d.b16_lo + b16l;
     const int r = lane & 15, g = lane >> 4;
@@ -1537,21 +1535,35 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             }
         }
     };
-    if constexpr (!WRITE_RT) load_fields(false);
+    // The statistics-only instantiations keep the hi / lo pairs in LDS instead ([site][state] float2, read per sequence):
+    // 42 registers less puts them under 128 -- TWO workgroups per CU, whose load and compute phases overlap (round 6)
+    constexpr bool LDSF = !WRITE_RT && !XACT && (STATS != 2 || Q > 21);     // (21 states: the sampled tiles are one workgroup per CU by LDS anyway)
+    constexpr size_t STAT_BYTES = (size_t)16 * (8 * Q * sizeof(double) * (DIAG ? 2 : 1) + HW * NH * sizeof(float));
+    float2 *lf = (float2 *)(smem + STAT_BYTES);
+    if constexpr (LDSF) {
+        for (int k = tid; k < 16 * Q; k += 512) {
+            const int ii = b16 * 16 + k / Q;
+            const double h64 = ii < d.L ? A.h[(size_t)(ii - d.h_site0) * Q + k % Q] : 0.0;
+            const float hi = (float)h64;
+            lf[k] = make_float2(hi, (float)(h64 - (double)hi));
+        }
+        __syncthreads();
+    } else if constexpr (!WRITE_RT) load_fields(false);
     float fxl = 0.f;
     // statistics areas, one per wave: gradient sums [site][Q] in f64, then Hessian sums [site][NH] in f32.  Lanes add
     // with fire-and-forget LDS adds (the 4 lanes of a site collide on one address inside one instruction: resolved in
     // lane order; the two halves of the tile accumulate); waves never share an address and the areas are summed in
     // wave order at the end: bit-reproducible
     double *lg = (double *)smem + ((size_t)wave * 16 + r) * Q;
-    float *lh0 = (float *)((double *)smem + (size_t)8 * 16 * Q);
-    float *ls = lh0 + ((size_t)wave * 16 + r) * NH;
-    double *ld = lg + (size_t)8 * 16 * Q;             // diagonal sums (tiles without Hessian sums): f64, in the Hessian area
-    if (STATS) {      // every wave clears what IT accumulates into (no barrier needed): a workgroup is sampled or not as a whole
+    double *ld = lg + (size_t)8 * 16 * Q;             // DIAG: a second f64 area behind the gradient sums
+    float *lh0 = (float *)((double *)smem + (size_t)8 * 16 * Q * (DIAG ? 2 : 1));
+    float *ls = lh0 + ((size_t)wave * 16 + r) * NH;   // (waves below HW only)
+    if (STATS) {      // every wave clears what IT accumulates into: no barrier needed
         for (int k = lane; k < 16 * Q; k += 64) ((double *)smem)[(size_t)wave * 16 * Q + k] = 0.0;
-        if (sampled)
-            for (int k = lane; k < 16 * NH; k += 64) lh0[(size_t)wave * 16 * NH + k] = 0.f;
-        else if (STATS == 2)
+        if constexpr (sampled)
+            if (wave < HW)
+                for (int k = lane; k < 16 * NH; k += 64) lh0[(size_t)wave * 16 * NH + k] = 0.f;
+        if constexpr (DIAG)
             for (int k = lane; k < 16 * Q; k += 64) ((double *)smem)[(size_t)(8 + wave) * 16 * Q + k] = 0.0;
     }
     // wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset: no 64-bit per-lane addresses
@@ -1585,9 +1597,20 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             const float ws = (skip || !site_ok) ? 0.f : A.w[s];
             float mx = -INFINITY, Z = 0.f, hx = 0.f, zo = 0.f;     // zo: sum of the exponentials of the states NOT observed
             if constexpr (!XACT) {
+                u32 foff = (u32)r * Q;
+                if constexpr (LDSF) asm volatile("" : "+v"(foff));   // per sequence: the 21 pairs are read again, not kept
 #pragma unroll
                 for (int a = 0; a < Q; a++) {
-                    const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : (acc[a][reg] + hl[a]) + hv[a];
+                    float fh, fl;
+                    if constexpr (LDSF) {
+                        const float2 f = lf[foff + a];
+                        fh = f.x;
+                        fl = f.y;
+                    } else {
+                        fh = hv[a];
+                        fl = hl[a];
+                    }
+                    const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : (acc[a][reg] + fl) + fh;
                     acc[a][reg] = H;
                     mx = fmaxf(mx, H);
                 }
@@ -1649,7 +1672,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 // Q gradient sums: the 4 lanes of a site add straight into LDS (f64, one ds_add_f64, resolved in
                 // lane order); the Hessian sums below are reduced in registers first
                 unsafeAtomicAdd(&lg[a], (double)ga);
-                if (STATS == 2 && !sampled) {
+                if constexpr (DIAG) {
                     float da = 0.f;                                           // sum_k w P_a^2, P_a = acc + [x = a]
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -1657,9 +1680,8 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                         da = fmaf(t[k] + (obs ? wk[k] : 0.f), acc[a][k] + (obs ? 1.f : 0.f), da);
                     }
                     unsafeAtomicAdd(&ld[a], (double)da);
-                    continue;
                 }
-                if constexpr (STATS == 2) {
+                if (STATS == 2 && wave < HW) {
                     // Hessian sums M_ab = sum_s w P_a P_b from every PLM_HESS_SAMPLE-th sequence tile only (scaled up
                     // by k_hsolve): the Newton iteration tolerates a few per cent of sampling error in H, the
                     // gradient sums above stay exact.  (Taking the diagonal M_aa from every tile buys nothing:
@@ -1748,7 +1770,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             for (int wv = 0; wv < 8; wv++) v += ((const double *)smem)[(size_t)wv * 16 * Q + k];
             gout[k] = v;
         }
-        if (STATS == 2 && !sampled) {
+        if constexpr (DIAG) {
             double *dout = A.dpart + (size_t)blk * 16 * Q;
             for (int k = tid; k < 16 * Q; k += 512) {
                 double v = 0;
@@ -1757,12 +1779,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 dout[k] = v;
             }
         }
-        if (STATS == 2 && sampled) {
+        if constexpr (sampled) {
             float *out = A.hpart + (size_t)blk * 16 * NH;
             for (int k = tid; k < 16 * NH; k += 512) {
                 float v = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < 8; wv++) v += lh0[(size_t)wv * 16 * NH + k];
+                for (int wv = 0; wv < HW; wv++) v += lh0[(size_t)wv * 16 * NH + k];
                 out[k] = v;
             }
         }
@@ -1783,8 +1805,10 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
                 hpart, gpart, d.rscale, dpart, state, cond, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
-        const dim3 grid(d.nstiles * nb);                                                               \
-        const size_t lds = (size_t)8 * 16 * ((QQ) * sizeof(double) + ((SS) == 2 ? (QQ) * ((QQ) + 1) / 2 : 0) * sizeof(float)); \
+        const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
+        const size_t lds = (size_t)16 * (8 * (QQ) * sizeof(double) * (((SS) == 3 || ((SS) == 2 && (QQ) > 21)) ? 2 : 1) + \
+                                         ((SS) == 2 ? ((QQ) > 21 ? 2 : 8) * ((QQ) * ((QQ) + 1) / 2) : 0) * sizeof(float)) + \
+                           (size_t)16 * (QQ) * sizeof(float2);      /* + the fields as hi / lo pairs */     \
         {                                                                                              \
             hipError_t e = exact ? plm_allow_lds<k_hpass<QQ, WW, SS, true>>(lds) : plm_allow_lds<k_hpass<QQ, WW, SS, false>>(lds); \
             if (e != hipSuccess) return e;                                                             \
@@ -1799,15 +1823,14 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
         else if (write_rt) HP_LAUNCH(QQ, true, 1)                                                      \
         else if (stats == 2) {                                                                         \
             if (!dpart) return hipErrorInvalidValue;                                                   \
-            A.sel = 3;                                                                                 \
+            A.sel = 1;     /* the sampled tiles first: long workgroups, one per CU */                   \
             HP_LAUNCH(QQ, false, 2)                                                                    \
+            A.sel = 2;                                                                                 \
+            if (d.nstiles > ns1) HP_LAUNCH(QQ, false, 3)                                               \
         } else HP_LAUNCH(QQ, false, 1)                                                                 \
         break;
     switch (d.Q) {
-    case 32:        // no field solver at this size (joint L-BFGS only): the residual pass alone
-        if (!write_rt || stats != 0) return hipErrorInvalidValue;
-        HP_LAUNCH(32, true, 0)
-        break;
+        HP_CASE(32)
         HP_CASE(21)
         HP_CASE(20)
         HP_CASE(5)
@@ -1859,6 +1882,7 @@ hipError_t plm_launch_site_counts(const PlmDims &d, const int8_t *msa_cm, const 
     const int nsites = (d.b16_hi - d.b16_lo) * 16;
     if (nsites <= 0) return hipSuccess;
     switch (d.Q) {
+    case 32: hipLaunchKernelGGL(k_site_counts<32>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
     case 21: hipLaunchKernelGGL(k_site_counts<21>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
     case 20: hipLaunchKernelGGL(k_site_counts<20>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
     case 5: hipLaunchKernelGGL(k_site_counts<5>, dim3(nsites), dim3(256), 0, st, d, msa_cm, w, cnt); break;
@@ -1938,7 +1962,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
             double v = 0;
             for (int tt = 0; tt < d.nstiles; tt += PLM_HESS_SAMPLE)
                 v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NH + k];
-            st[Q + k] = v * ((double)d.nstiles / nsamp);
+            st[Q + k] = v * ((double)d.nstiles / nsamp) * (Q > 21 ? 4.0 : 1.0);     // above 21 states 2 waves of 8 carry them
         }
         // exact diagonal second-order sums M_aa = sum_s w P_a^2 over ALL sequences (round 6): the tiles without Hessian
         // sums deliver them as f64 partials (k_hpass STATS = 3), the sampled tiles as the diagonal entries of their sums
@@ -1948,7 +1972,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
             for (int k = 0; k < Q; k++) part[k] = 0;
             for (int tt = t; tt < d.nstiles; tt += 64) {
                 const size_t blk = ((size_t)b16l * d.nstiles + tt) * 16 + r;
-                if ((tt % PLM_HESS_SAMPLE) == 0) {
+                if (Q <= 21 && (tt % PLM_HESS_SAMPLE) == 0) {      // (above 21 states every tile delivers its diagonal sums)
 #pragma unroll
                     for (int k = 0; k < Q; k++) part[k] += (double)hpart[blk * NH + (k * Q - k * (k - 1) / 2)];   // (k, k) of the upper triangle
                 } else {
@@ -2209,6 +2233,7 @@ hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double 
     const double tol_site2 = 0.0;
     const int hs = (int)plm_h64_stride(d);
     switch (d.Q) {
+    case 32: hipLaunchKernelGGL(k_hsolve<32>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
     case 21: hipLaunchKernelGGL(k_hsolve<21>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
     case 20: hipLaunchKernelGGL(k_hsolve<20>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
     case 5: hipLaunchKernelGGL(k_hsolve<5>, dim3(nsites), dim3(64), 0, st, d, hpart, gpart, full, x, h64, lambda_h, update, hinv, g2_site, tol_site2, state, chain, hs, cnt, dpart); break;
