@@ -105,6 +105,7 @@ SYMBOLS = [
     ("plm_ctx_optimize", C.c_int, [_P, ITER_CB, _P, C.POINTER(PlmResult)]),
     ("plm_ctx_scores", C.c_int, [_P, _P, _P]),
     ("plm_ctx_time_kernels", C.c_int, [_P, C.c_int32, _P]),
+    ("plm_ctx_time_field_positions", C.c_int, [_P, C.c_int32, _P]),
     ("plm_ctx_solver_stats", C.c_int, [_P, _P]),
     ("plm_rccl_probe", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int, _P]),
     ("plm_rccl_probe_local", C.c_int, [C.c_int32, C.c_int, _P]),

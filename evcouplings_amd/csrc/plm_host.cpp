@@ -1858,6 +1858,44 @@ int plm_ctx_scores(plm_ctx_t *c, float *fn_host, float *cn_host) {
     return PLM_OK;
 }
 
+int plm_ctx_time_field_positions(plm_ctx_t *c, int32_t reps, float *out_ms) {
+    if (!c || !out_ms || reps <= 0) return fail(PLM_EINVAL, "bad argument");
+    if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");
+    if (!vp_enabled(c) || !c->hj) return fail(PLM_EINVAL, "no stored potentials: plm_ctx_time_kernels on a variable-projection context first");
+    HIP_TRY(hipSetDevice(c->device));
+    const PlmDims &d = c->d;
+    c->eval_valid = false;
+    ctx_set_accurate(c, false);
+    PLM_TRY(vp_counts(c));
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    double acc[2] = {0, 0};
+    int rc = PLM_OK;
+    for (int r = 0; r < reps && rc == PLM_OK; r++) {
+        float ms;
+        hipError_t e = hipEventRecord(ev[0], c->st);
+        if (e == hipSuccess) e = plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 0, 2, 0, nullptr, nullptr, c->hpart, c->gpart, c->dpart,
+                                                  nullptr, PLM_VP_ALWAYS, c->st);
+        if (e == hipSuccess) e = plm_launch_hsolve(d, c->hpart, c->gpart, 1, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2, c->scal + 5,
+                                                   0.0, 0.0, nullptr, 0, c->hcnt, c->dpart, c->st);
+        if (e == hipSuccess) e = hipEventRecord(ev[1], c->st);
+        if (e == hipSuccess) e = plm_launch_hpass(d, c->hj, c->msa_rm, c->w, c->h64, 1, 1, 0, c->Rt, c->fx_part, c->hpart, c->gpart, nullptr,
+                                                  nullptr, PLM_VP_ALWAYS, c->st);
+        if (e == hipSuccess) e = plm_launch_hsolve(d, c->hpart, c->gpart, 0, c->x, c->h64, c->prob.lambda_h, 0, c->hinv, c->hg2, c->scal + 5,
+                                                   0.0, 0.0, nullptr, 0, c->hcnt, c->dpart, c->st);
+        if (e == hipSuccess) e = hipEventRecord(ev[2], c->st);
+        if (e == hipSuccess) e = hipEventSynchronize(ev[2]);
+        if (e == hipSuccess && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) acc[0] += ms;
+        if (e == hipSuccess && hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) acc[1] += ms;
+        if (e != hipSuccess) rc = fail(PLM_EDEVICE, "field position timing: %s", hipGetErrorString(e));
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    c->vp_hess_age = 0;
+    out_ms[0] = (float)(acc[0] / reps);
+    out_ms[1] = (float)(acc[1] / reps);
+    return rc;
+}
+
 int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
     if (!c || !out_ms || reps <= 0) return fail(PLM_EINVAL, "bad argument");
     if (!c->have_weights) return fail(PLM_EINVAL, "weights not set");

@@ -78,7 +78,7 @@ struct PlmDims {
     int nmf;       // row fragments of the backward GEMM: nb16*Q + FM (last FM = "ones" block)
     int nshards, shard;
     int blk_per_shard;  // ceil(nb16 / nshards): the most column blocks a shard owns (slab width)
-    int shard_base, shard_rem;   // balanced partition: the first shard_rem shards own shard_base + 1 blocks, the rest shard_base
+    int shard_base, shard_rem;   // balanced partition: the LAST shard_rem shards own shard_base + 1 blocks, the others shard_base
     int b16_lo, b16_hi; // this shard's column blocks [lo, hi)
     int nnfl;      // local col fragments = blk_per_shard * Q (slab width, padded)
     int ksplit;    // split-K factor of the backward GEMM
@@ -126,15 +126,22 @@ struct PlmOptions {
 };
 PlmOptions plm_options_from_env();
 
-// balanced partition of the nb16 column blocks over the shards (19 blocks on 8 GPUs: 3,3,3,2,2,2,2,2 -- no idle GPU)
+// balanced partition of the nb16 column blocks over the shards: the LAST nb16 % nshards shards own one block more (19
+// blocks on 8 GPUs: 2,2,2,2,2,3,3,3 -- no idle GPU).  The surplus blocks sit at the high end because a shard also owns
+// the block pairs (I own, J >= I): the low shards hold the long rows of the triangle (their share of the L-BFGS vectors
+// and of k_assemble), the high shards almost none -- at the headline the busiest rank then owns 3 blocks and 24 block
+// pairs instead of 3 blocks and 54 (round 6).
 static inline __host__ __device__ int plm_shard_lo(const PlmDims &d, int r) {
-    return r * d.shard_base + (r < d.shard_rem ? r : d.shard_rem);
+    const int small = d.nshards - d.shard_rem;          // shards with shard_base blocks come first
+    return r * d.shard_base + (r > small ? r - small : 0);
 }
-static inline __host__ __device__ int plm_shard_cnt(const PlmDims &d, int r) { return d.shard_base + (r < d.shard_rem ? 1 : 0); }
+static inline __host__ __device__ int plm_shard_cnt(const PlmDims &d, int r) {
+    return d.shard_base + (r >= d.nshards - d.shard_rem ? 1 : 0);
+}
 static inline __host__ __device__ int plm_shard_of(const PlmDims &d, int b) {
-    const int big = d.shard_rem * (d.shard_base + 1);
-    if (b < big) return b / (d.shard_base + 1);
-    return d.shard_rem + (d.shard_base > 0 ? (b - big) / d.shard_base : 0);
+    const int small = d.nshards - d.shard_rem, nsmall = small * d.shard_base;
+    if (b < nsmall) return d.shard_base > 0 ? b / d.shard_base : 0;
+    return small + (b - nsmall) / (d.shard_base + 1);
 }
 static inline __host__ __device__ int64_t plm_bp_index(int I, int J, int nb16) { // I <= J
     return (int64_t)I * nb16 - (int64_t)I * (I - 1) / 2 + (J - I);

@@ -1486,16 +1486,46 @@ __device__ __forceinline__ bool vp_runs(const int *state, int cond) {
 // DIAGONAL second-order sums sum_s w P_a^2 on all the others (two workgroups per CU) -- k_hsolve then knows the diagonal
 // exactly and rescales only the sampled off-diagonal part (round 6).  (One merged launch was measured: no gain, the sampled
 // tiles are throughput, not a tail -- gpurun_out/r6f.)  XACT: exact softmax arguments
+// The Hessian sums of a sampled tile are split over PLM_HESS_PARTS(Q) workgroups by ROWS of the upper triangle (each takes
+// a third of the entries; all of them redo the tile's softmax, which is the cheap part): a sampled workgroup was 120 us of
+// serial work on one CU -- the whole launch lasted as long as ONE of them, whatever the shard size (round 6: 0.12 ms of
+// every Hessian position at 1 GPU and at 8).  Entry index of (a, b >= a): E(a) + b - a, E(a) = a Q - a (a - 1) / 2.
+#define PLM_HESS_PARTS(Q) (((Q) == 20 || (Q) == 21) ? 3 : 1)
+template <int Q> __host__ __device__ constexpr int hess_entry0(int a) { return a * Q - a * (a - 1) / 2; }
+template <int Q> __host__ __device__ constexpr int hess_row_begin(int part) {      // first row of part `part` of PLM_HESS_PARTS(Q)
+    if (part <= 0) return 0;
+    if (part >= PLM_HESS_PARTS(Q)) return Q;
+    int a = 0;
+    while (a < Q && hess_entry0<Q>(a) * PLM_HESS_PARTS(Q) < part * (Q * (Q + 1) / 2)) a++;
+    return a;
+}
+template <int Q> __host__ __device__ constexpr int hess_part_entries() {           // most entries any part holds
+    int m = 0;
+    for (int p = 0; p < PLM_HESS_PARTS(Q); p++) {
+        const int n = hess_entry0<Q>(hess_row_begin<Q>(p + 1)) - hess_entry0<Q>(hess_row_begin<Q>(p));
+        m = n > m ? n : m;
+    }
+    return m;
+}
 template <int Q, bool WRITE_RT, int STATS, bool XACT>
 __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NH = (STATS == 2) ? Q * (Q + 1) / 2 : 0;
+    constexpr int NSP = (STATS == 2) ? PLM_HESS_PARTS(Q) : 1;                 // row parts of a sampled tile's Hessian sums
+    constexpr int NHP = (STATS == 2) ? hess_part_entries<Q>() : 0;            // LDS entries per wave and site
     if (!vp_runs(A.state, A.cond)) return;
     if (A.state) A.h += (size_t)((const PlmVpState *)A.state)->cur * A.hstride;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
     const int ns1 = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
-    const int sel = A.sel, bid = blockIdx.x;
+    const int sel = A.sel;
+    const int part = (int)blockIdx.x % NSP, bid = (int)blockIdx.x / NSP;      // (NSP = 1 outside the sampled launch)
+    int row_lo = 0, row_hi = Q;
+    if constexpr (NSP > 1) {
+        row_lo = part == 0 ? 0 : (part == 1 ? hess_row_begin<Q>(1) : hess_row_begin<Q>(2));
+        row_hi = part == 0 ? hess_row_begin<Q>(1) : (part == 1 ? hess_row_begin<Q>(2) : Q);
+    }
+    const int ent_lo = row_lo * Q - row_lo * (row_lo - 1) / 2, ent_hi = row_hi * Q - row_hi * (row_hi - 1) / 2;
     const int nst = sel == 0 ? d.nstiles : (sel == 1 ? ns1 : d.nstiles - ns1);
     const int kt = bid % nst, b16l = bid / nst;
     // a statistics pass of the chain leaves quiet blocks alone (PlmVpState::quiet; wave-uniform, scalar cache)
@@ -1538,7 +1568,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     // The statistics-only instantiations keep the hi / lo pairs in LDS instead ([site][state] float2, read per sequence):
     // 42 registers less puts them under 128 -- TWO workgroups per CU, whose load and compute phases overlap (round 6)
     constexpr bool LDSF = !WRITE_RT && !XACT && (STATS != 2 || Q > 21);     // (21 states: the sampled tiles are one workgroup per CU by LDS anyway)
-    constexpr size_t STAT_BYTES = (size_t)16 * (8 * Q * sizeof(double) * (DIAG ? 2 : 1) + HW * NH * sizeof(float));
+    constexpr size_t STAT_BYTES = (size_t)16 * (8 * Q * sizeof(double) * (DIAG ? 2 : 1) + HW * NHP * sizeof(float));
     float2 *lf = (float2 *)(smem + STAT_BYTES);
     if constexpr (LDSF) {
         for (int k = tid; k < 16 * Q; k += 512) {
@@ -1557,12 +1587,12 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     double *lg = (double *)smem + ((size_t)wave * 16 + r) * Q;
     double *ld = lg + (size_t)8 * 16 * Q;             // DIAG: a second f64 area behind the gradient sums
     float *lh0 = (float *)((double *)smem + (size_t)8 * 16 * Q * (DIAG ? 2 : 1));
-    float *ls = lh0 + ((size_t)wave * 16 + r) * NH;   // (waves below HW only)
+    float *ls = lh0 + ((size_t)wave * 16 + r) * NHP;  // (waves below HW only; this part's entries, from ent_lo)
     if (STATS) {      // every wave clears what IT accumulates into: no barrier needed
         for (int k = lane; k < 16 * Q; k += 64) ((double *)smem)[(size_t)wave * 16 * Q + k] = 0.0;
         if constexpr (sampled)
             if (wave < HW)
-                for (int k = lane; k < 16 * NH; k += 64) lh0[(size_t)wave * 16 * NH + k] = 0.f;
+                for (int k = lane; k < 16 * NHP; k += 64) lh0[(size_t)wave * 16 * NHP + k] = 0.f;
         if constexpr (DIAG)
             for (int k = lane; k < 16 * Q; k += 64) ((double *)smem)[(size_t)(8 + wave) * 16 * Q + k] = 0.0;
     }
@@ -1671,7 +1701,11 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                 }
                 // Q gradient sums: the 4 lanes of a site add straight into LDS (f64, one ds_add_f64, resolved in
                 // lane order); the Hessian sums below are reduced in registers first
-                unsafeAtomicAdd(&lg[a], (double)ga);
+#ifndef PLM_EXP_NOGRAD
+                if (NSP == 1 || part == 0) unsafeAtomicAdd(&lg[a], (double)ga);      // (one part of a sampled tile delivers them)
+#else
+                fxl += ga;
+#endif
                 if constexpr (DIAG) {
                     float da = 0.f;                                           // sum_k w P_a^2, P_a = acc + [x = a]
 #pragma unroll
@@ -1679,14 +1713,19 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                         const bool obs = xk[k] == a;
                         da = fmaf(t[k] + (obs ? wk[k] : 0.f), acc[a][k] + (obs ? 1.f : 0.f), da);
                     }
+#ifndef PLM_EXP_NOGRAD
                     unsafeAtomicAdd(&ld[a], (double)da);
+#else
+                    fxl += da;
+#endif
                 }
-                if (STATS == 2 && wave < HW) {
+#ifndef PLM_EXP_NOHESS
+                if (STATS == 2 && wave < HW && a >= row_lo && a < row_hi) {
                     // Hessian sums M_ab = sum_s w P_a P_b from every PLM_HESS_SAMPLE-th sequence tile only (scaled up
                     // by k_hsolve): the Newton iteration tolerates a few per cent of sampling error in H, the
                     // gradient sums above stay exact.  (Taking the diagonal M_aa from every tile buys nothing:
                     // H_aa = sum_b M_ab - M_aa + 2 lambda_h, it cancels.)
-                    idx = a * Q - a * (a - 1) / 2;
+                    idx = a * Q - a * (a - 1) / 2 - ent_lo;
 #pragma unroll
                     for (int k = 0; k < 4; k++) t[k] += (xk[k] == a) ? wk[k] : 0.f;     // w P(a)
 #pragma unroll
@@ -1694,11 +1733,18 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                         float v = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; k++) v = fmaf(t[k], acc[b][k] + ((xk[k] == b) ? 1.f : 0.f), v);
+#ifndef PLM_EXP_NOSWAP
                         v = sum_over_g(v);
+#endif
+#ifndef PLM_EXP_NOLDS
                         if (g == 0) __builtin_amdgcn_ds_faddf(LDS_FPTR(&ls[idx]), v, 0, 0, false);
+#else
+                        fxl += v;
+#endif
                         ++idx;
                     }
                 }
+#endif
             }
         }
         if constexpr (WRITE_RT) {
@@ -1763,12 +1809,14 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     }
     __syncthreads();
     if constexpr (STATS != 0) {
-        double *gout = A.gpart + (size_t)blk * 16 * Q;
-        for (int k = tid; k < 16 * Q; k += 512) {
-            double v = 0;
+        if (NSP == 1 || part == 0) {
+            double *gout = A.gpart + (size_t)blk * 16 * Q;
+            for (int k = tid; k < 16 * Q; k += 512) {
+                double v = 0;
 #pragma unroll
-            for (int wv = 0; wv < 8; wv++) v += ((const double *)smem)[(size_t)wv * 16 * Q + k];
-            gout[k] = v;
+                for (int wv = 0; wv < 8; wv++) v += ((const double *)smem)[(size_t)wv * 16 * Q + k];
+                gout[k] = v;
+            }
         }
         if constexpr (DIAG) {
             double *dout = A.dpart + (size_t)blk * 16 * Q;
@@ -1781,11 +1829,13 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
         }
         if constexpr (sampled) {
             float *out = A.hpart + (size_t)blk * 16 * NH;
-            for (int k = tid; k < 16 * NH; k += 512) {
+            const int ne = ent_hi - ent_lo;                       // this part's entries of every site
+            for (int k = tid; k < 16 * ne; k += 512) {
+                const int site = k / ne, e = k - site * ne;
                 float v = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < HW; wv++) v += lh0[(size_t)wv * 16 * NH + k];
-                out[k] = v;
+                for (int wv = 0; wv < HW; wv++) v += lh0[((size_t)wv * 16 + site) * NHP + e];
+                out[site * NH + ent_lo + e] = v;
             }
         }
     }
@@ -1805,9 +1855,9 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
                 hpart, gpart, d.rscale, dpart, state, cond, 0};
 #define HP_LAUNCH(QQ, WW, SS)                                                                          \
     {                                                                                                  \
-        const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 : d.nstiles - ns1)) * nb);         \
+        const dim3 grid((A.sel == 0 ? d.nstiles : (A.sel == 1 ? ns1 * ((SS) == 2 ? PLM_HESS_PARTS(QQ) : 1) : d.nstiles - ns1)) * nb); \
         const size_t lds = (size_t)16 * (8 * (QQ) * sizeof(double) * (((SS) == 3 || ((SS) == 2 && (QQ) > 21)) ? 2 : 1) + \
-                                         ((SS) == 2 ? ((QQ) > 21 ? 2 : 8) * ((QQ) * ((QQ) + 1) / 2) : 0) * sizeof(float)) + \
+                                         ((SS) == 2 ? ((QQ) > 21 ? 2 : 8) * hess_part_entries<QQ>() : 0) * sizeof(float)) + \
                            (size_t)16 * (QQ) * sizeof(float2);      /* + the fields as hi / lo pairs */     \
         {                                                                                              \
             hipError_t e = exact ? plm_allow_lds<k_hpass<QQ, WW, SS, true>>(lds) : plm_allow_lds<k_hpass<QQ, WW, SS, false>>(lds); \
@@ -1823,7 +1873,9 @@ hipError_t plm_launch_hpass(const PlmDims &d, const float *hj, const int8_t *msa
         else if (write_rt) HP_LAUNCH(QQ, true, 1)                                                      \
         else if (stats == 2) {                                                                         \
             if (!dpart) return hipErrorInvalidValue;                                                   \
-            A.sel = 1;     /* the sampled tiles first: long workgroups, one per CU */                   \
+            /* the sampled tiles: one round of workgroups (a side stream for them, beside the pass over the others, was \
+               measured in round 6: no gain -- gpurun_out/r6: fields 2.31 against 2.24 ms) */             \
+            A.sel = 1;                                                                                 \
             HP_LAUNCH(QQ, false, 2)                                                                    \
             A.sel = 2;                                                                                 \
             if (d.nstiles > ns1) HP_LAUNCH(QQ, false, 3)                                               \

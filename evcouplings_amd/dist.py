@@ -26,14 +26,16 @@ import numpy as np
 
 def shard_blocks(n_sites, n_shards):
     """Column-block partition used by the library (plm_internal.h plm_shard_lo / plm_shard_cnt): list of (lo, hi)
-    16-site block ranges, one per shard -- balanced: the first nb16 % n_shards shards own one block more
-    (19 blocks on 8 GPUs: 3,3,3,2,2,2,2,2); shards are empty only when there are more shards than blocks."""
+    16-site block ranges, one per shard -- balanced: the LAST nb16 % n_shards shards own one block more
+    (19 blocks on 8 GPUs: 2,2,2,2,2,3,3,3 -- the low shards own the long rows of the block-pair triangle, so the surplus
+    column blocks go to the high ones); shards are empty only when there are more shards than blocks."""
     nb16 = (n_sites + 15) // 16
     base, rem = divmod(nb16, n_shards)
-    out = []
+    out, lo = [], 0
     for r in range(n_shards):
-        lo = r * base + min(r, rem)
-        out.append((lo, lo + base + (1 if r < rem else 0)))
+        cnt = base + (1 if r >= n_shards - rem else 0)
+        out.append((lo, lo + cnt))
+        lo += cnt
     return out
 
 

@@ -540,6 +540,13 @@ class PlmContext:
                 # the two GEMMs as the fit ran them (HIP events inside the fit; plain arithmetic only)
                 "gemm_evaluations": int(out[4]), "forward_ms_per_evaluation": out[5] / gv, "backward_ms_per_evaluation": out[6] / gv}
 
+    def time_field_positions(self, reps=5):
+        """ms of one Hessian position and of the closing (residual-writing) position of the field solver's chain on this
+        context's site blocks (plm_ctx_time_field_positions; call time_kernels first)"""
+        ms = np.zeros(2, np.float32)
+        check(self.lib.plm_ctx_time_field_positions(self._h, int(reps), _ptr(ms)))
+        return {"hessian_position": float(ms[0]), "closing_position": float(ms[1])}
+
     def time_kernels(self, reps=5):
         ms = np.zeros(_lib.K_COUNT, np.float32)
         check(self.lib.plm_ctx_time_kernels(self._h, int(reps), _ptr(ms)))

@@ -335,6 +335,12 @@ int plm_ctx_scores(plm_ctx_t *ctx, float *fn_host, float *cn_host);
 #define PLM_K_LBFGS_VECTOR 8       /* the L-BFGS vector kernels of one iteration (m = 6) on this context's share of the state */
 #define PLM_K_COUNT 9
 int plm_ctx_time_kernels(plm_ctx_t *ctx, int32_t reps, float *out_ms /* [PLM_K_COUNT] */);
+/* The two kinds of position of the field solver's chain, timed alone on this context's site blocks (after
+ * plm_ctx_time_kernels, whose forward GEMM left the potentials): out_ms[0] = a Hessian position (pass with gradient,
+ * diagonal and sampled Hessian sums + per-site Newton step), out_ms[1] = the closing position (pass that writes the
+ * residual planes + gradient sums, norm check).  scripts/shard_compute.py prices a chain of p passes as
+ * (p - 1) out_ms[0] + out_ms[1]. */
+int plm_ctx_time_field_positions(plm_ctx_t *ctx, int32_t reps, float *out_ms /* [2] */);
 /* Field-solver statistics of the last plm_ctx_optimize on this context (variable-projection fits; zeros otherwise),
  * measured with HIP events on the context's stream around the solver of every evaluation: bench.py reports the average
  * field-solver time per evaluation of its timed window from these. */
