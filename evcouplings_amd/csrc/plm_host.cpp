@@ -191,16 +191,31 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     d.own_hi = d.sharded ? d.b16_hi : d.nb16;
     d.nblk_own = d.own_hi - d.own_lo;
     d.h_site0 = d.own_lo * 16;
-    d.bp_base = plm_bp_index(d.own_lo, d.own_lo, d.nb16);
-    d.np_own = plm_bp_index(d.own_hi, d.own_hi, d.nb16) - d.bp_base;
+    d.bp_base = 0;
+    for (int p = 0; p < PLM_MAX_SHARDS; p++) d.halo_base[p] = -1;
+    d.nx_halo = d.ng_halo = 0;
+    if (d.sharded) {
+        if (nshards > PLM_MAX_SHARDS) return fail(PLM_EUNSUPPORTED, "sharded-state mode takes at most %d shards", PLM_MAX_SHARDS);
+        d.ntri = d.nblk_own * (d.nblk_own + 1) / 2;
+        // rectangles shared with the other shards, each kind numbered in partner order (plm_internal.h)
+        for (int p = 0; p < nshards; p++) {
+            if (p == d.shard) continue;
+            const int64_t n = (int64_t)d.nblk_own * plm_shard_cnt(d, p);
+            const bool mine = plm_rect_owner(std::min(p, d.shard), std::max(p, d.shard)) == d.shard;
+            d.halo_base[p] = (int)(mine ? d.ng_halo : d.nx_halo);
+            (mine ? d.ng_halo : d.nx_halo) += n;
+        }
+        d.np_own = d.ntri + d.ng_halo;
+    } else {
+        d.np_own = d.nbp;
+        d.ntri = (int)d.nbp;
+    }
     {
         const int site_end = std::min(d.L, d.own_hi * 16);
         const int64_t nhl = (int64_t)std::max(0, site_end - d.h_site0) * d.Q;
         d.nh_pad_l = d.sharded ? std::max<int64_t>(256, (nhl + 255) / 256 * 256) : d.nh_pad;
     }
     d.n_local = d.nh_pad_l + d.np_own * d.Q * d.Q * 256;
-    d.nx_halo = (int64_t)d.own_lo * d.nblk_own;
-    d.ng_halo = (int64_t)d.nblk_own * (d.nb16 - d.own_hi);
     if (d.gap_mode && d.Qc < 3) return fail(PLM_EINVAL, "ignore_gaps needs at least 2 non-gap states");
     *out = d;
     return PLM_OK;
@@ -404,12 +419,15 @@ int forward_at_x(plm_ctx *c) {
     return PLM_OK;
 }
 
-// sharded-state evaluation: local x (+ halo from lower shards) -> local g; scal[0..1] = this shard's
+// The coupling message of the sharded-state mode needs no packing: the rectangles this shard owns lie behind the triangle
+// of its local vector, in partner order, each exactly as the partner expects it in its halo.
+float *x_rectangles(plm_ctx *c) { return c->x + c->d.nh_pad_l + (size_t)c->d.ntri * PLM_BLOCK_FLOATS(c->d); }
+
+// sharded-state evaluation: local x (+ halo from the partners) -> local g; scal[0..1] = this shard's
 // part of fx and nll (summed over shards by the caller together with its dot products)
 int ctx_eval_enqueue_sharded(plm_ctx *c) {
     const PlmDims &d = c->d;
-    HIP_TRY(plm_launch_pack_x(d, c->x, c->xsend, c->st));
-    PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
+    PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, x_rectangles(c), c->xhalo, c->x_send.data(), c->x_recv.data()));
     HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
                                d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, d.jexp_bias, c->st));
     HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
@@ -505,8 +523,7 @@ int vp_stage1(plm_ctx *c) {
     const PlmDims &d = c->d;
     PLM_TRY(vp_counts(c));
     if (d.sharded) {
-        HIP_TRY(plm_launch_pack_x(d, c->x, c->xsend, c->st));
-        PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, c->xsend, c->xhalo, c->x_send.data(), c->x_recv.data()));
+        PLM_TRY(ctx_collective(c, PLM_COLL_ALLTOALL, x_rectangles(c), c->xhalo, c->x_send.data(), c->x_recv.data()));
         HIP_TRY(plm_launch_maxabs2(c->x + d.nh_pad_l, d.n_local - d.nh_pad_l, c->xhalo,
                                    d.nx_halo * (int64_t)PLM_BLOCK_FLOATS(d), c->maxbits, c->jexp, d.jexp_bias, c->st));
         HIP_TRY(plm_launch_expand(d, c->x, c->xhalo, c->jexp, c->Bt, c->fwd_accurate ? 1 : 0, c->st));
@@ -928,17 +945,17 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     if (d.sharded) {
         const size_t blk = PLM_BLOCK_FLOATS(d);
         if ((rc = dalloc(&c->xhalo, (size_t)d.nx_halo * blk)) || (rc = dalloc(&c->gsend, (size_t)d.nx_halo * blk)) ||
-            (rc = dalloc(&c->ghalo, (size_t)d.ng_halo * blk)) || (rc = dalloc(&c->xsend, (size_t)d.ng_halo * blk)))
+            (rc = dalloc(&c->ghalo, (size_t)d.ng_halo * blk)))
             return bail(rc);
-        // all-to-all byte counts: blocks exchanged with shard r = (own blocks) x (blocks of r), towards
-        // higher shards for couplings, towards lower shards for gradient fragments
+        // all-to-all byte counts: with shard r this shard shares the rectangle (own blocks) x (blocks of r); its owner
+        // (plm_rect_owner) sends the couplings and receives the partner's gradient fragments
         c->x_send.assign(d.nshards, 0); c->x_recv.assign(d.nshards, 0);
         c->g_send.assign(d.nshards, 0); c->g_recv.assign(d.nshards, 0);
         for (int r = 0; r < d.nshards; r++) {
-            const int lo = plm_shard_lo(d, r), hi = lo + plm_shard_cnt(d, r);
-            const int64_t bytes = (int64_t)d.nblk_own * (hi - lo) * (int64_t)blk * 4;
-            if (r > d.shard) { c->x_send[r] = bytes; c->g_recv[r] = bytes; }
-            if (r < d.shard) { c->x_recv[r] = bytes; c->g_send[r] = bytes; }
+            if (r == d.shard) continue;
+            const int64_t bytes = (int64_t)d.nblk_own * plm_shard_cnt(d, r) * (int64_t)blk * 4;
+            if (plm_rect_owner(std::min(r, d.shard), std::max(r, d.shard)) == d.shard) { c->x_send[r] = bytes; c->g_recv[r] = bytes; }
+            else { c->x_recv[r] = bytes; c->g_send[r] = bytes; }
         }
     }
     hipError_t e;
@@ -1246,26 +1263,15 @@ int plm_ctx_set_x(plm_ctx_t *c, const float *x_canonical_host) {
 // shard contributes its own entries and an all-reduce (sum) puts the whole vector on every rank
 static int canon_full(plm_ctx_t *c, const float *native) {
     const PlmDims &d = c->d;
+    if (d.sharded) HIP_TRY(hipMemsetAsync(c->canon, 0, sizeof(float) * d.n_canon, c->st));
     HIP_TRY(plm_launch_native_to_canon(d, native, c->canon, c->st));
     if (d.sharded) {
-        // all-gather of the parameter slices: in the canonical order (fields by site, couplings by pair i<j, i
-        // major) the entries a shard owns -- the fields of its sites, the pairs whose first site is one of them --
-        // are two contiguous ranges, so every shard broadcasts its two ranges in place
-        const int64_t L = d.L, QQ = (int64_t)d.Qc * d.Qc;
-        auto pairs_before = [&](int64_t i) { return i * (2 * L - i - 1) / 2; };    // pairs (i', j) with i' < i
-        for (int r = 0; r < d.nshards; r++) {
-            const int64_t s0 = std::min<int64_t>(L, 16 * (int64_t)plm_shard_lo(d, r));
-            const int64_t s1 = std::min<int64_t>(L, 16 * (int64_t)(plm_shard_lo(d, r) + plm_shard_cnt(d, r)));
-            const int64_t hb = (s1 - s0) * d.Qc * (int64_t)sizeof(float);
-            const int64_t jb = (pairs_before(s1) - pairs_before(s0)) * QQ * (int64_t)sizeof(float);
-            // the callback contract hands over count arrays of n_shards entries
-            const std::vector<int64_t> roots(d.nshards, r), hbv(d.nshards, hb), jbv(d.nshards, jb);
-            if (hb > 0)
-                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + s0 * d.Qc, nullptr, hbv.data(), roots.data()));
-            if (jb > 0)
-                PLM_TRY(ctx_collective(c, PLM_COLL_BROADCAST, c->canon + L * d.Qc + pairs_before(s0) * QQ, nullptr,
-                                       jbv.data(), roots.data()));
-        }
+        // all-gather of the parameter slices.  Every shard has written the entries IT owns into a zeroed canonical vector;
+        // the sum over the shards is the whole vector on every rank (exact: every entry has one non-zero term).  (Round
+        // 5 broadcast two contiguous ranges per shard; with the rectangles split between the shards the own entries are
+        // no longer contiguous in the canonical order.)
+        const int64_t bytes = (int64_t)sizeof(float) * d.n_canon;
+        PLM_TRY(ctx_collective(c, PLM_COLL_ALLREDUCE_F32, c->canon, c->canon, &bytes, &bytes));
     }
     return PLM_OK;
 }

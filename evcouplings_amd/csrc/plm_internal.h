@@ -26,6 +26,7 @@
 #include <stddef.h>
 #include <hip/hip_runtime.h>
 
+#define PLM_MAX_SHARDS 16     // sharded-state mode: shards of one problem (PlmDims carries a table per partner)
 #define PLM_PAD_STATE 127
 #define PLM_SEQ_TILE 256      // sequences per forward workgroup (8 waves x 32)
 #define PLM_R_EXP 14          // forward operand: couplings are stored scaled by 2^(14 - exponent of max|J|)
@@ -93,9 +94,13 @@ struct PlmDims {
     int jexp_bias;     // measurement knob (PlmOptions::jexp_bias): added to the scale exponent of the forward operand
     int conv;          // PLM_CONV_* convention switches (include/plm_hip.h)
     double theta;      // identity threshold (PLM_CONV_G_UNGAPPED_LENGTH evaluates it per pair)
-    // ---- sharded-state mode (PLM_FLAG_SHARDED_STATE): parameters, gradient and L-BFGS vectors are
-    // split by owning site block; the "local" vector is [h of own sites | pairs (I own, J >= I)].
-    // In every other mode the local vector IS the native vector (own_lo = 0, own_hi = nb16).
+    // ---- sharded-state mode (PLM_FLAG_SHARDED_STATE): parameters, gradient and L-BFGS vectors are split over the shards;
+    // the "local" vector is [h of own sites | own block pairs].  Own block pairs (round 6: balanced): the TRIANGLE of
+    // pairs (I <= J) with both blocks own, then whole RECTANGLES of pairs shared with another shard p -- the rectangle
+    // of shards s < t belongs to s when t - s is odd, else to t (plm_rect_owner), so every shard owns about half of
+    // its rectangles (round 5: all of them went to the lower shard -- shard 0 of 8 held 23 % of the state at L = 500,
+    // the last one 2 %).  Inside a rectangle pairs are numbered (I - lo_s) * n_t + (J - lo_t); rectangles follow each
+    // other in partner order.  In every other mode the local vector IS the native vector (own_lo = 0, own_hi = nb16).
     int sharded;       // 1 in sharded-state mode
     int own_lo, own_hi;   // blocks whose parameters live in the local vector
     int nblk_own;      // own_hi - own_lo
@@ -104,8 +109,14 @@ struct PlmDims {
     int64_t np_own;    // own block pairs
     int64_t nh_pad_l;  // local field part, padded to 256 floats
     int64_t n_local;   // nh_pad_l + np_own*Q*Q*256
-    int64_t nx_halo;   // coupling blocks received per evaluation: own_lo * nblk_own   (pairs (J'<own_lo, I own))
-    int64_t ng_halo;   // gradient blocks received per evaluation: nblk_own * (nb16 - own_hi)
+    int64_t nx_halo;   // coupling blocks received per evaluation: the rectangles that belong to the partner
+    int64_t ng_halo;   // gradient blocks received per evaluation: the rectangles that belong to this shard
+    int ntri;          // own pairs with both blocks own: nblk_own (nblk_own + 1) / 2 (all of them outside sharded-state mode)
+    // per partner shard p: first block of its rectangle among the rectangles of the same kind, in partner order -- for a
+    // rectangle this shard owns: its place behind the triangle in the local vector (ntri + halo_base[p]) = in the coupling
+    // message sent to p = in ghalo (p's gradient fragments); for one that p owns: its place in xhalo (p's couplings) = in
+    // the gradient message sent to p.  -1: p is this shard, or has no blocks.
+    int halo_base[PLM_MAX_SHARDS];
 };
 
 // Environment knobs of the library, read ONCE per context (plm_options_from_env, plm_host.cpp) -- nothing on the
@@ -145,6 +156,48 @@ static inline __host__ __device__ int plm_shard_of(const PlmDims &d, int b) {
 }
 static inline __host__ __device__ int64_t plm_bp_index(int I, int J, int nb16) { // I <= J
     return (int64_t)I * nb16 - (int64_t)I * (I - 1) / 2 + (J - I);
+}
+// sharded-state mode: which of the shards s < t owns the rectangle of block pairs between them
+static inline __host__ __device__ int plm_rect_owner(int s, int t) { return ((t - s) & 1) ? s : t; }
+// Local number of the block pair (I <= J) among this context's own pairs, or -1; for a pair this shard does not own but
+// whose couplings it needs (one of the blocks is an own column block) *halo = its place in xhalo (else -1).
+static inline __host__ __device__ int64_t plm_pair_local(const PlmDims &d, int I, int J, int *halo) {
+    if (halo) *halo = -1;
+    if (!d.sharded) return plm_bp_index(I, J, d.nb16);
+    const int sI = plm_shard_of(d, I), sJ = plm_shard_of(d, J);
+    if (sI == d.shard && sJ == d.shard) {
+        const int r = I - d.own_lo;
+        return (int64_t)r * d.nblk_own - (int64_t)r * (r - 1) / 2 + (J - I);
+    }
+    if (sI != d.shard && sJ != d.shard) return -1;
+    const int p = sI == d.shard ? sJ : sI;
+    const int idx = d.halo_base[p] + (I - plm_shard_lo(d, sI)) * plm_shard_cnt(d, sJ) + (J - plm_shard_lo(d, sJ));
+    if (plm_rect_owner(sI, sJ) == d.shard) return (int64_t)d.ntri + idx;
+    if (halo) *halo = idx;
+    return -1;
+}
+// ... and back: the blocks (I <= J) of own pair number k
+static inline __host__ __device__ void plm_pair_of_local(const PlmDims &d, int64_t k, int *I, int *J) {
+    if (k < d.ntri) {                                   // the triangle over the own blocks, row major
+        int r = 0;
+        while (k >= d.nblk_own - r) { k -= d.nblk_own - r; r++; }
+        *I = d.own_lo + r;
+        *J = d.own_lo + r + (int)k;
+        return;
+    }
+    k -= d.ntri;
+    for (int p = 0; p < d.nshards; p++) {
+        if (p == d.shard || plm_rect_owner(p < d.shard ? p : d.shard, p < d.shard ? d.shard : p) != d.shard) continue;
+        const int np = plm_shard_cnt(d, p);
+        const int64_t n = (int64_t)d.nblk_own * np;
+        if (k < n) {
+            if (d.shard < p) { *I = d.own_lo + (int)(k / np); *J = plm_shard_lo(d, p) + (int)(k % np); }
+            else { *I = plm_shard_lo(d, p) + (int)(k / d.nblk_own); *J = d.own_lo + (int)(k % d.nblk_own); }
+            return;
+        }
+        k -= n;
+    }
+    *I = *J = 0;      // not reached for k < np_own
 }
 static inline __host__ __device__ int64_t plm_pair_index(int i, int j, int L) { // i < j
     return (int64_t)i * (2 * L - i - 1) / 2 + (j - i - 1);
@@ -258,7 +311,6 @@ hipError_t plm_launch_assemble(const PlmDims &d, const void *G, int ks_count, co
 hipError_t plm_launch_pair_norms(const PlmDims &d, const float *x, float *n2, hipStream_t st);
 // sharded-state exchange staging: blocks of Q*Q*256 floats
 #define PLM_BLOCK_FLOATS(d) ((size_t)(d).Q * (d).Q * 256)
-hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, hipStream_t st);
 hipError_t plm_launch_pack_g(const PlmDims &d, const int32_t *G, float *sendbuf, hipStream_t st);
 hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_t nb, uint32_t *maxbits,
                               int32_t *jexp, int jexp_bias, hipStream_t st);

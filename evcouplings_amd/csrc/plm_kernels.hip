@@ -573,7 +573,15 @@ __global__ __launch_bounds__(256) void k_maxabs(const float *__restrict__ x, int
     for (int64_t i = (n / 4) * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
     for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
+    // ONE atomic per workgroup (round 6: one per wave of 1024 workgroups were 4096 atomics on one address -- 50 of the
+    // kernel's 57 us at the headline, and as many on a shard with an eighth of the vector)
+    __shared__ u32 wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 t = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (t) atomicMax(maxbits, t);
+    }
 }
 // bias (PlmOptions::jexp_bias, measurement knob): added to the scale exponent of the coupling operand.  A different
 // power-of-two pre-scale moves every hi/lo split point and every f32 rounding of the forward GEMM without
@@ -591,8 +599,8 @@ hipError_t plm_launch_maxabs2(const float *a, int64_t na, const float *b, int64_
                               int jexp_bias, hipStream_t st) {
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(u32), st);
     if (e != hipSuccess) return e;
-    if (na > 0) hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, a, na, maxbits);
-    if (nb > 0) hipLaunchKernelGGL(k_maxabs, dim3(256), dim3(256), 0, st, b, nb, maxbits);
+    if (na > 0) hipLaunchKernelGGL(k_maxabs, dim3((unsigned)std::min<int64_t>(512, (na / 4 + 255) / 256 + 1)), dim3(256), 0, st, a, na, maxbits);
+    if (nb > 0) hipLaunchKernelGGL(k_maxabs, dim3((unsigned)std::min<int64_t>(256, (nb / 4 + 255) / 256 + 1)), dim3(256), 0, st, b, nb, maxbits);
     hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, jexp_bias);
     return hipGetLastError();
 }
@@ -600,7 +608,7 @@ hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(u32), st);
     if (e != hipSuccess) return e;
     const int64_t n = d.n_local - d.nh_pad_l;
-    hipLaunchKernelGGL(k_maxabs, dim3(1024), dim3(256), 0, st, x + d.nh_pad_l, n, maxbits);
+    hipLaunchKernelGGL(k_maxabs, dim3((unsigned)std::min<int64_t>(512, (n / 4 + 255) / 256 + 1)), dim3(256), 0, st, x + d.nh_pad_l, n, maxbits);
     hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, st, maxbits, jexp, d.jexp_bias);
     return hipGetLastError();
 }
@@ -613,18 +621,20 @@ hipError_t plm_launch_maxabs(const PlmDims &d, const float *x, u32 *maxbits, int
 __device__ __forceinline__ float load_coupling(const PlmDims &d, const float *__restrict__ xj,
                                                const float *__restrict__ xhalo, int I, int ii, int a, int J, int jj,
                                                int b) {
-    // coupling between (site 16I+ii, state a) and (site 16J+jj, state b); I is one of this shard's column
-    // blocks.  xj = coupling part of the LOCAL vector (own pairs, offset by bp_base); pairs (J, I) with
-    // J below the own range live in the halo received from their owner (sharded-state mode only).
+    // coupling between (site 16I+ii, state a) and (site 16J+jj, state b); I is one of this shard's column blocks.
+    // xj = coupling part of the LOCAL vector (own block pairs, plm_pair_local); a pair that belongs to the other shard
+    // (sharded-state mode) lies in the halo received from it, same block layout.  A block (lo <= hi) holds
+    // [a_lo][b_hi][ii_lo][jj_hi].
     const int QQ = d.Q * d.Q;
-    if (I < J) return xj[((plm_bp_index(I, J, d.nb16) - d.bp_base) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
-    if (I > J) {
-        if (J >= d.own_lo) return xj[((plm_bp_index(J, I, d.nb16) - d.bp_base) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
-        return xhalo[(((size_t)J * d.nblk_own + (I - d.own_lo)) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
+    if (I == J) {
+        if (ii == jj) return 0.f;
+        const float *blk = xj + (size_t)plm_pair_local(d, I, I, nullptr) * QQ * 256;
+        return ii < jj ? blk[(a * d.Q + b) * 256 + ii * 16 + jj] : blk[(b * d.Q + a) * 256 + jj * 16 + ii];
     }
-    if (ii < jj) return xj[((plm_bp_index(I, I, d.nb16) - d.bp_base) * QQ + a * d.Q + b) * 256 + ii * 16 + jj];
-    if (ii > jj) return xj[((plm_bp_index(I, I, d.nb16) - d.bp_base) * QQ + b * d.Q + a) * 256 + jj * 16 + ii];
-    return 0.f;
+    int h;
+    const int64_t k = plm_pair_local(d, min(I, J), max(I, J), &h);
+    const float *blk = k >= 0 ? xj + (size_t)k * QQ * 256 : xhalo + (size_t)h * QQ * 256;
+    return I < J ? blk[(a * d.Q + b) * 256 + ii * 16 + jj] : blk[(b * d.Q + a) * 256 + jj * 16 + ii];
 }
 // Sparse-MFMA layout (plm_internal.h).  One workgroup writes the two tiles (hi plane, lo plane) of an
 // instruction slice ci of block u.  Tile = for every state a a dense B fragment of v_smfmac_f32_16x16x64_f16, 64
@@ -661,7 +671,9 @@ __global__ __launch_bounds__(256) void k_expand(PlmDims d, const float *__restri
     const float *__restrict__ xj = x + d.nh_pad_l;
     _Float16 *tile_hi = Bt + ((size_t)b16l * d.nu * SPU + (size_t)u * SPU + 2 * ci) * (size_t)(2 * d.Q * 512);
     _Float16 *tile_lo = tile_hi + (size_t)(2 * d.Q * 512);
-    for (int idx = threadIdx.x; idx < d.Q * 64; idx += 256) {
+    // blockIdx.z: a slice of the tile's (state, lane) positions -- one position per thread (round 6: a thread used to walk
+    // 5 of them, 80 dependent gathers; a shard of three column blocks was 300 such workgroups and took as long as 19 blocks)
+    for (int idx = blockIdx.z * 256 + threadIdx.x; idx < d.Q * 64; idx += gridDim.z * 256) {
         const int a = idx >> 6, lane = idx & 63, gb = lane >> 4, r = lane & 15;
         const int i = b16 * 16 + r;
 #pragma unroll
@@ -753,8 +765,8 @@ hipError_t plm_launch_expand(const PlmDims &d, const float *x, const float *xhal
     if (exact)
         hipLaunchKernelGGL(k_expand_x, dim3(d.nu * NG, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp, (char *)Bt);
     else
-        hipLaunchKernelGGL(k_expand, dim3(d.nu * 2 * NG, d.b16_hi - d.b16_lo), dim3(256), 0, st, d, x, xhalo, jexp,
-                           (_Float16 *)Bt);
+        hipLaunchKernelGGL(k_expand, dim3(d.nu * 2 * NG, d.b16_hi - d.b16_lo, (d.Q * 64 + 255) / 256), dim3(256), 0, st, d, x, xhalo,
+                           jexp, (_Float16 *)Bt);
     hipLaunchKernelGGL(k_fwd_ref, dim3(d.b16_hi - d.b16_lo, 16, d.Q), dim3(64), 0, st, d, x, xhalo,
                        (float *)bt_cref32(d, Bt), (double *)bt_cref64(d, Bt));
     return hipGetLastError();
@@ -2750,11 +2762,8 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restr
                                                  const float *__restrict__ pair_n2, float lambda_g) {
     __shared__ double red[4];
     const int a = blockIdx.y;
-    // decode the own block pair number blockIdx.x (pairs are numbered I-major from (own_lo, own_lo))
-    int I = d.own_lo;
-    int64_t rem = blockIdx.x;
-    while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
-    const int J = I + (int)rem;
+    int I, J;
+    plm_pair_of_local(d, blockIdx.x, &I, &J);
     const int ii = threadIdx.x >> 4, jj = threadIdx.x & 15;
     const int i = I * 16 + ii, j = J * 16 + jj;
     const bool valid = i < d.L && j < d.L && i < j;
@@ -2762,22 +2771,28 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restr
     const int t2 = ((ii >> 2) * 16 + jj) * 4 + (ii & 3);   // element [row=ii][col=jj]
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
     const size_t xoff = d.nh_pad_l + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + threadIdx.x;
-    // sharded-state: the transposed fragments of a pair whose J block belongs to a higher shard arrive
-    // already summed over split-K in ghalo[(J - own_hi) * nblk_own + (I - own_lo)][a][b][256]
-    const bool remote = d.sharded && J >= d.own_hi;
-    const size_t hoff = remote ? (((size_t)(J - d.own_hi) * d.nblk_own + (I - d.own_lo)) * d.Q + a) * d.Q * 256 + t2 : 0;
+    // sharded-state: of the two fragments of a pair in a rectangle shared with another shard, the one over the OTHER
+    // shard's column block arrives, summed over split-K, in ghalo[rectangle pair][a][b][fragment]
+    const bool remote1 = d.sharded && (I < d.own_lo || I >= d.own_hi);      // G[(J,b),(I,a)]: column block I is not own
+    const bool remote2 = d.sharded && (J < d.own_lo || J >= d.own_hi);      // G[(I,a),(J,b)]: column block J is not own
+    const size_t hoff = (remote1 || remote2) ? (((size_t)(blockIdx.x - d.ntri) * d.Q + a) * d.Q) * 256 + (remote1 ? t1 : t2) : 0;
     double reg = 0;
     // group regulariser lambda_g sum_{i<j} sqrt(|J_ij|^2 + delta^2) (plm_hip.h PLM_GROUP_DELTA): gradient lambda_g J / norm
     const float gnorm = (lambda_g > 0.f && valid) ? sqrtf(pair_n2[(size_t)blockIdx.x * 256 + threadIdx.x] +
                                                           (float)(PLM_GROUP_DELTA * PLM_GROUP_DELTA)) : 1.f;
     const float gcoef = (lambda_g > 0.f) ? lambda_g / gnorm : 0.f;
     for (int b = 0; b < d.Q; b++) {
-        const size_t o1 = g_frag(d, ks_count, slab_stride, I, a, J * d.Q + b) + t1;
-        const float v = g_value(G, o1, ks_count, kstride, d.nplanes);
+        float v;
+        if (remote1) {
+            v = ghalo[hoff + (size_t)b * 256];
+        } else {
+            const size_t o1 = g_frag(d, ks_count, slab_stride, I, a, J * d.Q + b) + t1;
+            v = g_value(G, o1, ks_count, kstride, d.nplanes);
+        }
         float out;
         if (mode == 0) {
             float v2 = 0.f;
-            if (remote) {
+            if (remote2) {
                 v2 = ghalo[hoff + (size_t)b * 256];
             } else {
                 const size_t o2 = g_frag(d, ks_count, slab_stride, J, b, I * d.Q + a) + t2;
@@ -2795,6 +2810,118 @@ __global__ __launch_bounds__(256) void k_assemble(PlmDims d, const void *__restr
     if (mode == 0) {
         // the group term of a site pair is counted once: by the block of state a = 0
         const double t = block_reduce_sum((double)lambda_j * reg + ((lambda_g > 0.f && a == 0 && valid) ? (double)lambda_g * gnorm : 0.0), red);
+        if (threadIdx.x == 0) reg_part[(size_t)blockIdx.x * d.Q + a] = t;
+    }
+}
+// k_assemble with 16-byte accesses (round 6; the int32 partials of this shard's own G only -- the gathered float slabs of
+// the replicated multi-shard mode keep k_assemble).  k_assemble reads every accumulator fragment in 4-byte pieces, a
+// wave touching all eight cache lines of a fragment for a quarter of their bytes: 0.21 ms for 0.49 GB at the headline,
+// and as much on a shard of an eighth of the columns, whose K split multiplies the partial slabs.  Here a WAVE takes one
+// state b (b = wave, wave + 4, ...) and reads whole fragments, one int4 / float4 per lane and plane:
+//   * G[(J,b),(I,a)] holds element (row jj, col ii) at ((jj >> 2) * 16 + ii) * 4 + (jj & 3): lane l owns (ii = l & 15,
+//     jj = 4 (l >> 4) + 0..3) -- four neighbours of the output tile row ii: one float4 of x and of the gradient;
+//   * G[(I,a),(J,b)] (or the gradient halo, same layout) holds (row ii, col jj) at ((ii >> 2) * 16 + jj) * 4 + (ii & 3):
+//     lane l reads (ii = 4 (l >> 4) + 0..3, jj = l & 15) and turns them round through 1 KB of LDS per wave.
+// Element by element the arithmetic is k_assemble's (same sums in the same order): the gradient is bit-identical.
+__device__ __forceinline__ void g_combine4(const int *__restrict__ G, size_t off, int ks_count, size_t kstride, int nplanes,
+                                           float (&out)[4]) {
+    const size_t pstride = (size_t)ks_count * kstride;
+    double v[4] = {0.0, 0.0, 0.0, 0.0}, wgt = 1.0;
+    for (int p = 0; p < nplanes; p++) {
+        long long sp[4] = {0, 0, 0, 0};
+        for (int k = 0; k < ks_count; k++) {
+            const int4 q = *(const int4 *)(G + off + p * pstride + k * kstride);
+            sp[0] += q.x; sp[1] += q.y; sp[2] += q.z; sp[3] += q.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += wgt * (double)sp[e];
+        wgt *= 256.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) out[e] = (float)v[e];
+}
+__global__ __launch_bounds__(256) void k_assemble_v(PlmDims d, const int *__restrict__ G, int ks_count,
+                                                   const float *__restrict__ ghalo, const float *__restrict__ x,
+                                                   float *__restrict__ gout, float lambda_j, double *__restrict__ reg_part,
+                                                   int mode, float scale, const float *__restrict__ pair_n2, float lambda_g) {
+    __shared__ double red[4];
+    __shared__ __attribute__((aligned(16))) float turn[4][256];
+    const int a = blockIdx.y;
+    int I, J;
+    plm_pair_of_local(d, blockIdx.x, &I, &J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ii = lane & 15, jq = lane >> 4;                 // output: tile row ii, columns 4 jq .. 4 jq + 3
+    const int i = I * 16 + ii;
+    const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
+    const size_t xbase = d.nh_pad_l + ((size_t)blockIdx.x * d.Q + a) * d.Q * 256 + (size_t)ii * 16 + 4 * jq;
+    // (see k_assemble: the fragment over the other shard's column block comes from the gradient halo, the sender's layout)
+    const bool remote1 = d.sharded && (I < d.own_lo || I >= d.own_hi), remote2 = d.sharded && (J < d.own_lo || J >= d.own_hi);
+    const size_t hbase = (remote1 || remote2) ? (((size_t)(blockIdx.x - d.ntri) * d.Q + a) * d.Q) * 256 + 4 * lane : 0;
+    bool valid[4];
+    float gcoef[4], gnorm[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int j = J * 16 + 4 * jq + e;
+        valid[e] = i < d.L && j < d.L && i < j;
+        gnorm[e] = (lambda_g > 0.f && valid[e]) ? sqrtf(pair_n2[(size_t)blockIdx.x * 256 + ii * 16 + 4 * jq + e] +
+                                                        (float)(PLM_GROUP_DELTA * PLM_GROUP_DELTA)) : 1.f;
+        gcoef[e] = (lambda_g > 0.f) ? lambda_g / gnorm[e] : 0.f;
+    }
+    double reg = 0;
+    const int nb4 = (d.Q + 3) / 4;
+    for (int bb = 0; bb < nb4; bb++) {                       // uniform trip count: the barriers below are workgroup-wide
+        const int b = bb * 4 + wave;
+        const bool on = b < d.Q;
+        float v1[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            if (remote1) {
+                const float4 h = *(const float4 *)(ghalo + hbase + (size_t)b * 256);
+                v1[0] = h.x; v1[1] = h.y; v1[2] = h.z; v1[3] = h.w;
+            } else {
+                g_combine4(G, g_frag(d, ks_count, 0, I, a, J * d.Q + b) + 4 * lane, ks_count, kstride, d.nplanes, v1);
+            }
+            if (mode == 0) {
+                float w2[4];
+                if (remote2) {
+                    const float4 h = *(const float4 *)(ghalo + hbase + (size_t)b * 256);
+                    w2[0] = h.x; w2[1] = h.y; w2[2] = h.z; w2[3] = h.w;
+                } else {
+                    g_combine4(G, g_frag(d, ks_count, 0, J, b, I * d.Q + a) + 4 * lane, ks_count, kstride, d.nplanes, w2);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) turn[wave][(4 * jq + e) * 16 + ii] = w2[e];     // (row 4 (l >> 4) + e, col l & 15)
+            }
+        }
+        __syncthreads();
+        if (on && mode == 0) {
+            const float4 t = *(const float4 *)&turn[wave][ii * 16 + 4 * jq];
+            v2[0] = t.x; v2[1] = t.y; v2[2] = t.z; v2[3] = t.w;
+        }
+        __syncthreads();
+        if (on) {
+            float o[4];
+            if (mode == 0) {
+                const float4 xv4 = *(const float4 *)(x + xbase + (size_t)b * 256);
+                const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool live = valid[e] && !(d.gap_mode && (a == 0 || b == 0)) && a < d.Qc && b < d.Qc;
+                    o[e] = live ? fmaf(scale, v1[e] + v2[e], (2.f * lambda_j + gcoef[e]) * xv[e]) : 0.f;
+                    if (live) reg += (double)xv[e] * (double)xv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = valid[e] ? scale * v1[e] : 0.f;
+            }
+            *(float4 *)(gout + xbase + (size_t)b * 256) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (mode == 0) {
+        double grp = 0;      // the group term of a site pair is counted once: by the workgroup of state a = 0, wave 0
+        if (lambda_g > 0.f && a == 0 && wave == 0)
+#pragma unroll
+            for (int e = 0; e < 4; e++) grp += valid[e] ? (double)lambda_g * gnorm[e] : 0.0;
+        const double t = block_reduce_sum((double)lambda_j * reg + grp, red);
         if (threadIdx.x == 0) reg_part[(size_t)blockIdx.x * d.Q + a] = t;
     }
 }
@@ -2840,7 +2967,10 @@ hipError_t plm_launch_assemble(const PlmDims &d, const void *G, int ks_count, co
     // shard's own int32 plane / K-range partials
     const size_t slab_stride = (d.sharded || ks_count > 0) ? 0 : plm_slab_bytes(d) / 4;
     const float scale = d.gscale * (mode == 1 ? inv_neff : 1.f);
-    if (d.np_own > 0)
+    if (d.np_own > 0 && ks_count > 0 && slab_stride == 0)      // this shard's own int32 partials: 16-byte accesses
+        hipLaunchKernelGGL(k_assemble_v, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, (const int *)G, ks_count, ghalo, x, g,
+                           lambda_j, reg_part, mode == 2 ? 0 : mode, scale, pair_n2, mode == 1 ? 0.f : lambda_g);
+    else if (d.np_own > 0)
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)d.np_own, d.Q), dim3(256), 0, st, d, G, ks_count, slab_stride,
                            ghalo, x, g, lambda_j, reg_part, mode == 2 ? 0 : mode, scale, pair_n2, mode == 1 ? 0.f : lambda_g);
     hipLaunchKernelGGL(k_assemble_h, dim3((unsigned)(d.nh_pad_l / 256)), dim3(256), 0, st, d, G, ks_count, slab_stride, x, g, lambda_h,
@@ -2974,10 +3104,8 @@ __global__ __launch_bounds__(256) void k_canon_to_native(PlmDims d, const float 
                                                         float *__restrict__ xn) {
     // canonical side: the problem's alphabet (Qc states per site); native side: the instantiated size Q
     const int a = blockIdx.y;
-    int I = d.own_lo;
-    int64_t rem = blockIdx.x;
-    while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
-    const int J = I + (int)rem;
+    int I, J;
+    plm_pair_of_local(d, blockIdx.x, &I, &J);
     const int ii = threadIdx.x >> 4, jj = threadIdx.x & 15;
     const int i = I * 16 + ii, j = J * 16 + jj;
     const bool valid = i < d.L && j < d.L && i < j && a < d.Qc;
@@ -3008,9 +3136,10 @@ __global__ __launch_bounds__(64) void k_native_to_canon(PlmDims d, const float *
     const int i = blockIdx.x, j = blockIdx.y;
     if (j <= i) return;
     const int I = i >> 4, J = j >> 4;
-    if (I < d.own_lo || I >= d.own_hi) return;          // not an own pair: left untouched (sharded-state)
+    const int64_t k = plm_pair_local(d, I, J, nullptr);
+    if (k < 0) return;                                  // not an own pair: left untouched (sharded-state)
     const int QQc = d.Qc * d.Qc;
-    const size_t src = d.nh_pad_l + (size_t)(plm_bp_index(I, J, d.nb16) - d.bp_base) * d.Q * d.Q * 256 + (i & 15) * 16 + (j & 15);
+    const size_t src = d.nh_pad_l + (size_t)k * d.Q * d.Q * 256 + (i & 15) * 16 + (j & 15);
     const size_t dst = (size_t)d.L * d.Qc + (size_t)plm_pair_index(i, j, d.L) * QQc;
     for (int ab = threadIdx.x; ab < QQc; ab += 64)
         xc[dst + ab] = xn[src + (size_t)((ab / d.Qc) * d.Q + ab % d.Qc) * 256];
@@ -3131,10 +3260,8 @@ hipError_t plm_launch_gap_normalise_pairs(const PlmDims &d, float *fij_canon, do
 __global__ __launch_bounds__(256) void k_precond_j(PlmDims d, const float *__restrict__ fv, float neff, float lambda_j,
                                                   float *__restrict__ dinv) {
     const int a = blockIdx.y;
-    int I = d.own_lo;
-    int64_t rem = blockIdx.x;
-    while (rem >= d.nb16 - I) { rem -= d.nb16 - I; I++; }
-    const int J = I + (int)rem;
+    int I, J;
+    plm_pair_of_local(d, blockIdx.x, &I, &J);
     const int ii = threadIdx.x >> 4, jj = threadIdx.x & 15;
     const int i = I * 16 + ii, j = J * 16 + jj;
     const bool valid = i < d.L && j < d.L && i < j;
@@ -3231,49 +3358,44 @@ hipError_t plm_launch_align_stats(const int8_t *msa, int n, int L, int gap_state
 }
 
 // =========================================================================================
-// sharded-state exchange staging.  A "block" is the Q*Q*256 floats of one 16x16-site block pair.
-//   x halo : owner of J' (lower shard) -> owner of I (higher shard), pairs (J', I); receiver layout
-//            xhalo[J' * nblk_own + (I - own_lo)]
-//   g halo : owner of column block J (higher shard) -> owner of I (lower shard): the fragments
-//            G[(I,a),(J,b)] summed over split-K; receiver layout ghalo[(J - own_hi) * nblk_own + (I - own_lo)]
-// Messages are contiguous per destination, destinations in rank order (all_to_all_single).
+// Sharded-state mode: the two exchanges of an evaluation.  Rectangles of block pairs shared by two
+// shards belong to one of them (plm_rect_owner).
+//   couplings: the owner's blocks of a rectangle lie contiguously in its local vector (behind the triangle, partner
+//              order): they are sent from there, no packing; the partner finds them in xhalo[halo_base[owner] + pair].
+//   gradient:  the partner adds its half of every pair of the rectangle -- the fragment over ITS column block, summed
+//              over digit planes and K ranges -- to the message for the owner (k_pack_g), fragment layout as in G:
+//              gsend[halo_base[owner] + pair][a][b][256]; the owner reads it as ghalo[pair - ntri] (k_assemble).
 // =========================================================================================
-__global__ __launch_bounds__(256) void k_pack_x(PlmDims d, const float4 *__restrict__ xj, float4 *__restrict__ out) {
-    const int nhigh = d.nb16 - d.own_hi;
-    const int jp = blockIdx.x / nhigh, I = d.own_hi + blockIdx.x % nhigh;      // pair (own_lo + jp, I)
-    const int rdst = plm_shard_of(d, I), lo_r = plm_shard_lo(d, rdst);
-    const int n_r = plm_shard_cnt(d, rdst);
-    const size_t blk4 = PLM_BLOCK_FLOATS(d) / 4;
-    const size_t dst = ((size_t)d.nblk_own * (lo_r - d.own_hi) + (size_t)jp * n_r + (I - lo_r)) * blk4;
-    const size_t src = (size_t)(plm_bp_index(d.own_lo + jp, I, d.nb16) - d.bp_base) * blk4;
-    for (size_t k = (size_t)blockIdx.y * 256 + threadIdx.x; k < blk4; k += (size_t)gridDim.y * 256)
-        out[dst + k] = xj[src + k];
-}
-hipError_t plm_launch_pack_x(const PlmDims &d, const float *x, float *sendbuf, hipStream_t st) {
-    const int nhigh = d.nb16 - d.own_hi;
-    if (d.nblk_own <= 0 || nhigh <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_x, dim3(d.nblk_own * nhigh, 8), dim3(256), 0, st, d, (const float4 *)(x + d.nh_pad_l),
-                       (float4 *)sendbuf);
-    return hipGetLastError();
-}
 __global__ __launch_bounds__(256) void k_pack_g(PlmDims d, const int *__restrict__ G, float *__restrict__ out) {
-    // one block per (own column block J, lower block I, state a); thread t = fragment element
+    // one workgroup per (pair of a rectangle that belongs to the partner, state a); a wave per state b, one int4 per lane,
+    // plane and K range
     const int a = blockIdx.y;
-    const int jl = blockIdx.x / d.own_lo, I = blockIdx.x % d.own_lo;            // J = own_lo + jl
-    const int rdst = plm_shard_of(d, I), lo_r = plm_shard_lo(d, rdst), n_r = plm_shard_cnt(d, rdst);
-    const size_t blkf = PLM_BLOCK_FLOATS(d);
-    // message to shard rdst: its blocks x my blocks, my block major; messages in rank order
-    const size_t dst = ((size_t)lo_r * d.nblk_own + (size_t)jl * n_r + (I - lo_r)) * blkf + (size_t)a * d.Q * 256 +
-                       threadIdx.x;
+    int64_t k = blockIdx.x;
+    int p = 0, np = 0;
+    for (; p < d.nshards; p++) {
+        if (p == d.shard || plm_rect_owner(min(p, d.shard), max(p, d.shard)) == d.shard) continue;
+        np = plm_shard_cnt(d, p);
+        if (k < (int64_t)d.nblk_own * np) break;
+        k -= (int64_t)d.nblk_own * np;
+    }
+    if (p >= d.nshards) return;
+    int I, J;             // the pair (I < J): this shard is the lower one of the two iff d.shard < p
+    if (d.shard < p) { I = d.own_lo + (int)(k / np); J = plm_shard_lo(d, p) + (int)(k % np); }
+    else { I = plm_shard_lo(d, p) + (int)(k / d.nblk_own); J = d.own_lo + (int)(k % d.nblk_own); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t dst = (((size_t)blockIdx.x * d.Q + a) * d.Q) * 256 + 4 * lane;
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;
-    for (int b = 0; b < d.Q; b++) {
-        const size_t o = ((size_t)(I * d.Q + a) * d.nnfl + (size_t)jl * d.Q + b) * 256 + threadIdx.x;
-        out[dst + (size_t)b * 256] = g_combine(G, o, d.ksplit, kstride, d.nplanes);
+    for (int b = wave; b < d.Q; b += 4) {
+        // own column block I: G[(row J,b),(col I,a)]; own column block J: G[(row I,a),(col J,b)]
+        const size_t o = (d.shard < p ? g_frag(d, d.ksplit, 0, I, a, J * d.Q + b) : g_frag(d, d.ksplit, 0, J, b, I * d.Q + a)) + 4 * lane;
+        float v[4];
+        g_combine4(G, o, d.ksplit, kstride, d.nplanes, v);
+        *(float4 *)(out + dst + (size_t)b * 256) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 hipError_t plm_launch_pack_g(const PlmDims &d, const int32_t *G, float *sendbuf, hipStream_t st) {
-    if (d.nblk_own <= 0 || d.own_lo <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_g, dim3(d.nblk_own * d.own_lo, d.Q), dim3(256), 0, st, d, (const int *)G, sendbuf);
+    if (d.nblk_own <= 0 || d.nx_halo <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_g, dim3((unsigned)d.nx_halo, d.Q), dim3(256), 0, st, d, (const int *)G, sendbuf);
     return hipGetLastError();
 }
 

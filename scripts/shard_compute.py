@@ -76,12 +76,18 @@ for G in (2, 4, 8):
             km = timed(c)
         lo, hi = parts[r]
         own = hi - lo
-        # all-to-all volumes of this rank per evaluation (blocks of Q*Q*256 floats): couplings of lower shards' pairs
-        # with own column blocks come in, gradient fragments of own pairs with higher column blocks come in
         peer_max = max((b - a) for k, (a, b) in enumerate(parts) if k != r)
-        km.update(blocks=own, block_pairs=sum(nb16 - I for I in range(lo, hi)),
-                  x_halo_recv_MB=lo * own * blk_bytes / 1e6, g_halo_recv_MB=own * (nb16 - hi) * blk_bytes / 1e6,
-                  x_halo_send_MB=own * (nb16 - hi) * blk_bytes / 1e6, g_halo_send_MB=lo * own * blk_bytes / 1e6,
+        # block pairs of this rank: the triangle over its own blocks + the rectangles it owns (the rectangle of shards
+        # s < t belongs to s when t - s is odd, else to t: plm_rect_owner); per evaluation it sends the couplings of
+        # its rectangles and receives the partner's gradient fragments for them, and the other way round for the rest
+        mine = [p for p in range(G) if p != r and ((min(p, r) if (max(p, r) - min(p, r)) % 2 else max(p, r)) == r)]
+        theirs = [p for p in range(G) if p != r and p not in mine]
+        cnt = [b - a for a, b in parts]
+        km.update(blocks=own, block_pairs=own * (own + 1) // 2 + sum(own * cnt[p] for p in mine),
+                  x_halo_recv_MB=sum(own * cnt[p] for p in theirs) * blk_bytes / 1e6,
+                  g_halo_recv_MB=sum(own * cnt[p] for p in mine) * blk_bytes / 1e6,
+                  x_halo_send_MB=sum(own * cnt[p] for p in mine) * blk_bytes / 1e6,
+                  g_halo_send_MB=sum(own * cnt[p] for p in theirs) * blk_bytes / 1e6,
                   largest_peer_message_MB=peer_max * own * blk_bytes / 1e6)
         shards.append(km)
     out["gpus"][str(G)] = {"shards": shards}

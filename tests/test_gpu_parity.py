@@ -518,9 +518,10 @@ def test_eight_shard_fit_matches_single_gpu(plm, L):
 
 
 def test_one_shard_of_eight_can_be_timed_alone_and_the_solver_reports_its_passes(plm):
-    """scripts/shard_compute.py (profiles/r05_shard_compute.json): plm_ctx_time_kernels on a sharded-state context times
-    that shard's kernels over its own site blocks; plm_ctx_solver_stats reports the field solver's chain of the last fit"""
-    msa, _ = synthetic_msa(1500, 300, seed=8)
+    """scripts/shard_compute.py (profiles/r06_shard_compute.json): plm_ctx_time_kernels / plm_ctx_time_field_positions on a
+    sharded-state context time that shard's kernels over its own site blocks; plm_ctx_solver_stats reports the field
+    solver's chain of the last fit"""
+    msa, _ = synthetic_msa(6000, 300, seed=8)
     with plm.PlmContext(msa, q=Q, max_iter=12, epsilon=1e-3) as ctx:
         w, _, _ = ctx.reweight()
         ctx.marginals(pairs=False)
@@ -529,14 +530,19 @@ def test_one_shard_of_eight_can_be_timed_alone_and_the_solver_reports_its_passes
         st = ctx.solver_stats()
         x0 = ctx.get_x()
         full = ctx.time_kernels(reps=2)
+        full_pos = ctx.time_field_positions(reps=2)
     assert st["evaluations"] == r["n_evals"] and 1.0 <= st["passes_per_evaluation"] <= 14.0
     assert st["field_ms_per_evaluation"] > 0 and st["chains_continued_by_host"] <= r["n_evals"]
-    with plm.PlmContext(msa, q=Q, n_shards=8, shard=7, sharded_state=True, max_iter=12, epsilon=1e-3) as c:
+    with plm.PlmContext(msa, q=Q, n_shards=8, shard=0, sharded_state=True, max_iter=12, epsilon=1e-3) as c:
         c.set_weights(w)
         c.set_x(x0)
         part = c.time_kernels(reps=2)
-    for k in ("forward", "backward", "fields", "lbfgs_vector"):
-        assert 0 < part[k] < full[k], (k, part[k], full[k])        # 2 of 19 site blocks, 3 of 190 block pairs
+        part_pos = c.time_field_positions(reps=2)
+    for k in ("forward", "backward", "lbfgs_vector"):
+        assert 0 < part[k] < full[k], (k, part[k], full[k])        # 2 of 19 site blocks, about an eighth of the block pairs
+    # (the field solver's positions are a handful of launches each: latency-bound on a shard of this size)
+    assert 0 < part["fields"] < 1.5 * full["fields"]
+    assert all(0 < part_pos[k] < 1.5 * full_pos[k] for k in ("hessian_position", "closing_position")), (part_pos, full_pos)
 
 
 def test_native_rccl_collectives_on_one_rank(plm):
