@@ -192,18 +192,19 @@ int make_dims(const plm_problem_t &p, const PlmOptions &opt, PlmDims *out) {
     d.nblk_own = d.own_hi - d.own_lo;
     d.h_site0 = d.own_lo * 16;
     d.bp_base = 0;
-    for (int p = 0; p < PLM_MAX_SHARDS; p++) d.halo_base[p] = -1;
+    for (int p = 0; p < PLM_MAX_SHARDS; p++) d.own_base[p] = d.oth_base[p] = -1;
     d.nx_halo = d.ng_halo = 0;
     if (d.sharded) {
         if (nshards > PLM_MAX_SHARDS) return fail(PLM_EUNSUPPORTED, "sharded-state mode takes at most %d shards", PLM_MAX_SHARDS);
         d.ntri = d.nblk_own * (d.nblk_own + 1) / 2;
-        // rectangles shared with the other shards, each kind numbered in partner order (plm_internal.h)
+        // the two halves of the rectangle shared with every other shard, each kind numbered in partner order (plm_internal.h)
         for (int p = 0; p < nshards; p++) {
             if (p == d.shard) continue;
-            const int64_t n = (int64_t)d.nblk_own * plm_shard_cnt(d, p);
-            const bool mine = plm_rect_owner(std::min(p, d.shard), std::max(p, d.shard)) == d.shard;
-            d.halo_base[p] = (int)(mine ? d.ng_halo : d.nx_halo);
-            (mine ? d.ng_halo : d.nx_halo) += n;
+            const int64_t mine = plm_half_blocks(d, p), theirs = (int64_t)d.nblk_own * plm_shard_cnt(d, p) - mine;
+            d.own_base[p] = (int)d.ng_halo;
+            d.ng_halo += mine;
+            d.oth_base[p] = (int)d.nx_halo;
+            d.nx_halo += theirs;
         }
         d.np_own = d.ntri + d.ng_halo;
     } else {
@@ -947,15 +948,16 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
         if ((rc = dalloc(&c->xhalo, (size_t)d.nx_halo * blk)) || (rc = dalloc(&c->gsend, (size_t)d.nx_halo * blk)) ||
             (rc = dalloc(&c->ghalo, (size_t)d.ng_halo * blk)))
             return bail(rc);
-        // all-to-all byte counts: with shard r this shard shares the rectangle (own blocks) x (blocks of r); its owner
-        // (plm_rect_owner) sends the couplings and receives the partner's gradient fragments
+        // all-to-all byte counts: with shard r this shard shares the rectangle (own blocks) x (blocks of r); each of the
+        // two owns half of its rows (plm_pair_owner), sends the couplings of its half and receives the partner's gradient
+        // fragments for it
         c->x_send.assign(d.nshards, 0); c->x_recv.assign(d.nshards, 0);
         c->g_send.assign(d.nshards, 0); c->g_recv.assign(d.nshards, 0);
         for (int r = 0; r < d.nshards; r++) {
             if (r == d.shard) continue;
-            const int64_t bytes = (int64_t)d.nblk_own * plm_shard_cnt(d, r) * (int64_t)blk * 4;
-            if (plm_rect_owner(std::min(r, d.shard), std::max(r, d.shard)) == d.shard) { c->x_send[r] = bytes; c->g_recv[r] = bytes; }
-            else { c->x_recv[r] = bytes; c->g_send[r] = bytes; }
+            const int64_t mine = plm_half_blocks(d, r), theirs = (int64_t)d.nblk_own * plm_shard_cnt(d, r) - mine;
+            c->x_send[r] = c->g_recv[r] = mine * (int64_t)blk * 4;
+            c->x_recv[r] = c->g_send[r] = theirs * (int64_t)blk * 4;
         }
     }
     hipError_t e;

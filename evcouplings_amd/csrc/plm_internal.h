@@ -96,11 +96,12 @@ struct PlmDims {
     double theta;      // identity threshold (PLM_CONV_G_UNGAPPED_LENGTH evaluates it per pair)
     // ---- sharded-state mode (PLM_FLAG_SHARDED_STATE): parameters, gradient and L-BFGS vectors are split over the shards;
     // the "local" vector is [h of own sites | own block pairs].  Own block pairs (round 6: balanced): the TRIANGLE of
-    // pairs (I <= J) with both blocks own, then whole RECTANGLES of pairs shared with another shard p -- the rectangle
-    // of shards s < t belongs to s when t - s is odd, else to t (plm_rect_owner), so every shard owns about half of
-    // its rectangles (round 5: all of them went to the lower shard -- shard 0 of 8 held 23 % of the state at L = 500,
-    // the last one 2 %).  Inside a rectangle pairs are numbered (I - lo_s) * n_t + (J - lo_t); rectangles follow each
-    // other in partner order.  In every other mode the local vector IS the native vector (own_lo = 0, own_hi = nb16).
+    // pairs (I <= J) with both blocks own, then this shard's HALF of every rectangle of pairs it shares with another
+    // shard p: of the rectangle of shards s < t (rows = blocks of s) the even rows belong to s, the odd rows to t
+    // (plm_pair_owner) -- every shard owns about half of each of its rectangles, for any number of shards.  (Round 5: all
+    // of them went to the lower shard -- shard 0 of 8 held 23 % of the state at L = 500, the last one 2 %.)  A shard's
+    // rows of a rectangle are numbered row-major, (row >> 1) * n_t + (J - lo_t); the rectangles follow each other in
+    // partner order.  In every other mode the local vector IS the native vector (own_lo = 0, own_hi = nb16).
     int sharded;       // 1 in sharded-state mode
     int own_lo, own_hi;   // blocks whose parameters live in the local vector
     int nblk_own;      // own_hi - own_lo
@@ -109,14 +110,14 @@ struct PlmDims {
     int64_t np_own;    // own block pairs
     int64_t nh_pad_l;  // local field part, padded to 256 floats
     int64_t n_local;   // nh_pad_l + np_own*Q*Q*256
-    int64_t nx_halo;   // coupling blocks received per evaluation: the rectangles that belong to the partner
-    int64_t ng_halo;   // gradient blocks received per evaluation: the rectangles that belong to this shard
+    int64_t nx_halo;   // coupling blocks received per evaluation: the partners' halves of the shared rectangles
+    int64_t ng_halo;   // gradient blocks received per evaluation: this shard's halves
     int ntri;          // own pairs with both blocks own: nblk_own (nblk_own + 1) / 2 (all of them outside sharded-state mode)
-    // per partner shard p: first block of its rectangle among the rectangles of the same kind, in partner order -- for a
-    // rectangle this shard owns: its place behind the triangle in the local vector (ntri + halo_base[p]) = in the coupling
-    // message sent to p = in ghalo (p's gradient fragments); for one that p owns: its place in xhalo (p's couplings) = in
-    // the gradient message sent to p.  -1: p is this shard, or has no blocks.
-    int halo_base[PLM_MAX_SHARDS];
+    // per partner shard p, in partner order: own_base[p] = first block of THIS shard's half of the rectangle shared with p
+    // among its halves -- its place behind the triangle in the local vector (ntri + own_base[p]) = in the coupling message
+    // sent to p = in ghalo (p's gradient fragments for it); oth_base[p] = first block of p's half among the partners'
+    // halves -- its place in xhalo (p's couplings) = in the gradient message sent to p.
+    int own_base[PLM_MAX_SHARDS], oth_base[PLM_MAX_SHARDS];
 };
 
 // Environment knobs of the library, read ONCE per context (plm_options_from_env, plm_host.cpp) -- nothing on the
@@ -157,8 +158,15 @@ static inline __host__ __device__ int plm_shard_of(const PlmDims &d, int b) {
 static inline __host__ __device__ int64_t plm_bp_index(int I, int J, int nb16) { // I <= J
     return (int64_t)I * nb16 - (int64_t)I * (I - 1) / 2 + (J - I);
 }
-// sharded-state mode: which of the shards s < t owns the rectangle of block pairs between them
-static inline __host__ __device__ int plm_rect_owner(int s, int t) { return ((t - s) & 1) ? s : t; }
+// sharded-state mode: the block pair (I < J) of two different shards sI < sJ belongs to sI when I is an even row of the
+// rectangle (counted from sI's first block), else to sJ
+static inline __host__ __device__ int plm_pair_owner(const PlmDims &d, int I, int sI, int sJ) {
+    return ((I - plm_shard_lo(d, sI)) & 1) ? sJ : sI;
+}
+// blocks in this shard's half of the rectangle it shares with shard p
+static inline __host__ __device__ int64_t plm_half_blocks(const PlmDims &d, int p) {
+    return d.shard < p ? (int64_t)((d.nblk_own + 1) / 2) * plm_shard_cnt(d, p) : (int64_t)(plm_shard_cnt(d, p) / 2) * d.nblk_own;
+}
 // Local number of the block pair (I <= J) among this context's own pairs, or -1; for a pair this shard does not own but
 // whose couplings it needs (one of the blocks is an own column block) *halo = its place in xhalo (else -1).
 static inline __host__ __device__ int64_t plm_pair_local(const PlmDims &d, int I, int J, int *halo) {
@@ -171,10 +179,21 @@ static inline __host__ __device__ int64_t plm_pair_local(const PlmDims &d, int I
     }
     if (sI != d.shard && sJ != d.shard) return -1;
     const int p = sI == d.shard ? sJ : sI;
-    const int idx = d.halo_base[p] + (I - plm_shard_lo(d, sI)) * plm_shard_cnt(d, sJ) + (J - plm_shard_lo(d, sJ));
-    if (plm_rect_owner(sI, sJ) == d.shard) return (int64_t)d.ntri + idx;
-    if (halo) *halo = idx;
+    const int idx = ((I - plm_shard_lo(d, sI)) >> 1) * plm_shard_cnt(d, sJ) + (J - plm_shard_lo(d, sJ));
+    if (plm_pair_owner(d, I, sI, sJ) == d.shard) return (int64_t)d.ntri + d.own_base[p] + idx;
+    if (halo) *halo = d.oth_base[p] + idx;
     return -1;
+}
+// the blocks (I < J) of pair k of one half of the rectangle shared with shard p: this shard's half (mine) or p's
+static inline __host__ __device__ void plm_half_pair(const PlmDims &d, int p, bool mine, int64_t k, int *I, int *J) {
+    const int np = plm_shard_cnt(d, p);
+    if (d.shard < p) {      // rows = own blocks; even rows are this shard's
+        *I = d.own_lo + 2 * (int)(k / np) + (mine ? 0 : 1);
+        *J = plm_shard_lo(d, p) + (int)(k % np);
+    } else {                // rows = p's blocks; odd rows are this shard's
+        *I = plm_shard_lo(d, p) + 2 * (int)(k / d.nblk_own) + (mine ? 1 : 0);
+        *J = d.own_lo + (int)(k % d.nblk_own);
+    }
 }
 // ... and back: the blocks (I <= J) of own pair number k
 static inline __host__ __device__ void plm_pair_of_local(const PlmDims &d, int64_t k, int *I, int *J) {
@@ -187,12 +206,10 @@ static inline __host__ __device__ void plm_pair_of_local(const PlmDims &d, int64
     }
     k -= d.ntri;
     for (int p = 0; p < d.nshards; p++) {
-        if (p == d.shard || plm_rect_owner(p < d.shard ? p : d.shard, p < d.shard ? d.shard : p) != d.shard) continue;
-        const int np = plm_shard_cnt(d, p);
-        const int64_t n = (int64_t)d.nblk_own * np;
+        if (p == d.shard) continue;
+        const int64_t n = plm_half_blocks(d, p);
         if (k < n) {
-            if (d.shard < p) { *I = d.own_lo + (int)(k / np); *J = plm_shard_lo(d, p) + (int)(k % np); }
-            else { *I = plm_shard_lo(d, p) + (int)(k / d.nblk_own); *J = d.own_lo + (int)(k % d.nblk_own); }
+            plm_half_pair(d, p, true, k, I, J);
             return;
         }
         k -= n;

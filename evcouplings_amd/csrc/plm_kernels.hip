@@ -3358,30 +3358,29 @@ hipError_t plm_launch_align_stats(const int8_t *msa, int n, int L, int gap_state
 }
 
 // =========================================================================================
-// Sharded-state mode: the two exchanges of an evaluation.  Rectangles of block pairs shared by two
-// shards belong to one of them (plm_rect_owner).
-//   couplings: the owner's blocks of a rectangle lie contiguously in its local vector (behind the triangle, partner
-//              order): they are sent from there, no packing; the partner finds them in xhalo[halo_base[owner] + pair].
-//   gradient:  the partner adds its half of every pair of the rectangle -- the fragment over ITS column block, summed
-//              over digit planes and K ranges -- to the message for the owner (k_pack_g), fragment layout as in G:
-//              gsend[halo_base[owner] + pair][a][b][256]; the owner reads it as ghalo[pair - ntri] (k_assemble).
+// Sharded-state mode: the two exchanges of an evaluation.  Of the rectangle of block pairs shared by
+// two shards each owns half of the rows (plm_pair_owner).
+//   couplings: a shard's half of a rectangle lies contiguously in its local vector (behind the triangle, partner order):
+//              it is sent from there, no packing; the partner finds it in xhalo[oth_base[owner] + pair].
+//   gradient:  for every pair of the PARTNER's half a shard contributes the fragment over ITS column block, summed over
+//              digit planes and K ranges (k_pack_g), fragment layout as in G: gsend[oth_base[owner] + pair][a][b][256];
+//              the owner reads it as ghalo[pair - ntri] (k_assemble).
 // =========================================================================================
 __global__ __launch_bounds__(256) void k_pack_g(PlmDims d, const int *__restrict__ G, float *__restrict__ out) {
-    // one workgroup per (pair of a rectangle that belongs to the partner, state a); a wave per state b, one int4 per lane,
+    // one workgroup per (pair of a partner's half, state a); a wave per state b, one int4 per lane,
     // plane and K range
     const int a = blockIdx.y;
     int64_t k = blockIdx.x;
-    int p = 0, np = 0;
+    int p = 0;
     for (; p < d.nshards; p++) {
-        if (p == d.shard || plm_rect_owner(min(p, d.shard), max(p, d.shard)) == d.shard) continue;
-        np = plm_shard_cnt(d, p);
-        if (k < (int64_t)d.nblk_own * np) break;
-        k -= (int64_t)d.nblk_own * np;
+        if (p == d.shard) continue;
+        const int64_t n = (int64_t)d.nblk_own * plm_shard_cnt(d, p) - plm_half_blocks(d, p);      // p's half
+        if (k < n) break;
+        k -= n;
     }
     if (p >= d.nshards) return;
     int I, J;             // the pair (I < J): this shard is the lower one of the two iff d.shard < p
-    if (d.shard < p) { I = d.own_lo + (int)(k / np); J = plm_shard_lo(d, p) + (int)(k % np); }
-    else { I = plm_shard_lo(d, p) + (int)(k / d.nblk_own); J = d.own_lo + (int)(k % d.nblk_own); }
+    plm_half_pair(d, p, false, k, &I, &J);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t dst = (((size_t)blockIdx.x * d.Q + a) * d.Q) * 256 + 4 * lane;
     const size_t kstride = (size_t)d.nmf * d.nnfl * 256;

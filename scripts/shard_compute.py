@@ -76,19 +76,17 @@ for G in (2, 4, 8):
             km = timed(c)
         lo, hi = parts[r]
         own = hi - lo
-        peer_max = max((b - a) for k, (a, b) in enumerate(parts) if k != r)
-        # block pairs of this rank: the triangle over its own blocks + the rectangles it owns (the rectangle of shards
-        # s < t belongs to s when t - s is odd, else to t: plm_rect_owner); per evaluation it sends the couplings of
-        # its rectangles and receives the partner's gradient fragments for them, and the other way round for the rest
-        mine = [p for p in range(G) if p != r and ((min(p, r) if (max(p, r) - min(p, r)) % 2 else max(p, r)) == r)]
-        theirs = [p for p in range(G) if p != r and p not in mine]
+        # block pairs of this rank: the triangle over its own blocks + its half of the rectangle shared with every other
+        # rank (even rows -- blocks of the lower rank -- belong to the lower rank, odd rows to the higher: plm_pair_owner);
+        # per evaluation it sends the couplings of its halves and receives the partners' gradient fragments for them, and
+        # the other way round for the partners' halves
         cnt = [b - a for a, b in parts]
-        km.update(blocks=own, block_pairs=own * (own + 1) // 2 + sum(own * cnt[p] for p in mine),
-                  x_halo_recv_MB=sum(own * cnt[p] for p in theirs) * blk_bytes / 1e6,
-                  g_halo_recv_MB=sum(own * cnt[p] for p in mine) * blk_bytes / 1e6,
-                  x_halo_send_MB=sum(own * cnt[p] for p in mine) * blk_bytes / 1e6,
-                  g_halo_send_MB=sum(own * cnt[p] for p in theirs) * blk_bytes / 1e6,
-                  largest_peer_message_MB=peer_max * own * blk_bytes / 1e6)
+        mine = {p: ((own + 1) // 2) * cnt[p] if r < p else (cnt[p] // 2) * own for p in range(G) if p != r}
+        theirs = {p: own * cnt[p] - mine[p] for p in mine}
+        km.update(blocks=own, block_pairs=own * (own + 1) // 2 + sum(mine.values()),
+                  x_halo_recv_MB=sum(theirs.values()) * blk_bytes / 1e6, g_halo_recv_MB=sum(mine.values()) * blk_bytes / 1e6,
+                  x_halo_send_MB=sum(mine.values()) * blk_bytes / 1e6, g_halo_send_MB=sum(theirs.values()) * blk_bytes / 1e6,
+                  largest_peer_message_MB=max(max(mine.values()), max(theirs.values())) * blk_bytes / 1e6)
         shards.append(km)
     out["gpus"][str(G)] = {"shards": shards}
 
