@@ -305,6 +305,7 @@ struct plm_ctx {
     // host side of the chain (ctx_eval_vp_enqueue / ctx_eval_vp_finish)
     int vp_c_prev = 3;         // Newton steps the previous evaluation's chain took before it converged
     int vp_pos = 0;            // chain positions enqueued for the current evaluation
+    unsigned vp_hess_mask = 0; // ... and which of them (bit = position) were enqueued with Hessian sums
     int vp_extra = 0;          // continuations of the current evaluation (a chain that ran out of positions)
     double vp_last_gh2 = 0;    // squared field-gradient norm when the current evaluation's chain was last looked at
     double vp_floor2 = 0;      // squared noise floor of the field gradient's f32 sums (set by plm_ctx_optimize)
@@ -578,7 +579,11 @@ int vp_chain(plm_ctx *c, int npos, int hess_upto, int expected_last, double tol2
                                  nullptr, c->vp_flag, PLM_VP_PASS_RT, c->st));
         HIP_TRY(plm_launch_hsolve(d, c->hpart, c->gpart, hess ? 2 : 0, c->x, c->h64, c->prob.lambda_h, 1, c->hinv, c->hg2,
                                   c->scal + 5, tol2, c->vp_floor2, c->vp_flag, 1, c->hcnt, c->dpart, c->st));
-        if (hess) c->vp_hess_age = 0;
+        // (whether the device RUNS this position is known only after the chain: ctx_eval_vp_finish resets the age of the
+        // cached inverses if a Hessian position was among the passes executed -- ADVICE r5: resetting it here made the
+        // periodic refresh dead code)
+        if (hess && pos < 32) c->vp_hess_mask |= 1u << pos;
+        if (hess && c->vp_hess_age < 0) c->vp_hess_age = 0;
     }
     return PLM_OK;
 }
@@ -618,17 +623,20 @@ int ctx_eval_vp_enqueue(plm_ctx *c, double tol2) {
     if (c->vp_ev_pending) c->vp_ev_pending = false;     // (an evaluation nobody waited for: its events are re-recorded)
     HIP_TRY(hipEventRecord(c->vp_ev[0], c->st));
     // a chain expected to end on its first pass (late in a fit: the L-BFGS extrapolation of the fields is within the
-    // tolerance) starts in the residual-writing role
+    // tolerance) starts in the residual-writing role -- unless the cached inverse Hessians are due for their periodic
+    // refresh (every 32 evaluations: a pass in that role carries no Hessian sums)
     const int c_prev = c->vp_c_prev;
-    HIP_TRY(plm_launch_vp_reset(c->vp_flag, (c_prev == 0 && c->vp_hess_age >= 0) ? 1 : 0, c->st));
+    if (c->vp_hess_age >= 0) c->vp_hess_age++;
+    const bool stale = c->vp_hess_age < 0 || c->vp_hess_age >= 32;
+    HIP_TRY(plm_launch_vp_reset(c->vp_flag, (c_prev == 0 && !stale) ? 1 : 0, c->st));
     HIP_TRY(hipMemsetAsync(c->scal + 5, 0, 3 * sizeof(double), c->st));
     c->vp_pos = 0;
     c->vp_extra = 0;
+    c->vp_hess_mask = 0;
     c->vp_last_gh2 = INFINITY;
-    if (c->vp_hess_age >= 0) c->vp_hess_age++;
     // fresh Hessian sums at every position before the expected last one (measured, gpurun_out/r5c9: Hessians at the
     // first position only -> 9.8 passes per evaluation in the bench window instead of 4.6, at the first two -> 5.9)
-    int hess_upto = c_prev >= 2 ? c_prev : ((c->vp_hess_age < 0 || c->vp_hess_age >= 32) ? 1 : 0);
+    int hess_upto = c_prev >= 2 ? c_prev : (stale ? 1 : 0);
     if (c->opt.vp_hess_pos >= 0) hess_upto = std::min(hess_upto, std::max(c->opt.vp_hess_pos, c->vp_hess_age < 0 ? 1 : 0));
     PLM_TRY(vp_chain(c, std::min(14, c_prev + 3), hess_upto, c_prev, tol2));
     HIP_TRY(plm_launch_fields_to_x(d, c->h64, c->vp_flag, c->x, c->st));
@@ -681,6 +689,9 @@ int ctx_eval_vp_finish(plm_ctx *c, double tol2, bool *again, double *gh2_out) {
         fprintf(stderr, "\n");
     }
     if (c->vp_extra == 0) c->stat_passes += passes;
+    // the cached inverse Hessians are fresh if one of the passes that RAN carried Hessian sums (a position in the
+    // residual-writing role does not: at most one per chain, the last)
+    if (passes > 0 && (c->vp_hess_mask & ((passes >= 32 ? 0xffffffffu : ((1u << passes) - 1u))))) c->vp_hess_age = 0;
     if (done && c->vp_extra == 0) {
         c->vp_c_prev = std::max(0, passes - 1);
         return PLM_OK;
@@ -1530,8 +1541,6 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
     double eps_eff = eps;      // target of the reduced gradient: the stop rule minus what the f32 rounding of the fields costs
     double rounding_note = 0;  // > 0: the rule was met on the f64-field point only; what rounding the fields to f32 adds
     int n_cert = 0;
-    double best_cond = 1e300;  // stagnation watch (see the end of the iteration)
-    int best_k = 0, stag_resets = 0;
     int k = 0, end = 0, stored = 0, status = PLM_STATUS_CONVERGED, ls_reason = 0, restarts = 0;
     // The next pair is (x - anchor, g - g(anchor)).  The anchor is the previous accepted point (xp, gp) -- unless the
     // pair(s) since were skipped as noise (below): then it stays where the last STORED pair ended, in its own buffers,
@@ -1778,25 +1787,9 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 anchored = false;
             }
             step = 1.0;
-            // Stagnation next to the stop rule.  Config 3 (N = 100 000) reached |g|/|x| = 1.13e-3 after 264 iterations and
-            // then walked between 1.2e-3 and 4e-3 for 120 more -- curvature pairs taken over steps this short are mostly
-            // differences of evaluation errors (they pass the cosine test above one by one and still add up to a poor
-            // model) -- until a failed line search dropped the history: the preconditioned gradient step that followed
-            // met the rule in three iterations (gpurun_out/r4c45).  So: no new best |g|/|x| for 12 iterations while within
-            // a decade of the rule -> the history is dropped and the next step starts from the preconditioned gradient, at
-            // most three times per fit.
-            if (last_cond < 0.97 * best_cond) {
-                best_cond = last_cond;
-                best_k = k;
-            } else if (vp && k - best_k >= 12 && last_cond < 10.0 * eps && stag_resets < 3 && stored > 0) {
-                stored = 0;
-                end = 0;
-                anchored = false;
-                step = first_step();
-                stag_resets++;
-                best_k = k;
-                if (c->opt.debug) fprintf(stderr, "[plm] stagnation watch: history dropped at iteration %d (|g|/|x| %.3e, best %.3e)\n", k, last_cond, best_cond);
-            }
+            // (Rounds 4-5 kept a stagnation watch here -- no new best |g|/|x| for 12 iterations next to the stop rule ->
+            // history dropped.  It did not fire in any run since the accurate evaluation took over the last iterations of a
+            // fit and had no test: removed in round 6.)
         }
     }
     HIP_TRY(hipStreamSynchronize(c->st));

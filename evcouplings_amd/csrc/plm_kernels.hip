@@ -2206,7 +2206,15 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
     __shared__ double red[4];
     __shared__ int bad[4];
     PlmVpState *S = (PlmVpState *)state;
-    if (S && S->done) return;
+    if (S && S->done) {
+        // (a host continuation of a sharded chain zeroes the verdict slots before it re-enqueues: a rank whose chain had
+        // ended must publish them again, or the all-reduced verdict could never be "every rank done" -- ADVICE r5)
+        if (threadIdx.x == 0) {
+            g2_out[1] = (double)S->passes;
+            g2_out[2] = 1.0;
+        }
+        return;
+    }
     double s = 0;
     int open_sites = 0;
     __shared__ int loud_blocks;
