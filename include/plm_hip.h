@@ -79,9 +79,12 @@ typedef struct {
  * sequences.  All arrays keep the q-state layout of the alphabet; every entry that involves state 0
  * is zero (the Python host drops them and writes a (q-1)-state model file).  DESIGN.md section 2b. */
 #define PLM_FLAG_IGNORE_GAPS 2
-/* n_shards > 1 only: parameters, gradient and L-BFGS state are sharded by owning site block instead
- * of replicated.  Needs a plm_collective_cb; per evaluation two all-to-alls of
- * neighbour blocks and one scalar all-reduce replace the all-gather of whole gradient slabs. */
+/* n_shards > 1 only (at most 16): parameters, gradient and L-BFGS state are split over the shards instead of
+ * replicated: a shard's fields, the block pairs inside its site blocks and half of every
+ * rectangle of block pairs it shares with another shard.  Needs a plm_collective_cb; per evaluation two all-to-alls
+ * (couplings, gradient fragments; every rank exchanges with every other) and one scalar all-reduce replace the
+ * all-gather of whole gradient slabs; the fitted parameters are assembled with one PLM_COLL_ALLREDUCE_F32 of the
+ * canonical vector. */
 #define PLM_FLAG_SHARDED_STATE 4
 /* L-BFGS with a diagonal initial Hessian (inverse Hessian diagonal of the independent-site model) instead of the
  * textbook scalar one.  Same optimum (strictly convex objective), different path.  Measured on MI355X: fewer
