@@ -1424,6 +1424,8 @@ size_t plm_hj_bytes(const PlmDims &d) { return (size_t)d.nstiles * (d.b16_hi - d
 // of the solver's forward epilogue.  k_hsolve takes one Newton step per site: H = diag(rowsum M) - M + 2 lambda_h I.
 // =========================================================================================
 #define PLM_HSTATS(Q) ((Q) + (Q) * ((Q) + 1) / 2)
+// smallest alphabet that runs on the instantiation for Q states (plm_q_template: 2-4 -> 4, 5 -> 5, 6-20 -> 20, 21 -> 21, 22-32 -> 32)
+__host__ __device__ constexpr int plm_qc_min(int Q) { return Q == 4 ? 2 : Q == 5 ? 5 : Q == 20 ? 6 : Q == 21 ? 21 : 22; }
 #ifndef PLM_HESS_SAMPLE
 #define PLM_HESS_SAMPLE 32    // measured round 6 (with the exact diagonal): 8 / 16 / 32 / 64 / 128 -> 95.7 / 96.9 / 100.5 / 99.5 / 99.2 it/s in the bench window
 #endif
@@ -1582,6 +1584,14 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
     constexpr bool LDSF = !WRITE_RT && !XACT && (STATS != 2 || Q > 21);     // (21 states: the sampled tiles are one workgroup per CU by LDS anyway)
     constexpr size_t STAT_BYTES = (size_t)16 * (8 * Q * sizeof(double) * (DIAG ? 2 : 1) + HW * NHP * sizeof(float));
     float2 *lf = (float2 *)(smem + STAT_BYTES);
+    // FAST (round 6): the statistics passes of the plain evaluation are VALU-bound (~21 issue slots per (sequence, site,
+    // state) = 0.2 of their 0.28-0.33 ms; persistent workgroups with prefetch were slower: NOTES_r06 2c e).  They need no
+    // residual P - [x = a] per element: the sums take the unobserved states' exponentials with the weight w / Z folded into
+    // one factor per sequence, and the OBSERVED state's term -w (1 - P_x) (resp. w P_x^2) goes into the LDS sums with one
+    // add per sequence at a dynamic address -- the normalising multiply and the compare / select of every element are
+    // gone, the exponent's argument is one fma, the padding mask is compiled in only where states can be dead.
+    // Same precision argument as before: 1 - P_x is the sum of the other states' probabilities.
+    constexpr bool FAST = !WRITE_RT && !XACT && (STATS == 1 || STATS == 3);
     if constexpr (LDSF) {
         for (int k = tid; k < 16 * Q; k += 512) {
             const int ii = b16 * 16 + k / Q;
@@ -1624,6 +1634,7 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             acc[a] = (f32x4){v.x, v.y, v.z, v.w};
         }
         float wk[4];     // weight of the lane's 4 (sequence, site) pairs (0: padding, gapped site in gap mode)
+        float izk[4];    // FAST with diagonal sums: 1 / Z of the same pairs
         // After the softmax acc[a][reg] holds P(a) - [a = observed state]: the residual without its weight.  For the
         // observed state that is -(1 - P), formed as the SUM of the other states' probabilities: where a site is all but
         // certain (P = 1 - 1e-8: gap runs, conserved columns) the f32 P rounds to 1 - k 2^-24 and P - 1 loses every bit --
@@ -1652,19 +1663,33 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
                         fh = hv[a];
                         fl = hl[a];
                     }
-                    const float H = ((gap && a == 0) || a >= d.Qc) ? -INFINITY : (acc[a][reg] + fl) + fh;
+                    // (states a >= Qc are padding of an alphabet that runs on the next instantiated size: impossible below the
+                    // smallest alphabet of this instantiation -- at 21 states the test compiles away)
+                    const float H = ((gap && a == 0) || (a >= plm_qc_min(Q) && a >= d.Qc)) ? -INFINITY : (acc[a][reg] + fl) + fh;
                     acc[a][reg] = H;
                     mx = fmaxf(mx, H);
                 }
+                if constexpr (FAST) {
+                    const float mxl = -mx * 1.44269502f;            // exp(H - mx) = exp2(fma(H, log2 e, -mx log2 e))
 #pragma unroll
-                for (int a = 0; a < Q; a++) {
-                    const float H = acc[a][reg] - mx;
-                    const float ev = __expf(H);
-                    float evo;
-                    sel_eq2(xi, a, hx, H, ev, 0.f, hx, evo);       // hx = H of the observed state; evo = ev of the others
-                    acc[a][reg] = ev;
-                    Z += ev;
-                    zo += evo;
+                    for (int a = 0; a < Q; a++) {
+                        const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[a][reg], 1.44269502f, mxl));
+                        const float evo = sel_eq(xi, a, ev, 0.f);   // the exponentials of the states NOT observed
+                        acc[a][reg] = evo;
+                        Z += ev;
+                        zo += evo;
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < Q; a++) {
+                        const float H = acc[a][reg] - mx;
+                        const float ev = __expf(H);
+                        float evo;
+                        sel_eq2(xi, a, hx, H, ev, 0.f, hx, evo);       // hx = H of the observed state; evo = ev of the others
+                        acc[a][reg] = ev;
+                        Z += ev;
+                        zo += evo;
+                    }
                 }
             } else {
                 // accurate evaluation: the argument of every exponential exactly.  H = potential + field in f64, the
@@ -1694,10 +1719,25 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
             const float invZ = 1.f / Z;
             if (WRITE_RT && ws > 0.f) fxl -= ws * (hx - log_unbiased(Z));
             const float mpo = -(zo * invZ);                      // -(1 - P(observed))
+            if constexpr (FAST) {
+                // the observed state's terms, one LDS add each (a sequence that does not count -- padding, a gapped site in
+                // gap mode -- has weight 0 and possibly no valid state: skipped)
+                if (ws != 0.f) {
+                    unsafeAtomicAdd(&lg[xi], (double)(ws * mpo));
+                    if constexpr (STATS == 3) {
+                        const float px = 1.f + mpo;
+                        unsafeAtomicAdd(&ld[xi], (double)(ws * px * px));
+                    }
+                }
+                wk[reg] = ws * invZ;                             // w / Z: acc holds the unnormalised exponentials of the other states
+                izk[reg] = invZ;
+                xk[reg] = xi;
+            } else {
 #pragma unroll
             for (int a = 0; a < Q; a++) acc[a][reg] = sel_eq(xi, a, acc[a][reg] * invZ, mpo);     // P - [a = observed]
             wk[reg] = ws;
             xk[reg] = xi;
+            }
             asm volatile("" : "+v"(xk[reg]));   // no sharing of compare masks between the sections (SGPR spills)
             if constexpr (XACT) __builtin_amdgcn_sched_barrier(0);   // one sequence at a time: the f64 temporaries of four would spill
         }
@@ -1720,10 +1760,16 @@ __global__ __launch_bounds__(512) void k_hpass(PlmDims d, HpassArgs A) {
 #endif
                 if constexpr (DIAG) {
                     float da = 0.f;                                           // sum_k w P_a^2, P_a = acc + [x = a]
+                    if constexpr (FAST) {
+                        // t = (w / Z) e_a; P_a = e_a / Z = t / w ... the observed state's term went into the LDS sum above
+#pragma unroll
+                        for (int k = 0; k < 4; k++) da = fmaf(t[k] * acc[a][k], izk[k], da);
+                    } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const bool obs = xk[k] == a;
                         da = fmaf(t[k] + (obs ? wk[k] : 0.f), acc[a][k] + (obs ? 1.f : 0.f), da);
+                    }
                     }
 #ifndef PLM_EXP_NOGRAD
                     unsafeAtomicAdd(&ld[a], (double)da);
