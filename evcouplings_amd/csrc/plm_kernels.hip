@@ -93,6 +93,19 @@ extern "C" __attribute__((visibility("default"))) void plm_probe_read(unsigned l
 }
 #endif
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+// The stored potentials (1.28 GB per evaluation at the headline) are written once and read back from HBM by the field
+// solver: a streaming store keeps them from evicting the forward operand, which every workgroup of a site block shares
+// through L2 (round 6; -DPLM_HJ_NT=0 for the A/B build)
+#ifndef PLM_HJ_NT
+#define PLM_HJ_NT 1
+#endif
+__device__ __forceinline__ void store_hj(float4 *p, float x, float y, float z, float w) {
+#if PLM_HJ_NT
+    __builtin_nontemporal_store((f32x4){x, y, z, w}, (f32x4 *)p);
+#else
+    *p = make_float4(x, y, z, w);
+#endif
+}
 #define LDS_FPTR(p) ((__attribute__((address_space(3))) float *)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
@@ -957,9 +970,9 @@ __global__ __launch_bounds__(512) void k_fwd(PlmDims d, FwdArgs A) {
             const float chi = (float)c, clo = (float)(c - (double)chi);
 #pragma unroll
             for (int m = 0; m < 2; m++)
-                hj[(size_t)(m * Q + a_lo + a) * 64] =
-                    make_float4(__builtin_fmaf(acc[m][a][0], sc32, clo) + chi, __builtin_fmaf(acc[m][a][1], sc32, clo) + chi,
-                                __builtin_fmaf(acc[m][a][2], sc32, clo) + chi, __builtin_fmaf(acc[m][a][3], sc32, clo) + chi);
+                store_hj(&hj[(size_t)(m * Q + a_lo + a) * 64],
+                         __builtin_fmaf(acc[m][a][0], sc32, clo) + chi, __builtin_fmaf(acc[m][a][1], sc32, clo) + chi,
+                         __builtin_fmaf(acc[m][a][2], sc32, clo) + chi, __builtin_fmaf(acc[m][a][3], sc32, clo) + chi);
         }
         return;
     }
@@ -1166,7 +1179,7 @@ __global__ __launch_bounds__(512) void k_fwd_x(PlmDims d, FwdArgs A) {
         for (int a = 0; a < QG; a++) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
-                hj[(size_t)(m * Q + a_lo + a) * 64] = make_float4(value(m, a, 0), value(m, a, 1), value(m, a, 2), value(m, a, 3));
+                store_hj(&hj[(size_t)(m * Q + a_lo + a) * 64], value(m, a, 0), value(m, a, 1), value(m, a, 2), value(m, a, 3));
         }
     } else {        // FWD_POTENTIALS
         const int i = b16 * 16 + r;
@@ -1221,9 +1234,9 @@ template <int M, int A>
 __device__ __forceinline__ void fwdw_store(float4 *hj, const float *chi, const float *clo, float sc32) {
     const f32x4 v = fwdw_acc_read<(M * PLM_FWDW_QG + A) * 4>();
     const float h = chi[A], l = clo[A];       // the f64 constant C_i(a) as hi + lo (see k_fwd's store epilogue)
-    hj[(size_t)((M & 1) * 21 + A) * 64 + (size_t)(M >> 1) * 2 * 21 * 64] =
-        make_float4(__builtin_fmaf(v[0], sc32, l) + h, __builtin_fmaf(v[1], sc32, l) + h,
-                    __builtin_fmaf(v[2], sc32, l) + h, __builtin_fmaf(v[3], sc32, l) + h);
+    store_hj(&hj[(size_t)((M & 1) * 21 + A) * 64 + (size_t)(M >> 1) * 2 * 21 * 64],
+             __builtin_fmaf(v[0], sc32, l) + h, __builtin_fmaf(v[1], sc32, l) + h,
+             __builtin_fmaf(v[2], sc32, l) + h, __builtin_fmaf(v[3], sc32, l) + h);
 }
 template <int M, int... A>
 __device__ __forceinline__ void fwdw_store_row(float4 *hj, const float *chi, const float *clo, float sc32, std::integer_sequence<int, A...>) {
