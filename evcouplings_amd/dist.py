@@ -7,10 +7,12 @@ callbacks implemented here with torch.distributed -- backend "nccl" is RCCL over
 ROCm -- directly on the library's device buffers.
 
 Sharded-state mode (default, `make_torch_collective`): parameters, gradient and L-BFGS state
-are split by owning site block; per evaluation two all-to-alls of neighbour blocks (couplings
-towards higher shards, gradient fragments towards lower ones) and one scalar all-reduce, plus
-one scalar all-reduce per iteration for the L-BFGS Gram matrix; at the end of a fit every
-shard broadcasts its slice of the parameters (the all-gather of the J tensor).
+are split over the shards (a shard's fields, the block pairs inside its site blocks, half of the
+rows of every rectangle of block pairs it shares with another shard); per evaluation two
+all-to-alls (couplings, gradient fragments: every rank exchanges with every other) and one scalar
+all-reduce, plus one scalar all-reduce per iteration for the L-BFGS Gram matrix (DESIGN.md
+section 8); at the end of a fit ONE float32 all-reduce of the canonical parameter vector, in
+which every entry has exactly one non-zero term (the all-gather of the J tensor).
 Replicated mode (`make_torch_exchange`): one all-gather of the gradient slabs per evaluation,
 every rank repeats the same L-BFGS step on the full vectors.
 `ThreadedShards` / `LoopbackShards` run either mode with all shards on ONE GPU for tests.

@@ -154,9 +154,9 @@ typedef int (*plm_exchange_cb)(void *dev_buf, size_t bytes_per_shard, int32_t n_
 #define PLM_COLL_ALLREDUCE_F64 2
 #define PLM_COLL_ALLREDUCE_F32 3
 /*   PLM_COLL_BROADCAST     send_counts[0] bytes at `send` travel from rank recv_counts[0] to every rank (in place).
- *                          Used once per fit: every shard broadcasts its slice of the fitted parameters -- together
- *                          the all-gather of the J tensor (each rank receives (n-1)/n of the vector, half of what the
- *                          all-reduce of a zero-padded vector moved). */
+ *                          Rounds 2-5 assembled the fitted parameters with two broadcasts per shard; since round 6 (a
+ *                          shard's entries are no longer contiguous in the canonical order) that is one
+ *                          PLM_COLL_ALLREDUCE_F32 of the canonical vector.  The operation stays part of the contract. */
 #define PLM_COLL_BROADCAST 4
 typedef int (*plm_collective_cb)(int32_t op, void *send, void *recv, const int64_t *send_counts,
                                  const int64_t *recv_counts, int32_t n_shards, int32_t shard, void *user);
