@@ -41,6 +41,28 @@ def shard_blocks(n_sites, n_shards):
     return out
 
 
+def pair_owner(I, J, parts):
+    """Which shard owns the block pair (I <= J) in sharded-state mode (plm_internal.h plm_pair_owner): the shard of both
+    blocks if it is the same one; else, counting rows over the LOWER shard's blocks, even rows belong to the lower
+    shard, odd rows to the higher one -- every shard owns half of each rectangle it shares with another."""
+    s_i = next(r for r, (lo, hi) in enumerate(parts) if lo <= I < hi)
+    s_j = next(r for r, (lo, hi) in enumerate(parts) if lo <= J < hi)
+    if s_i == s_j:
+        return s_i
+    return s_j if (I - parts[s_i][0]) & 1 else s_i
+
+
+def owned_block_pairs(n_sites, n_shards):
+    """Number of block pairs (I <= J) every shard owns: its share of x, g and every L-BFGS vector."""
+    parts = shard_blocks(n_sites, n_shards)
+    nb16 = (n_sites + 15) // 16
+    counts = [0] * n_shards
+    for I in range(nb16):
+        for J in range(I, nb16):
+            counts[pair_owner(I, J, parts)] += 1
+    return counts
+
+
 def shard_sites(n_sites, n_shards):
     """Site ranges [lo, hi) owned by each shard."""
     return [(min(n_sites, 16 * lo), min(n_sites, 16 * hi)) for lo, hi in shard_blocks(n_sites, n_shards)]

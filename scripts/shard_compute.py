@@ -25,7 +25,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from evcouplings_amd import plm
-from evcouplings_amd.dist import shard_blocks
+from evcouplings_amd.dist import shard_blocks, owned_block_pairs
 from evcouplings_amd.synthetic import synthetic_msa, BASE_SEED
 
 N = int(sys.argv[1]) if len(sys.argv) > 2 else 50000
@@ -83,6 +83,7 @@ for G in (2, 4, 8):
         cnt = [b - a for a, b in parts]
         mine = {p: ((own + 1) // 2) * cnt[p] if r < p else (cnt[p] // 2) * own for p in range(G) if p != r}
         theirs = {p: own * cnt[p] - mine[p] for p in mine}
+        assert own * (own + 1) // 2 + sum(mine.values()) == owned_block_pairs(L, G)[r]
         km.update(blocks=own, block_pairs=own * (own + 1) // 2 + sum(mine.values()),
                   x_halo_recv_MB=sum(theirs.values()) * blk_bytes / 1e6, g_halo_recv_MB=sum(mine.values()) * blk_bytes / 1e6,
                   x_halo_send_MB=sum(mine.values()) * blk_bytes / 1e6, g_halo_send_MB=sum(theirs.values()) * blk_bytes / 1e6,

@@ -29,6 +29,25 @@ def test_shard_partition_covers_all_sites_once():
     assert [hi - lo for lo, hi in pdist.shard_blocks(300, 8)] == [2, 2, 2, 2, 2, 3, 3, 3]
 
 
+def test_block_pair_ownership_is_a_balanced_partition():
+    """Sharded-state mode, round 6: every block pair has exactly one owner (by construction of pair_owner), a shard owns
+    the triangle over its own blocks + about half of every rectangle it shares; the busiest shard stays within one
+    rectangle row per partner of the mean (round 5, pairs (I own, J >= I): 122 against 10 of 528 at L = 500 on 8 shards)."""
+    for L, n in ((300, 8), (500, 8), (500, 2), (600, 4), (1000, 8), (48, 3), (20, 8)):
+        parts = pdist.shard_blocks(L, n)
+        nb16 = (L + 15) // 16
+        counts = pdist.owned_block_pairs(L, n)
+        assert sum(counts) == nb16 * (nb16 + 1) // 2
+        cnt = [hi - lo for lo, hi in parts]
+        for r in range(n):      # closed form used by the library (plm_half_blocks)
+            mine = sum(((cnt[r] + 1) // 2) * cnt[p] if r < p else (cnt[p] // 2) * cnt[r] for p in range(n) if p != r)
+            assert counts[r] == cnt[r] * (cnt[r] + 1) // 2 + mine
+        mean = sum(counts) / n
+        assert max(counts) <= mean + max(cnt) * (n - 1) / 2 + max(cnt) ** 2, (L, n, counts)
+    assert pdist.owned_block_pairs(500, 8) == [66] * 8
+    assert pdist.owned_block_pairs(500, 2) == [264, 264]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
