@@ -88,6 +88,7 @@ SYMBOLS = [
     ("plm_alignment_stats", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int, _P]),
     ("plm_fasta_split", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P, _P, _P, _P]),
     ("plm_encode_columns", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P]),
+    ("plm_write_raw_ec_file", C.c_int, [C.c_char_p, C.c_int32, _P, C.c_char_p, _P]),
     ("plm_ctx_create", C.c_int, [C.POINTER(PlmProblem), C.c_int, _P, C.POINTER(_P)]),
     ("plm_ctx_destroy", None, [_P]),
     ("plm_ctx_set_exchange", C.c_int, [_P, EXCHANGE_CB, _P]),

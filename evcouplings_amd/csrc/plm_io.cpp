@@ -9,7 +9,9 @@
 //   * the stripped data lines of a record are concatenated (whitespace INSIDE a line stays);
 //   * data before the first header is an error.
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/plm_hip.h"
 #include "plm_internal.h"
@@ -78,4 +80,35 @@ extern "C" int plm_encode_columns(const uint8_t *mat, int64_t n_rows, int64_t wi
         valid[r] = bad ? 0 : 1;
     }
     return PLM_OK;
+}
+
+// The raw EC file (couplings/pairs.py:55-58 reads it; plmc writes it): one line per site pair i < j, i ascending then j,
+// "index_i A_i index_j A_j 0 cn" with cn printed "%.6f".  44 850 lines at L = 300 were 20-55 ms of Python string formatting
+// in every run_plmc_hip call; here one buffer and one fwrite.  cn: dense row-major [L][L] doubles (the caller's float32
+// scores widened exactly as Python's "%.6f" % numpy.float32 does).  model_io.write_raw_ec_file keeps its Python twin (fallback
+// and test oracle: both reproduce the reference's two real plmc outputs byte for byte).
+extern "C" int plm_write_raw_ec_file(const char *path, int32_t n_sites, const int32_t *index_list, const char *target_seq,
+                                     const double *cn) {
+    if (!path || n_sites < 0 || !index_list || !target_seq || !cn) return plm_fail(PLM_EINVAL, "plm_write_raw_ec_file: NULL argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return plm_fail(PLM_EINVAL, "cannot open %s for writing", path);
+    std::vector<char> buf;
+    buf.reserve((size_t)1 << 20);
+    char line[128];
+    bool ok = true;
+    for (int32_t i = 0; i < n_sites && ok; i++) {
+        for (int32_t j = i + 1; j < n_sites; j++) {
+            const int n = snprintf(line, sizeof line, "%d %c %d %c 0 %.6f\n", index_list[i], target_seq[i], index_list[j],
+                                   target_seq[j], cn[(size_t)i * n_sites + j]);
+            if (n <= 0 || n >= (int)sizeof line) { ok = false; break; }
+            buf.insert(buf.end(), line, line + n);
+        }
+        if (buf.size() >= ((size_t)1 << 20) - 4096 || i == n_sites - 1) {
+            if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) ok = false;
+            buf.clear();
+        }
+    }
+    if (n_sites < 2 && ok) ok = fputc('\n', f) != EOF;      // (the Python twin ends an empty table with one newline)
+    if (fclose(f) != 0) ok = false;
+    return ok ? PLM_OK : plm_fail(PLM_EINVAL, "writing %s failed", path);
 }

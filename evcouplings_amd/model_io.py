@@ -93,6 +93,8 @@ def write_raw_ec_file(path, index_list, target_seq, cn):
     """
     cn = np.asarray(cn)
     L = cn.shape[0]
+    if L >= 2 and _native_writer(path, index_list, target_seq, cn):
+        return path
     iu, ju = np.triu_indices(L, 1)
     idx = np.asarray(index_list)
     letters = np.array(list(target_seq))
@@ -104,3 +106,27 @@ def write_raw_ec_file(path, index_list, target_seq, cn):
         f.write("\n".join(lines))
         f.write("\n")
     return path
+
+
+def _native_writer(path, index_list, target_seq, cn):
+    """plm_write_raw_ec_file (host code of libplm_hip: one buffer, one write) when the library is built and every
+    residue letter is one ASCII byte; False -> the Python lines above, which give the same bytes (PLM_IO_PYTHON=1 forces
+    them: tests compare the two).  File formatting is plumbing, not the solver: like the alignment reader it may fall back."""
+    import ctypes as C
+    import os
+    if os.environ.get("PLM_IO_PYTHON"):
+        return False
+    try:
+        from evcouplings_amd import _lib
+        lib = _lib.load()
+        if not hasattr(lib, "plm_write_raw_ec_file"):
+            return False
+        seq = "".join(target_seq).encode("ascii")
+        idx = np.ascontiguousarray(index_list, dtype=np.int32)
+        if len(seq) != cn.shape[0] or idx.size != cn.shape[0]:
+            return False
+        dense = np.ascontiguousarray(cn, dtype=np.float64)
+        return lib.plm_write_raw_ec_file(os.fsencode(path), cn.shape[0], idx.ctypes.data_as(C.c_void_p), seq,
+                                         dense.ctypes.data_as(C.c_void_p)) == 0
+    except Exception:       # noqa: BLE001 -- library missing / non-ASCII letters: the Python twin
+        return False

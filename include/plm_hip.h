@@ -302,6 +302,11 @@ int plm_fasta_split(const char *buf, int64_t n, int64_t *n_records, int64_t *seq
                     int32_t *hdr_len, int64_t *seq_len, char *seq_out);
 int plm_encode_columns(const uint8_t *mat, int64_t n_rows, int64_t width, const int64_t *cols, int64_t n_cols,
                        const int8_t *lut256, int8_t *out, uint8_t *valid);
+/* ... and output (host code): the raw EC file plmc writes and couplings/pairs.py:55-58 reads -- one line per site pair
+ * i < j, "index_i A_i index_j A_j 0 cn" with cn as "%.6f"; cn = dense row-major [n_sites][n_sites] doubles.  One buffer, one
+ * write instead of 44 850 Python format operations (L = 300); model_io.write_raw_ec_file keeps the Python twin. */
+int plm_write_raw_ec_file(const char *path, int32_t n_sites, const int32_t *index_list, const char *target_seq,
+                          const double *cn);
 
 /* -- resident-context API (bench / multi-GPU host) ---------------------------------------- */
 /* Uploads the alignment once; everything below runs on data resident in HBM. */

@@ -217,6 +217,15 @@ def test_raw_ec_writer_reproduces_real_plmc_output_byte_for_byte(tmp_path, golde
     assert open(out, "rb").read() == open(src, "rb").read()
     if name == "test_b0.6":
         assert (tab["cn"] < 0).any() and (np.diff(sites) > 1).any()      # the cases the tiny golden does not have
+    # the library's writer (plm_write_raw_ec_file, the default) and its Python twin give the same bytes
+    twin = str(tmp_path / "ecs_twin.txt")
+    os.environ["PLM_IO_PYTHON"] = "1"
+    try:
+        model_io.write_raw_ec_file(twin, np.array(sites), "".join(letter[s] for s in sites), cn.astype(np.float32))
+    finally:
+        del os.environ["PLM_IO_PYTHON"]
+    model_io.write_raw_ec_file(out, np.array(sites), "".join(letter[s] for s in sites), cn.astype(np.float32))
+    assert open(out, "rb").read() == open(twin, "rb").read()
 
 
 # ------------------------------------------------------------------ stderr grammar
