@@ -2124,7 +2124,7 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
             Hm[a][Q + b] = (a == b) ? 1.0 : 0.0;
         }
         __syncthreads();
-        // The second-order sums M~ come from every 16th sequence tile; their row sums estimate the first-order sums
+        // The second-order sums M~ come from every PLM_HESS_SAMPLE-th sequence tile (32nd since round 6); their row sums estimate the first-order sums
         // m_a = sum_s w P_s(a) -- which this pass knows EXACTLY (gradient sum + weighted count of the state).  A rare state
         // whose few sequences happen to sit in (or outside) the sampled tiles has its row of M~ off by up to 16x, and the
         // site then converges at 0.6 ... 0.94 per step (round 5 traces: tails of 5-9 passes; at config 3 ten times the
