@@ -1419,7 +1419,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         PLM_TRY(dots(c, 1, a, a, d.nh_pad_l, SL_HH));
         return PLM_OK;
     };
-    auto direction = [&](int stored, int end, double *dginit) -> int {
+    // trial != nullptr: the launch also writes the first trial point of the line search, trial = xacc + stp0 * p
+    auto direction = [&](int stored, int end, double *dginit, const float *xacc, float stp0, float *trial) -> int {
         // p = sum cs[j] s_j + D^-1 (sum cy[j] y_j + cg g): two-loop recursion in coefficient space over the LIVE pairs,
         // the `stored` ring slots before `end` (after a skipped pair on a full ring the dead slot is `end` itself, not
         // the highest physical slot)
@@ -1434,7 +1435,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         for (int i = 0; i < stored; i++) { const int j = (end + m - 1 - i) % m; B.v[B.n] = Y + (size_t)j * n; C.c[B.n++] = (float)cy[j]; }
         B.v[B.n] = c->g;
         C.c[B.n++] = (float)cg;
-        HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, dinv, first_weighted, c->st));
+        if (trial) HIP_TRY(plm_launch_multiaxpy_trial(c->dir, B, C, n, dinv, first_weighted, xacc, stp0, trial, c->st));
+        else HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, dinv, first_weighted, c->st));
         return PLM_OK;
     };
 
@@ -1563,7 +1565,11 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
         double step = first_step();
         for (k = 1;; k++) {
             double dginit;
-            PLM_TRY(direction(stored, end, &dginit));
+            // the direction and, in the same pass, the first trial point x + stp0 p -- written where the trial points are
+            // built after the swap below (today's xp: the point before the accepted one, not needed any more unless it is
+            // still the anchor of the next pair, which lives in its own buffers then)
+            const float stp0 = (float)std::max(stpmin, std::min(stpmax, step));
+            PLM_TRY(direction(stored, end, &dginit, c->x, stp0, c->xp));
             if (!(dginit < 0)) { status = PLM_STATUS_LINESEARCH; ls_reason = 10; k--; break; }
             // the accepted point moves to (xp, gp); trial points are built in (x, g)
             std::swap(c->x, c->xp);
@@ -1590,16 +1596,15 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 if (!vp) PLM_TRY(ctx_eval_enqueue(c));
                 else PLM_TRY(ctx_eval_vp_enqueue(c, tol2));
               for (;;) {
-                const float *a[1] = {c->g}, *b[1] = {c->dir};
-                PLM_TRY(dots(c, 1, a, b, n, SL_DG));
                 // Speculate that this trial point is accepted (it is, 97 % of the time): form its (s, y) pair
                 // in slot `end` -- the slot the next pair goes to anyway; a rejected trial is simply
                 // overwritten by the next one -- and run the Gram pass now, so that ONE host
                 // synchronisation (and, sharded, one all-reduce) per trial brings back f, the directional
                 // derivative and everything the next direction needs.
-                HIP_TRY(plm_launch_sy(s_new, y_new, c->x, anchored ? c->xa : c->xp, c->g, anchored ? c->ga : c->gp, n, c->st));
-                HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + SL_MD, dinv, wq, wb, c->st));
-                PLM_TRY(norm_dots());
+                // (round 6: pair, Gram rows, g.p, x.x and the fields' x.x in ONE pass over the vectors)
+                HIP_TRY(plm_launch_sy_multidot(s_new, y_new, c->x, anchored ? c->xa : c->xp, c->g, anchored ? c->ga : c->gp,
+                                               c->dir, B, n, d.nh_pad_l, c->dot_scratch, c->scal + SL_MD, c->scal + SL_DG, dinv,
+                                               wq, wb, c->st));
                 PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
                 PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
                 bool again = false;      // the field solver's chain ran out of positions: more was enqueued (rare)
@@ -1619,7 +1624,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 if ((brackt && (stp <= stmin || stmax <= stp || count >= max_ls - 1 || uinfo)) ||
                     (brackt && stmax - stmin <= xtol * stmax))
                     stp = stx;
-                HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, (float)stp, c->dir, n, c->st));
+                if (!(count == 0 && (float)stp == stp0))      // the first trial point came with the direction
+                    HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, (float)stp, c->dir, n, c->st));
                 PLM_TRY(evaluate_trial());
                 double dg = c->h_scal[SL_DG];
                 fx = c->h_scal[SL_FX];
@@ -1974,15 +1980,11 @@ int plm_ctx_time_kernels(plm_ctx_t *c, int32_t reps, float *out_ms) {
         HIP_TRY(hipMemcpyAsync(c->gp, c->g, sizeof(float) * n, hipMemcpyDeviceToDevice, c->st));
         HIP_TRY(hipEventRecord(ev[0], c->st));
         for (int r = 0; r < reps; r++) {
-            const float *a[1] = {c->g}, *b[1] = {c->dir}, *xx[1] = {c->x};
-            HIP_TRY(plm_launch_lincomb(c->x, 1.f, c->xp, 0.f, c->dir, n, c->st));
-            HIP_TRY(plm_launch_dots(1, a, b, n, c->dot_scratch, c->scal + 2, c->st));
-            HIP_TRY(plm_launch_sy(S, Y, c->x, c->xp, c->g, c->gp, n, c->st));
-            HIP_TRY(plm_launch_multidot(Qv, B, n, c->dot_scratch, c->scal + 8, nullptr, 6u, 0ull, c->st));
-            HIP_TRY(plm_launch_dots(1, xx, xx, n, c->dot_scratch, c->scal + 3, c->st));
-            HIP_TRY(plm_launch_dots(1, xx, xx, d.nh_pad_l, c->dot_scratch, c->scal + 4, c->st));
+            // as the optimiser issues them: pair + Gram rows + scalar products in one pass, direction + first trial point
+            HIP_TRY(plm_launch_sy_multidot(S, Y, c->x, c->xp, c->g, c->gp, c->dir, B, n, d.nh_pad_l, c->dot_scratch, c->scal + 8,
+                                           c->scal + 2, nullptr, 6u, 0ull, c->st));
             B.n -= 1;
-            HIP_TRY(plm_launch_multiaxpy(c->dir, B, C, n, nullptr, m, c->st));
+            HIP_TRY(plm_launch_multiaxpy_trial(c->dir, B, C, n, nullptr, m, c->xp, 0.f, c->x, c->st));
             B.n += 1;
         }
         HIP_TRY(hipEventRecord(ev[1], c->st));

@@ -385,3 +385,17 @@ hipError_t plm_launch_precond(const PlmDims &d, const float *fv, float neff, flo
 // s = x - xp ; y = g - gp in one pass
 hipError_t plm_launch_sy(float *s, float *y, const float *x, const float *xp, const float *g, const float *gp,
                          int64_t n, hipStream_t st);
+// The vector work behind a trial point in ONE pass (round 6): the pair s = x - xp, y = g - gp is formed in registers, written
+// to its ring slot and used at once as the queries (s, y, g) of the Gram pass over `basis` -- the entries of `basis` that
+// ARE s_new / y_new / g are taken from the registers, the others read once -- together with g.dir, x.x and x.x over the first
+// nh entries (the fields).  Same accumulation per product as plm_launch_sy + plm_launch_multidot + three plm_launch_dots
+// (same grid, same reduction tree: the same bits), 33 instead of 41 vector transfers per iteration.
+//   out_md[q * basis.n + k] as plm_launch_multidot (queries s_new, y_new, g); out_ex[0..2] = g.dir, x.x, x.x (fields)
+hipError_t plm_launch_sy_multidot(float *s_new, float *y_new, const float *x, const float *xp, const float *g, const float *gp,
+                                  const float *dir, const PlmVecList &basis, int64_t n, int64_t nh, double *scratch,
+                                  double *out_md, double *out_ex, const float *dinv, unsigned wq, unsigned long long wb,
+                                  hipStream_t st);
+// plm_launch_multiaxpy that also writes the first trial point of the line search, trial = xacc + stp * out
+hipError_t plm_launch_multiaxpy_trial(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n,
+                                      const float *dinv, int first_weighted, const float *xacc, float stp, float *trial,
+                                      hipStream_t st);

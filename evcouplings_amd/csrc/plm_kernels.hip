@@ -31,6 +31,7 @@
 #include "plm_internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <utility>
 
@@ -3538,7 +3539,8 @@ hipError_t plm_launch_multidot(const PlmVecList &queries, const PlmVecList &basi
 
 // out = sum_{k < kw} c_k b_k  +  dinv (.) sum_{k >= kw} c_k b_k     (dinv == nullptr: plain linear combination)
 __global__ __launch_bounds__(256) void k_multiaxpy(float4 *__restrict__ out, PlmVecList B, PlmCoefList C, int64_t n4,
-                                                  const float4 *__restrict__ dinv, int kw) {
+                                                  const float4 *__restrict__ dinv, int kw,
+                                                  const float4 *__restrict__ xacc, float stp, float4 *__restrict__ trial) {
     const int nb = B.n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 r = {0.f, 0.f, 0.f, 0.f}, t = {0.f, 0.f, 0.f, 0.f};
@@ -3561,6 +3563,11 @@ __global__ __launch_bounds__(256) void k_multiaxpy(float4 *__restrict__ out, Plm
             r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
         }
         out[i] = r;
+        if (trial) {      // the first trial point of the line search: k_lincomb's arithmetic on the rounded direction
+            const float4 u = xacc[i];
+            trial[i] = make_float4(fmaf(stp, r.x, 1.f * u.x), fmaf(stp, r.y, 1.f * u.y), fmaf(stp, r.z, 1.f * u.z),
+                                   fmaf(stp, r.w, 1.f * u.w));
+        }
     }
 }
 hipError_t plm_launch_multiaxpy(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n,
@@ -3568,7 +3575,16 @@ hipError_t plm_launch_multiaxpy(float *out, const PlmVecList &basis, const PlmCo
     if (basis.n < 1 || basis.n > PLM_MAX_BASIS || (n & 3)) return hipErrorInvalidValue;
     const int kw = dinv ? std::max(0, std::min(basis.n, first_weighted)) : basis.n;
     hipLaunchKernelGGL(k_multiaxpy, dim3(2048), dim3(256), 0, st, (float4 *)out, basis, coef, n / 4,
-                       (const float4 *)dinv, kw);
+                       (const float4 *)dinv, kw, (const float4 *)nullptr, 0.f, (float4 *)nullptr);
+    return hipGetLastError();
+}
+hipError_t plm_launch_multiaxpy_trial(float *out, const PlmVecList &basis, const PlmCoefList &coef, int64_t n,
+                                      const float *dinv, int first_weighted, const float *xacc, float stp, float *trial,
+                                      hipStream_t st) {
+    if (basis.n < 1 || basis.n > PLM_MAX_BASIS || (n & 3) || !xacc || !trial) return hipErrorInvalidValue;
+    const int kw = dinv ? std::max(0, std::min(basis.n, first_weighted)) : basis.n;
+    hipLaunchKernelGGL(k_multiaxpy, dim3(2048), dim3(256), 0, st, (float4 *)out, basis, coef, n / 4,
+                       (const float4 *)dinv, kw, (const float4 *)xacc, stp, (float4 *)trial);
     return hipGetLastError();
 }
 
@@ -3586,5 +3602,147 @@ hipError_t plm_launch_sy(float *s, float *y, const float *x, const float *xp, co
     if (n & 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_sy, dim3(2048), dim3(256), 0, st, (float4 *)s, (float4 *)y, (const float4 *)x,
                        (const float4 *)xp, (const float4 *)g, (const float4 *)gp, n / 4);
+    return hipGetLastError();
+}
+
+// ---- the pair, the Gram pass and the scalar products of a trial point in one pass (plm_launch_sy_multidot) -------------
+#define SYD_OLD 10        // basis vectors read from memory per blockIdx.y: 2 (m - 1) at the default history m = 6
+struct PlmSyDot {
+    const float4 *x, *xp, *g, *gp, *dir, *dinv;
+    float4 *s_new, *y_new;
+    const float4 *old[PLM_MAX_BASIS];      // the basis vectors that are not s_new / y_new / g
+    int pos[PLM_MAX_BASIS];                // ... and their positions in the caller's basis order
+    int n_old, nb, pos_s, pos_y, pos_g0, pos_g1;      // (-1: the caller's basis does not hold that vector)
+    unsigned wq;
+    unsigned long long wb;
+    int64_t n4, nh4;
+};
+__device__ __forceinline__ double dot4(const float4 &a, const float4 &b) {
+    return (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+}
+__global__ __launch_bounds__(256) void k_sy_multidot(PlmSyDot A, double *__restrict__ scratch) {
+    __shared__ double red[4];
+    const int k0 = blockIdx.y * SYD_OLD;
+    const bool first = blockIdx.y == 0;
+    const float4 *bp[SYD_OLD];
+    unsigned wold = 0;
+#pragma unroll
+    for (int k = 0; k < SYD_OLD; k++) {
+        const int kk = min(k0 + k, max(A.n_old - 1, 0));
+        bp[k] = A.n_old > 0 ? A.old[kk] : A.g;
+        if (A.n_old > 0 && ((A.wb >> A.pos[kk]) & 1ull)) wold |= 1u << k;
+    }
+    const int spos[4] = {A.pos_s, A.pos_y, A.pos_g0, A.pos_g1};
+    bool wsp[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) wsp[e] = spos[e] >= 0 && ((A.wb >> spos[e]) & 1ull);
+    const bool any_w = A.dinv != nullptr && A.wq != 0;
+    double acc[3][SYD_OLD], sp[3][4], ex[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int k = 0; k < SYD_OLD; k++) acc[q][k] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) sp[q][e] = 0;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n4; i += (int64_t)gridDim.x * 256) {
+        const float4 xv = A.x[i], xpv = A.xp[i], gv = A.g[i], gpv = A.gp[i];
+        float4 qv[3], qd[3];
+        qv[0] = make_float4(xv.x - xpv.x, xv.y - xpv.y, xv.z - xpv.z, xv.w - xpv.w);
+        qv[1] = make_float4(gv.x - gpv.x, gv.y - gpv.y, gv.z - gpv.z, gv.w - gpv.w);
+        qv[2] = gv;
+        if (first) {
+            A.s_new[i] = qv[0];
+            A.y_new[i] = qv[1];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) qd[q] = qv[q];
+        if (any_w) {
+            const float4 dv = A.dinv[i];
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if ((A.wq >> q) & 1u) { qd[q].x *= dv.x; qd[q].y *= dv.y; qd[q].z *= dv.z; qd[q].w *= dv.w; }
+        }
+        if (A.n_old > 0) {
+#pragma unroll
+            for (int k = 0; k < SYD_OLD; k++) {
+                const float4 b = bp[k][i];
+                const bool wk = (wold >> k) & 1u;
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc[q][k] += dot4(wk ? qd[q] : qv[q], b);
+            }
+        }
+        if (first) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float4 b = e == 0 ? qv[0] : e == 1 ? qv[1] : gv;
+#pragma unroll
+                for (int q = 0; q < 3; q++) sp[q][e] += dot4(wsp[e] ? qd[q] : qv[q], b);
+            }
+            ex[0] += dot4(gv, A.dir[i]);
+            const double x2 = dot4(xv, xv);
+            ex[1] += x2;
+            if (i < A.nh4) ex[2] += x2;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int k = 0; k < SYD_OLD; k++) {
+            const double t = block_reduce_sum(acc[q][k], red);
+            if (threadIdx.x == 0 && k0 + k < A.n_old)
+                scratch[((size_t)q * A.nb + A.pos[k0 + k]) * PLM_DOT_BLOCKS + blockIdx.x] = t;
+            __syncthreads();
+        }
+    if (!first) return;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const double t = block_reduce_sum(sp[q][e], red);
+            if (threadIdx.x == 0 && spos[e] >= 0) scratch[((size_t)q * A.nb + spos[e]) * PLM_DOT_BLOCKS + blockIdx.x] = t;
+            __syncthreads();
+        }
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const double t = block_reduce_sum(ex[e], red);
+        if (threadIdx.x == 0) scratch[((size_t)3 * A.nb + e) * PLM_DOT_BLOCKS + blockIdx.x] = t;
+        __syncthreads();
+    }
+}
+// rows [0, na) of the scratch go to out_a, the rows behind them to out_b
+__global__ __launch_bounds__(256) void k_dots_final2(const double *__restrict__ scratch, double *out_a, int na, double *out_b) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int i = threadIdx.x; i < PLM_DOT_BLOCKS; i += 256) s += scratch[(size_t)blockIdx.x * PLM_DOT_BLOCKS + i];
+    const double t = block_reduce_sum(s, red);
+    if (threadIdx.x == 0) {
+        if ((int)blockIdx.x < na) out_a[blockIdx.x] = t;
+        else out_b[blockIdx.x - na] = t;
+    }
+}
+hipError_t plm_launch_sy_multidot(float *s_new, float *y_new, const float *x, const float *xp, const float *g, const float *gp,
+                                  const float *dir, const PlmVecList &basis, int64_t n, int64_t nh, double *scratch,
+                                  double *out_md, double *out_ex, const float *dinv, unsigned wq, unsigned long long wb,
+                                  hipStream_t st) {
+    if (basis.n < 1 || basis.n > PLM_MAX_BASIS - 1 || (n & 3) || (nh & 3) || nh > n) return hipErrorInvalidValue;
+    PlmSyDot A;
+    memset(&A, 0, sizeof A);
+    A.x = (const float4 *)x; A.xp = (const float4 *)xp; A.g = (const float4 *)g; A.gp = (const float4 *)gp;
+    A.dir = (const float4 *)dir; A.dinv = (const float4 *)dinv;
+    A.s_new = (float4 *)s_new; A.y_new = (float4 *)y_new;
+    A.nb = basis.n; A.wq = wq; A.wb = wb; A.n4 = n / 4; A.nh4 = nh / 4;
+    A.pos_s = A.pos_y = A.pos_g0 = A.pos_g1 = -1;
+    for (int k = 0; k < basis.n; k++) {
+        const float *v = basis.v[k];
+        if (v == s_new && A.pos_s < 0) A.pos_s = k;
+        else if (v == y_new && A.pos_y < 0) A.pos_y = k;
+        else if (v == g && A.pos_g0 < 0) A.pos_g0 = k;
+        else if (v == g && A.pos_g1 < 0) A.pos_g1 = k;
+        else { A.old[A.n_old] = (const float4 *)v; A.pos[A.n_old++] = k; }
+    }
+    const dim3 grid(PLM_DOT_BLOCKS, std::max(1, (A.n_old + SYD_OLD - 1) / SYD_OLD)), block(256);
+    hipLaunchKernelGGL(k_sy_multidot, grid, block, 0, st, A, scratch);
+    hipLaunchKernelGGL(k_dots_final2, dim3(3 * basis.n + 3), dim3(256), 0, st, scratch, out_md, 3 * basis.n, out_ex);
     return hipGetLastError();
 }
