@@ -231,6 +231,11 @@ template <int NF, int A, int NP, int STG, int NW = 8> __device__ __forceinline__
     }
 }
 
+// the value lane `src` (compile-time constant after unrolling) holds, in every lane: two v_readlane_b32
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2065,13 +2070,19 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
     {
         // gradient sums: lane = sequence tile (mod 64), then the 64 lane sums per state are added in a fixed butterfly
         // -- 64 loads in flight per state instead of a chain of nstiles dependent ones
+        // (round 6: two tiles per round, 2 Q loads in flight -- the loop was a chain of load latencies; same order of sums)
         double part[Q];
 #pragma unroll
         for (int k = 0; k < Q; k++) part[k] = 0;
-        for (int tt = t; tt < d.nstiles; tt += 64) {
-            const double *src = gpart + (((size_t)b16l * d.nstiles + tt) * 16 + r) * Q;
+        for (int tt = t; tt < d.nstiles; tt += 128) {
+            const bool two = tt + 64 < d.nstiles;
+            const double *src0 = gpart + (((size_t)b16l * d.nstiles + tt) * 16 + r) * Q;
+            const double *src1 = gpart + (((size_t)b16l * d.nstiles + (two ? tt + 64 : tt)) * 16 + r) * Q;
+            double v0[Q], v1[Q];
 #pragma unroll
-            for (int k = 0; k < Q; k++) part[k] += src[k];
+            for (int k = 0; k < Q; k++) { v0[k] = src0[k]; v1[k] = src1[k]; }
+#pragma unroll
+            for (int k = 0; k < Q; k++) { part[k] += v0[k]; if (two) part[k] += v1[k]; }
         }
 #pragma unroll
         for (int k = 0; k < Q; k++) {
@@ -2084,8 +2095,17 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
         const int nsamp = (d.nstiles + PLM_HESS_SAMPLE - 1) / PLM_HESS_SAMPLE;
         for (int k = t; k < NH; k += 64) {      // Hessian sums exist for the sampled tiles only
             double v = 0;
-            for (int tt = 0; tt < d.nstiles; tt += PLM_HESS_SAMPLE)
-                v += (double)hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NH + k];
+            for (int j0 = 0; j0 < nsamp; j0 += 8) {      // eight loads in flight (round 6), summed in tile order as before
+                float u[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int tt = min(j0 + j, nsamp - 1) * PLM_HESS_SAMPLE;
+                    u[j] = hpart[(((size_t)b16l * d.nstiles + tt) * 16 + r) * NH + k];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (j0 + j < nsamp) v += (double)u[j];
+            }
             st[Q + k] = v * ((double)d.nstiles / nsamp) * (Q > 21 ? 4.0 : 1.0);     // above 21 states 2 waves of 8 carry them
         }
         // exact diagonal second-order sums M_aa = sum_s w P_a^2 over ALL sequences (round 6): the tiles without Hessian
@@ -2094,15 +2114,23 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
             double part[Q];
 #pragma unroll
             for (int k = 0; k < Q; k++) part[k] = 0;
-            for (int tt = t; tt < d.nstiles; tt += 64) {
-                const size_t blk = ((size_t)b16l * d.nstiles + tt) * 16 + r;
-                if (Q <= 21 && (tt % PLM_HESS_SAMPLE) == 0) {      // (above 21 states every tile delivers its diagonal sums)
+            for (int tt0 = t; tt0 < d.nstiles; tt0 += 128) {      // two tiles per round, as for the gradient sums
+                const bool two = tt0 + 64 < d.nstiles;
+                double v[2][Q];
 #pragma unroll
-                    for (int k = 0; k < Q; k++) part[k] += (double)hpart[blk * NH + (k * Q - k * (k - 1) / 2)];   // (k, k) of the upper triangle
-                } else {
+                for (int h = 0; h < 2; h++) {
+                    const int tt = (h && two) ? tt0 + 64 : tt0;
+                    const size_t blk = ((size_t)b16l * d.nstiles + tt) * 16 + r;
+                    if (Q <= 21 && (tt % PLM_HESS_SAMPLE) == 0) {      // (above 21 states every tile delivers its diagonal sums)
 #pragma unroll
-                    for (int k = 0; k < Q; k++) part[k] += dpart[blk * Q + k];
+                        for (int k = 0; k < Q; k++) v[h][k] = (double)hpart[blk * NH + (k * Q - k * (k - 1) / 2)];   // (k, k) of the upper triangle
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < Q; k++) v[h][k] = dpart[blk * Q + k];
+                    }
                 }
+#pragma unroll
+                for (int k = 0; k < Q; k++) { part[k] += v[0][k]; if (two) part[k] += v[1][k]; }
             }
 #pragma unroll
             for (int k = 0; k < Q; k++) {
@@ -2173,18 +2201,30 @@ __global__ __launch_bounds__(64) void k_hsolve(PlmDims d, const float *__restric
         __syncthreads();
         if (t < Q) Hm[t][t] += Hm[t][2 * Q] + 2.0 * lambda_h + 1e-12 * (1.0 + Hm[t][2 * Q]);
         __syncthreads();
-        // Gauss-Jordan without pivoting (H is symmetric positive definite): lane -> one of the 2Q columns
-        for (int p = 0; p < Q; p++) {
-            const double piv = 1.0 / Hm[p][p];
-            __syncthreads();
-            if (t < 2 * Q) Hm[p][t] *= piv;
-            __syncthreads();
-            const double fcol = (t < Q) ? Hm[t][p] : 0.0;   // column p before it is eliminated (lane = row)
-            __syncthreads();
-            for (int a = 0; a < Q; a++) {
-                if (a == p) continue;
-                const double f = __shfl(fcol, a, 64);
-                if (t < 2 * Q) Hm[a][t] -= f * Hm[p][t];     // every lane stays in its own column
+        // Gauss-Jordan without pivoting (H is symmetric positive definite): lane -> one of the 2Q columns, held in
+        // REGISTERS over all Q pivots (round 6; the LDS version read-modified-wrote its column once per row and pivot:
+        // ~20 of the kernel's 34 us).  Row p of the own column is the lane's own register; the multipliers of a pivot
+        // -- column p before it is eliminated -- are lane p's registers, broadcast with v_readlane.  Same operations
+        // in the same order as before: the same inverse, bit for bit.
+        {
+            double col[Q];
+            const int tc = min(t, 2 * Q - 1);
+#pragma unroll
+            for (int a = 0; a < Q; a++) col[a] = Hm[a][tc];
+#pragma unroll
+            for (int p = 0; p < Q; p++) {
+                const double piv = 1.0 / lane_bcast(col[p], p);
+                col[p] *= piv;
+#pragma unroll
+                for (int a = 0; a < Q; a++) {
+                    if (a == p) continue;
+                    const double f = lane_bcast(col[a], p);
+                    col[a] -= f * col[p];
+                }
+            }
+            if (t >= Q && t < 2 * Q) {
+#pragma unroll
+                for (int a = 0; a < Q; a++) Hm[a][t] = col[a];
             }
             __syncthreads();
         }
