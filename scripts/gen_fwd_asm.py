@@ -48,6 +48,14 @@ NODMA = int(os.environ.get("FWDW_NODMA", "0"))
 NOSYNC = int(os.environ.get("FWDW_NOSYNC", "0"))
 RD_GAPS = tuple(int(v) for v in os.environ.get("FWDW_RDGAPS", "5,6").split(","))
 DMA_GAPS = tuple(int(v) for v in os.environ.get("FWDW_DMAGAPS", "3,4").split(","))
+# Schedule of the fillers (round 6, scripts/ubench/mfma_coissue.hip): behind a v_smfmac of the one wave a SIMD hosts ONE
+# VALU operation issues for free and so does one LDS read -- but a VALU operation and an LDS read (or an LDS-DMA copy) in
+# the SAME gap cost 11 / 46 cycles.  SCHED 1 keeps them apart: the one-hot build is spread over the gaps 0-4 and 7 of
+# fragments 0..12, gaps 5 / 6 belong to the LDS reads, gap 4 of the copying fragments to the copy.  SCHED 0 = round 4's
+# (build in every gap of the first 8 fragments).
+SCHED = int(os.environ.get("FWDW_SCHED", "1"))
+VALU_GAPS = tuple(int(v) for v in os.environ.get("FWDW_VALUGAPS", "0,1,2,3,4,7").split(","))
+CNT_GAP = int(os.environ.get("FWDW_CNTGAP", str(RD_GAPS[0])))      # gap of the arrival counter's read in fragment CNT_READ_FRAG
 
 
 def vr(b, n):
@@ -98,15 +106,29 @@ def slice_block(cur):
     nxt = 1 - cur
     L = ["s_waitcnt lgkmcnt(%d)" % (2 if NOSYNC else 3)]          # fragment 0 is in; fragment 1 (2 reads) and the arrival add may be in flight
     dma = dma_ops()
+    # SCHED 1: the build operations of all row fragments in order, one per VALU gap (cmp / cndmask stay adjacent in the
+    # VALU stream: nothing else writes VCC)
+    valu_slots = {}
+    if SCHED and not NOBUILD:
+        flat = [o for m in range(NM) for o in build_ops(nxt, m, nxt)]
+        slots = [(F, g) for F in range(NF) for g in VALU_GAPS
+                 if not (g == DMA_GAPS[1] and F in DMA_FRAGS) and not (F == CNT_CHECK_FRAG and g in (0, 1))
+                 and not (F == CNT_READ_FRAG and g == CNT_GAP)]
+        assert len(flat) <= len(slots), (len(flat), len(slots))
+        for o, sl in zip(flat, slots):
+            valu_slots.setdefault(sl, []).append(o)
     for F in range(NF):
         a = F % QG
         gaps = [[] for _ in range(NM)]
-        if F < NM and not NOBUILD:
+        if SCHED:
+            for g in range(NM):
+                gaps[g] += valu_slots.get((F, g), [])
+        elif F < NM and not NOBUILD:
             ops = build_ops(nxt, F, nxt)
             for j, o in enumerate(ops):       # cmp / cndmask pairs in order, one operation per gap; the move rides along
                 gaps[j if j < NM else NM - 2].append(o)
         if F == CNT_READ_FRAG and not NOSYNC:
-            gaps[RD_GAPS[0]].append(f"ds_read_b32 v{VCNT}, %[cnt]")
+            gaps[CNT_GAP if SCHED else RD_GAPS[0]].append(f"ds_read_b32 v{VCNT}, %[cnt]")
         if F == CNT_CHECK_FRAG and not NOSYNC:
             gaps[0] += [f"v_readfirstlane_b32 %[st], v{VCNT}", "s_cmp_ge_u32 %[st], %[tgt]"]
             gaps[1] += ["s_cbranch_scc1 .Lfwdw_go_%=", "s_mov_b32 %[sp], 0x400000", ".Lfwdw_poll_%=:",
@@ -120,7 +142,7 @@ def slice_block(cur):
             gaps[RD_GAPS[1]].append(rd[1])
         if F in DMA_FRAGS and not NODMA:
             m0, ld = dma[DMA_FRAGS.index(F)]
-            gaps[DMA_GAPS[0]].append(m0)
+            gaps[DMA_GAPS[0]].append(m0)      # (SALU: free beside the VALU operation of its gap)
             gaps[DMA_GAPS[1]].append(ld)
         if F + 1 < NF and not NOLDS:
             gaps[7].append("s_waitcnt lgkmcnt(2)")       # all but the two newest reads: fragment F + 1 is in
