@@ -628,8 +628,7 @@ int ctx_eval_vp_enqueue(plm_ctx *c, double tol2) {
     const int c_prev = c->vp_c_prev;
     if (c->vp_hess_age >= 0) c->vp_hess_age++;
     const bool stale = c->vp_hess_age < 0 || c->vp_hess_age >= 32;
-    HIP_TRY(plm_launch_vp_reset(c->vp_flag, (c_prev == 0 && !stale) ? 1 : 0, c->st));
-    HIP_TRY(hipMemsetAsync(c->scal + 5, 0, 3 * sizeof(double), c->st));
+    HIP_TRY(plm_launch_vp_reset(c->vp_flag, (c_prev == 0 && !stale) ? 1 : 0, c->scal + 5, c->st));
     c->vp_pos = 0;
     c->vp_extra = 0;
     c->vp_hess_mask = 0;

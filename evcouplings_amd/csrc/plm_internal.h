@@ -280,7 +280,7 @@ struct PlmVpState {
 #define PLM_VP_PASS 1       // chain pass in its statistics role: runs while !done && !want_rt
 #define PLM_VP_PASS_RT 2    // chain pass in its residual-writing role: runs while !done && want_rt
 #define PLM_VP_FINAL 3      // residual pass after the chain: runs unless final_skip
-hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st);
+hipError_t plm_launch_vp_reset(int *state, int want_rt, double *zero3, hipStream_t st);   // zero3: three scalar slots cleared with the state (or nullptr)
 // Per-site gradient norms of the last pass (their sum -> g2_out[0]); update = 1: sites above their share of tol2 take a
 // Newton step on the field part of x (full = 1: that pass carried Hessian sums: inverse recomputed and cached in hinv
 // [sites][Q][Q]; 0: the cached inverse; 2: a chain position with Hessian sums -- fresh unless the pass ran in its

@@ -2376,14 +2376,15 @@ __global__ __launch_bounds__(256) void k_vp_check(const double *__restrict__ g2_
         S->g2_prev = t;
     }
 }
-__global__ void k_vp_reset(int *state, int want_rt) {
+__global__ void k_vp_reset(int *state, int want_rt, double *zero3) {
     PlmVpState *S = (PlmVpState *)state;
+    if (zero3) zero3[0] = zero3[1] = zero3[2] = 0.0;      // the chain's scalar slots (norm, passes, verdict)
     S->done = 0; S->want_rt = want_rt; S->final_skip = 0; S->passes = 0; S->cur = 0; S->g2_prev = 0.0; S->g2_prev2 = 0.0;
     for (int k = 0; k < PLM_VP_HIST; k++) S->hist[k] = 0.0;
     for (int k = 0; k < PLM_VP_MAXBLK; k++) S->quiet[k] = 0;
 }
-hipError_t plm_launch_vp_reset(int *state, int want_rt, hipStream_t st) {
-    hipLaunchKernelGGL(k_vp_reset, dim3(1), dim3(1), 0, st, state, want_rt);
+hipError_t plm_launch_vp_reset(int *state, int want_rt, double *zero3, hipStream_t st) {
+    hipLaunchKernelGGL(k_vp_reset, dim3(1), dim3(1), 0, st, state, want_rt, zero3);
     return hipGetLastError();
 }
 hipError_t plm_launch_hsolve(const PlmDims &d, const float *hpart, const double *gpart, int full, float *x, double *h64,
@@ -3105,12 +3106,27 @@ __global__ __launch_bounds__(256) void k_finish_fx(const double *__restrict__ fx
         if (threadIdx.x == 0)
             for (int k = 0; k < nshard; k++) s += *(const double *)((const char *)shard_nll + k * shard_stride);
     } else {
-        for (int i = threadIdx.x; i < nfx; i += 256) s += fx_part[i];
+        // sixteen loads in flight, summed in index order as before (the plain loop was a chain of load latencies: 14 us)
+        for (int i0 = threadIdx.x; i0 < nfx; i0 += 16 * 256) {
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = fx_part[min(i0 + j * 256, nfx - 1)];
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (i0 + j * 256 < nfx) s += v[j];
+        }
     }
     const double nll = block_reduce_sum(s, red);
     __syncthreads();
     double rsum = 0;
-    for (int i = threadIdx.x; i < nreg; i += 256) rsum += reg_part[i];
+    for (int i0 = threadIdx.x; i0 < nreg; i0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = reg_part[min(i0 + j * 256, nreg - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (i0 + j * 256 < nreg) rsum += v[j];
+    }
     const double reg = block_reduce_sum(rsum, red);
     if (threadIdx.x == 0) {
         out2[0] = nll + reg;
