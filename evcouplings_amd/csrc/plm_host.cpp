@@ -940,6 +940,19 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
     std::vector<int8_t> rm(rm_rows * d.Lp32, (int8_t)PLM_PAD_STATE);
     for (int s = 0; s < d.N; s++) memcpy(&rm[(size_t)s * d.Lp32], prob->msa + (size_t)s * d.L, d.L);
     const size_t cm_size = cm_rows * d.Np;
+    {
+        // Refuse a problem the device cannot hold BEFORE allocating: the runtime grants allocations beyond the HBM and the
+        // failure would surface at some later launch.  What a fit holds: the operands of the two GEMMs, the stored
+        // potentials, x, g, the canonical image and the optimiser's 2 m + 3 vectors (m = 6 unless the caller asks for more).
+        const int m = std::min(20, prob->lbfgs_m > 0 ? prob->lbfgs_m : 6);
+        const double need = (double)rm.size() + (double)cm_size + (double)plm_bt_bytes(d) + (double)plm_rt_bytes(dmax) +
+                            (double)plm_g_bytes(dmax) + (vp_enabled(c) ? (double)plm_hj_bytes(d) : 0.0) +
+                            4.0 * ((double)d.n_local * (2 * m + 5) + (double)d.n_canon + (double)d.L * d.L);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b)
+            return bail(fail(PLM_ENOMEM, "the problem needs %.1f GB of device memory, %.1f GB are free (of %.1f GB)", need / 1e9,
+                             free_b / 1e9, total_b / 1e9));
+    }
     if ((rc = dalloc(&c->msa_rm, rm.size())) || (rc = dalloc(&c->msa_cm, cm_size)) ||
         (rc = dalloc(&c->w, (size_t)d.Np)) || (rc = dalloc(&c->counts, (size_t)d.Np)) ||
         (rc = dalloc((char **)&c->Bt, plm_bt_bytes(d))) || (rc = dalloc((char **)&c->Rt, plm_rt_bytes(dmax))) ||
@@ -975,7 +988,9 @@ int plm_ctx_create(const plm_problem_t *prob, int device, void *stream, plm_ctx_
         return bail(fail(PLM_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e)));
 #define CT(expr)                                                                                  \
     if ((e = (expr)) != hipSuccess)                                                               \
-        return bail(fail(PLM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e)));
+        return bail(fail(e == hipErrorOutOfMemory ? PLM_ENOMEM : PLM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e)));
+    // (a problem beyond the device may get its hipMallocs granted and meet hipErrorOutOfMemory only here, at the first
+    // launch: tests/test_gpu_parity.py::test_a_problem_that_does_not_fit_the_device_is_refused_with_enomem)
     CT(hipMemcpyAsync(c->msa_rm, rm.data(), rm.size(), hipMemcpyHostToDevice, c->st));
     CT(plm_launch_msa_columns(d, c->msa_rm, c->msa_cm, (int)cm_rows, c->st));
     CT(hipMemsetAsync(c->w, 0, sizeof(float) * d.Np, c->st));
@@ -2191,7 +2206,7 @@ static int energies_impl(const int8_t *seqs, int32_t n, int32_t L, int32_t q, co
     hipError_t e;
 #define ET(expr)                                                                                   \
     if ((e = (expr)) != hipSuccess)                                                                \
-        return cleanup(fail(PLM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e)));
+        return cleanup(fail(e == hipErrorOutOfMemory ? PLM_ENOMEM : PLM_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e)));
     ET(hipMemcpyAsync(msa_rm, rm.data(), rm.size(), hipMemcpyHostToDevice, st));
     ET(hipMemcpyAsync(canon, x_canon, sizeof(float) * d.n_canon, hipMemcpyHostToDevice, st));
     ET(hipMemsetAsync(x, 0, sizeof(float) * d.n_native, st));

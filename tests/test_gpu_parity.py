@@ -1492,3 +1492,33 @@ def test_compact_gap_output_equals_the_stripped_q_state_arrays(plm):
     np.testing.assert_array_equal(cut["jij"], full["jij"][:, 1:, 1:])
     np.testing.assert_array_equal(cut["cn"], full["cn"])
     assert np.abs(cut["jij"]).max() > 0 and abs(cut["fij"].sum() / npair - 1.0) < 1e-3
+
+
+# ---------------------------------------------------------------- sizes at and beyond the device (maximum sizes)
+def test_a_problem_that_does_not_fit_the_device_is_refused_with_enomem(plm):
+    """L = 20 000 sites: one parameter vector alone is 353 GB (the optimiser holds 17 of them) -- no MI355X has that.  The fit
+    must come back with PLM_ENOMEM (tools.run_plmc_hip turns it into the reference's ExternalToolError), not crash, and the
+    device must still serve the next call."""
+    from evcouplings_amd import _lib
+    rng = np.random.default_rng(5)
+    big = rng.integers(1, Q, size=(4, 20000)).astype(np.int8)
+    with pytest.raises(_lib.PlmError) as err:
+        plm.fit(big, q=Q, max_iter=2, want_fij=False)
+    assert err.value.code == -2, str(err.value)      # PLM_ENOMEM (include/plm_hip.h)
+    msa, _ = synthetic_msa(300, 20, seed=2)
+    r = plm.fit(msa, q=Q, max_iter=5)
+    assert r["iters"] >= 1 and np.isfinite(r["cn"]).all()
+
+
+def test_long_and_deep_alignments_match_the_oracle(plm, oracle64):
+    """Shapes far outside the BASELINE table (tests/probes/extreme_shapes_probe.py runs L = 1536 / 2500 and more): 700 sites with few
+    sequences, 60 000 sequences on two site blocks -- the evaluation against the f64 oracle at a random point."""
+    for N, L in ((100, 700), (60000, 24)):
+        msa, _ = synthetic_msa(N, L, seed=N + L)
+        w = (1.0 / plm.reweight(msa, 0.8)).astype(np.float32)
+        x = (0.05 * np.random.default_rng(L).normal(size=plm.n_params(L, Q))).astype(np.float32)
+        lj = plm.default_lambda_j(L, Q)
+        fx, nll, g = plm.evaluate(msa, w, Q, 0.01, lj, x)
+        fxo, nllo, go = oracle64.eval(msa, w.astype(np.float64), Q, 0.01, lj, x.astype(np.float64))
+        assert fx == pytest.approx(fxo, rel=2e-6) and nll == pytest.approx(nllo, rel=2e-6)
+        assert np.abs(g - go).max() <= 2e-5 * np.abs(go).max()
