@@ -13,7 +13,8 @@ fragments = 112 v_smfmac_f32_16x16x64_f16.  With the K order of k_expand (slice 
 states) the compressed one-hot fragment of a row fragment and slice is
     value of pair p  = 1.0 where (state - 1) >> 2 of site 4 (ci % 2) + p equals ci / 2      (byte compare, SDWA)
     2-bit positions  = (state - 1) & 3 of those four sites                                  (per u, not per slice)
-and the fragments of slice ci + 1 are built in the gaps of slice ci's first 8 B fragments (9 VALU per row fragment).
+and the fragments of slice ci + 1 are built behind the MFMAs of slice ci (9 VALU per row fragment), ONE operation per gap and
+never in a gap that holds an LDS read or a copy (SCHED below: round 6, after scripts/ubench/mfma_coissue.hip).
 
 Register map of a wave (arch VGPRs from V_LO; everything below belongs to the compiler):
     AS[set][m]   4 value dwords, AI[set][m] the index word; slice ci computes on set ci % 2 and builds the other
