@@ -3781,7 +3781,7 @@ hipError_t plm_launch_sy_multidot(float *s_new, float *y_new, const float *x, co
                                   const float *dir, const PlmVecList &basis, int64_t n, int64_t nh, double *scratch,
                                   double *out_md, double *out_ex, const float *dinv, unsigned wq, unsigned long long wb,
                                   hipStream_t st) {
-    if (basis.n < 1 || basis.n > PLM_MAX_BASIS - 1 || (n & 3) || (nh & 3) || nh > n) return hipErrorInvalidValue;
+    if (basis.n < 1 || basis.n > PLM_MAX_BASIS || (n & 3) || (nh & 3) || nh > n) return hipErrorInvalidValue;
     PlmSyDot A;
     memset(&A, 0, sizeof A);
     A.x = (const float4 *)x; A.xp = (const float4 *)xp; A.g = (const float4 *)g; A.gp = (const float4 *)gp;

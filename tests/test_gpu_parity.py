@@ -1522,3 +1522,19 @@ def test_long_and_deep_alignments_match_the_oracle(plm, oracle64):
         fxo, nllo, go = oracle64.eval(msa, w.astype(np.float64), Q, 0.01, lj, x.astype(np.float64))
         assert fx == pytest.approx(fxo, rel=2e-6) and nll == pytest.approx(nllo, rel=2e-6)
         assert np.abs(g - go).max() <= 2e-5 * np.abs(go).max()
+
+
+@pytest.mark.parametrize("kw", [dict(lbfgs_m=3), dict(lbfgs_m=10), dict(lbfgs_m=20), dict(precond=True),
+                                dict(precond=True, lbfgs_m=12), dict(joint=True, lbfgs_m=10), dict(joint=True, precond=True)])
+def test_history_sizes_and_the_diagonal_metric_reach_the_same_optimum(plm, kw):
+    """The vector work of an iteration is one pass (k_sy_multidot: the pair formed in registers, Gram rows over the history
+    in chunks of ten vectors read from memory) + the direction: other history sizes than the default m = 6 run it with one to
+    four chunks, PLM_FLAG_PRECOND with the H0 metric on the flagged products.  Convex objective: every variant must end at
+    the default fit's optimum."""
+    msa, _ = synthetic_msa(2000, 48, seed=77)
+    ref = plm.fit(msa, q=Q, max_iter=3000, epsilon=1e-4, want_fij=False)
+    assert ref["status"] == 0, ref["status_msg"]
+    r = plm.fit(msa, q=Q, max_iter=6000, epsilon=1e-4, want_fij=False, **kw)
+    assert r["status"] == 0, (kw, r["status_msg"])
+    assert abs(r["fx"] - ref["fx"]) <= 1e-7 * abs(ref["fx"]), (kw, r["fx"], ref["fx"])
+    assert np.abs(r["cn"] - ref["cn"]).max() <= 2e-3 * np.abs(ref["cn"]).max(), kw
