@@ -30,7 +30,7 @@ extern "C" {
 
 #define PLM_OK 0
 #define PLM_EINVAL (-1)      /* bad argument (NULL, size <= 0, state outside 0..q-1, ...) */
-#define PLM_ENOMEM (-2)      /* host or device allocation failed */
+#define PLM_ENOMEM (-2)      /* host or device allocation failed, or the problem needs more device memory than is free (checked up front) */
 #define PLM_EDEVICE (-3)     /* HIP runtime error / no gfx950 device */
 #define PLM_EUNSUPPORTED (-4)/* alphabet size outside 2..32 (any size in that range runs, padded to 4 / 5 / 20 / 21 / 32) */
 #define PLM_ENUMERIC (-5)    /* NaN/Inf met in objective */
