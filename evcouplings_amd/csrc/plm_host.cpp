@@ -1719,6 +1719,9 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 break;
             }
             restarts = 0;
+            if (c->opt.debug)
+                fprintf(stderr, "[plm] it %d: %d trial(s), step %.4e (first %.4e), f - f0 = %.6e, dg0 = %.4e, dg = %.4e%s\n", k, count, stp,
+                        trace[0][0], fx - finit, dginit, c->h_scal[SL_DG], c->fwd_accurate ? " [accurate]" : "");
             step = stp;
             // the pair of the accepted point already sits in slot `end` and its Gram rows in h_scal (see above)
             const double *md = c->h_scal + SL_MD;
