@@ -1783,6 +1783,10 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             // pairs; the slot is written again by the next iteration -- with a pair over the longer baseline from the
             // anchor, see `anchored`).
             const double sy = SY[e * m + e], ss = md[0 * nbv + e], yy = md[1 * nbv + nst + e];
+            if (c->opt.debug)
+                fprintf(stderr, "[plm]        pair: s.y = %.4e, |s| = %.4e, |y| = %.4e, cos = %.3e; history %d pair(s)%s%s\n", sy,
+                        std::sqrt(ss), std::sqrt(yy), sy / std::sqrt(std::max(1e-300, ss * yy)), stored,
+                        anchored ? ", anchored" : "", straddle ? ", straddle" : "");
             if (straddle) {
                 // y = g_accurate(x) - g_plain(previous x) carries the DIFFERENCE of the two evaluations' errors (~3e-11 N L
                 // |x|): not a curvature pair.  It is dropped (slot e, the oldest pair once the ring is full, goes with it);
