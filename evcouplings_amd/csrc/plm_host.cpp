@@ -1619,8 +1619,8 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
                 HIP_TRY(plm_launch_sy_multidot(s_new, y_new, c->x, anchored ? c->xa : c->xp, c->g, anchored ? c->ga : c->gp,
                                                c->dir, B, n, d.nh_pad_l, c->dot_scratch, c->scal + SL_MD, c->scal + SL_DG, dinv,
                                                wq, wb, c->st));
-                PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
-                PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n - SL_FX));
+                PLM_TRY(ctx_allreduce_scalars(c, SL_FX, SL_MD + 3 * B.n + 1 - SL_FX));
+                PLM_TRY(fetch_scalars(c, SL_FX, SL_MD + 3 * B.n + 1 - SL_FX));
                 bool again = false;      // the field solver's chain ran out of positions: more was enqueued (rare)
                 if (vp) PLM_TRY(ctx_eval_vp_finish(c, tol2, &again, &gh2_trial));
                 if (!again) break;
@@ -1782,10 +1782,16 @@ int plm_ctx_optimize(plm_ctx_t *c, plm_iter_cb cb, void *user, plm_result_t *res
             // pure noise has cos ~ 1 / sqrt(P) = 2e-4: pairs below 1e-3 are not stored (the history keeps its other
             // pairs; the slot is written again by the next iteration -- with a pair over the longer baseline from the
             // anchor, see `anchored`).
-            const double sy = SY[e * m + e], ss = md[0 * nbv + e], yy = md[1 * nbv + nst + e];
+            // Variable projection: y has no field part (the reduced gradient's is zero), the curvature information of the pair
+            // lives in the couplings -- but s carries the CHANGE OF THE OPTIMAL FIELDS as well, which enters no product of the
+            // two-loop recursion and only lowers cos(s, y) (0.12 -> 0.04 at the headline; at N = 500 000 below the admission
+            // rule: every pair of the accurate phase was skipped and the history went stale, NOTES_r06.md).  The rule looks at
+            // the coupling part of s.
+            const double ss_full = md[0 * nbv + e], ss_h = vp ? std::min(ss_full, std::max(0.0, md[3 * nbv])) : 0.0;
+            const double sy = SY[e * m + e], ss = std::max(ss_full - ss_h, 1e-300), yy = md[1 * nbv + nst + e];
             if (c->opt.debug)
-                fprintf(stderr, "[plm]        pair: s.y = %.4e, |s| = %.4e, |y| = %.4e, cos = %.3e; history %d pair(s)%s%s\n", sy,
-                        std::sqrt(ss), std::sqrt(yy), sy / std::sqrt(std::max(1e-300, ss * yy)), stored,
+                fprintf(stderr, "[plm]        pair: s.y = %.4e, |s| = %.4e (couplings %.4e), |y| = %.4e, cos = %.3e; history %d pair(s)%s%s\n",
+                        sy, std::sqrt(ss_full), std::sqrt(ss), std::sqrt(yy), sy / std::sqrt(std::max(1e-300, ss * yy)), stored,
                         anchored ? ", anchored" : "", straddle ? ", straddle" : "");
             if (straddle) {
                 // y = g_accurate(x) - g_plain(previous x) carries the DIFFERENCE of the two evaluations' errors (~3e-11 N L

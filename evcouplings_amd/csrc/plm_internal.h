@@ -390,7 +390,8 @@ hipError_t plm_launch_sy(float *s, float *y, const float *x, const float *xp, co
 // ARE s_new / y_new / g are taken from the registers, the others read once -- together with g.dir, x.x and x.x over the first
 // nh entries (the fields).  Same accumulation per product as plm_launch_sy + plm_launch_multidot + three plm_launch_dots
 // (same grid, same reduction tree: the same bits), 33 instead of 41 vector transfers per iteration.
-//   out_md[q * basis.n + k] as plm_launch_multidot (queries s_new, y_new, g); out_ex[0..2] = g.dir, x.x, x.x (fields)
+//   out_md[q * basis.n + k] as plm_launch_multidot (queries s_new, y_new, g), out_md[3 * basis.n] = s_new.s_new over the
+//   fields; out_ex[0..2] = g.dir, x.x, x.x (fields)
 hipError_t plm_launch_sy_multidot(float *s_new, float *y_new, const float *x, const float *xp, const float *g, const float *gp,
                                   const float *dir, const PlmVecList &basis, int64_t n, int64_t nh, double *scratch,
                                   double *out_md, double *out_ex, const float *dinv, unsigned wq, unsigned long long wb,

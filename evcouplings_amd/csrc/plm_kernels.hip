@@ -3693,7 +3693,7 @@ __global__ __launch_bounds__(256) void k_sy_multidot(PlmSyDot A, double *__restr
 #pragma unroll
     for (int e = 0; e < 4; e++) wsp[e] = spos[e] >= 0 && ((A.wb >> spos[e]) & 1ull);
     const bool any_w = A.dinv != nullptr && A.wq != 0;
-    double acc[3][SYD_OLD], sp[3][4], ex[3] = {0, 0, 0};
+    double acc[3][SYD_OLD], sp[3][4], ex[3] = {0, 0, 0}, ssh = 0;      // ssh: s.s over the fields
 #pragma unroll
     for (int q = 0; q < 3; q++) {
 #pragma unroll
@@ -3738,7 +3738,10 @@ __global__ __launch_bounds__(256) void k_sy_multidot(PlmSyDot A, double *__restr
             ex[0] += dot4(gv, A.dir[i]);
             const double x2 = dot4(xv, xv);
             ex[1] += x2;
-            if (i < A.nh4) ex[2] += x2;
+            if (i < A.nh4) {
+                ex[2] += x2;
+                ssh += dot4(qv[0], qv[0]);
+            }
         }
     }
 #pragma unroll
@@ -3759,10 +3762,15 @@ __global__ __launch_bounds__(256) void k_sy_multidot(PlmSyDot A, double *__restr
             if (threadIdx.x == 0 && spos[e] >= 0) scratch[((size_t)q * A.nb + spos[e]) * PLM_DOT_BLOCKS + blockIdx.x] = t;
             __syncthreads();
         }
+    {
+        const double t = block_reduce_sum(ssh, red);
+        if (threadIdx.x == 0) scratch[((size_t)3 * A.nb) * PLM_DOT_BLOCKS + blockIdx.x] = t;
+        __syncthreads();
+    }
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         const double t = block_reduce_sum(ex[e], red);
-        if (threadIdx.x == 0) scratch[((size_t)3 * A.nb + e) * PLM_DOT_BLOCKS + blockIdx.x] = t;
+        if (threadIdx.x == 0) scratch[((size_t)3 * A.nb + 1 + e) * PLM_DOT_BLOCKS + blockIdx.x] = t;
         __syncthreads();
     }
 }
@@ -3799,6 +3807,6 @@ hipError_t plm_launch_sy_multidot(float *s_new, float *y_new, const float *x, co
     }
     const dim3 grid(PLM_DOT_BLOCKS, std::max(1, (A.n_old + SYD_OLD - 1) / SYD_OLD)), block(256);
     hipLaunchKernelGGL(k_sy_multidot, grid, block, 0, st, A, scratch);
-    hipLaunchKernelGGL(k_dots_final2, dim3(3 * basis.n + 3), dim3(256), 0, st, scratch, out_md, 3 * basis.n, out_ex);
+    hipLaunchKernelGGL(k_dots_final2, dim3(3 * basis.n + 4), dim3(256), 0, st, scratch, out_md, 3 * basis.n + 1, out_ex);
     return hipGetLastError();
 }
