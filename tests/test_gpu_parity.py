@@ -1538,3 +1538,16 @@ def test_history_sizes_and_the_diagonal_metric_reach_the_same_optimum(plm, kw):
     assert r["status"] == 0, (kw, r["status_msg"])
     assert abs(r["fx"] - ref["fx"]) <= 1e-7 * abs(ref["fx"]), (kw, r["fx"], ref["fx"])
     assert np.abs(r["cn"] - ref["cn"]).max() <= 2e-3 * np.abs(ref["cn"]).max(), kw
+
+
+def test_deep_alignment_keeps_its_curvature_pairs(plm):
+    """N = 300 000 sequences on 64 sites (N_eff 283 000).  Under variable projection the field part of s -- the change of the
+    optimal fields, at this depth mostly gradient noise along their softmax-gauge direction (curvature 2 lambda_h) -- is
+    orders of magnitude larger than the coupling part; the admission rule for curvature pairs, cos(s, y) >= 1e-3, looked at
+    the whole s until round 6, threw away every pair of the tail and left plain gradient steps: 1281 iterations / 2056
+    evaluations on this alignment (N = 500 000 x 300 never met the stop rule).  With the rule on the coupling part: 676 / 700."""
+    msa, _ = synthetic_msa(300000, 64, seed=300064)
+    r = plm.fit(msa, q=Q, max_iter=3000, epsilon=1e-3, want_fij=False)
+    assert r["status"] == 0, r["status_msg"]
+    assert r["iters"] <= 900, (r["iters"], r["n_evals"])
+    assert r["n_evals"] <= 1.1 * r["iters"], (r["iters"], r["n_evals"])      # one trial per iteration, a few exceptions
